@@ -1,0 +1,133 @@
+"""ctypes binding of libcsmri_hip.so (C-ABI declared in include/csmri_hip.h).
+
+The library is the product; there is NO fallback.  Importing this module without
+the built shared object raises, and every entry point raises RuntimeError on a
+non-zero status.  Build with ``python __graft_entry__.py`` (or ``make -C csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcsmri_hip.so')
+
+F32, BF16 = 0, 1
+BORDER_ZERO, BORDER_REFLECT = 0, 1
+
+if not os.path.exists(LIB_PATH):
+  raise ImportError('libcsmri_hip.so not found at %s -- build it first '
+                    '(python __graft_entry__.py); there is no CPU fallback' % LIB_PATH)
+_lib = C.CDLL(LIB_PATH)
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+
+class GConvDesc(C.Structure):
+  _fields_ = [
+      ('dtype', i32), ('out_dtype', i32),
+      ('in0', vp), ('in1', vp),
+      ('in0_pix_stride', i32), ('in1_pix_stride', i32), ('c0', i32),
+      ('B', i32), ('Hin', i32), ('Win', i32), ('Cin', i32),
+      ('upsample', i32), ('border', i32),
+      ('TH', i32), ('TW', i32), ('in_s', i32), ('dy0', i32), ('dy_step', i32),
+      ('dx0', i32), ('dx_step', i32),
+      ('w', vp), ('Kp', i32), ('nclass', i32), ('w_class_stride', i64),
+      ('out', vp), ('out_pix_stride', i32), ('Hout_t', i32), ('Wout_t', i32),
+      ('Ho', i32), ('Wo', i32),
+      ('out_sy', i32), ('out_sx', i32), ('out_oy', i32), ('out_ox', i32),
+      ('Cout', i32),
+      ('bias', vp), ('act_slope', f32),
+      ('g_src', vp), ('g_pix_stride', i32), ('g_slope', f32), ('g_dtype', i32),
+      ('stats_partial', vp),
+      ('splitk', i32), ('slab', vp),
+  ]
+
+
+class WGradDesc(C.Structure):
+  _fields_ = [
+      ('dtype', i32),
+      ('in0', vp), ('in1', vp),
+      ('in0_pix_stride', i32), ('in1_pix_stride', i32), ('c0', i32),
+      ('B', i32), ('Hin', i32), ('Win', i32), ('Cin', i32),
+      ('upsample', i32), ('border', i32),
+      ('KH', i32), ('KW', i32), ('stride', i32), ('pad_t', i32), ('pad_l', i32),
+      ('dy', vp), ('dy_pix_stride', i32), ('Ho', i32), ('Wo', i32), ('Cout', i32),
+      ('Cin_real', i32), ('Cout_real', i32),
+      ('dw', vp), ('db', vp),
+      ('splitk', i32), ('slab', vp),
+      ('accumulate', i32),
+  ]
+
+
+_SIGS = {
+    'csmri_version': (i32, []),
+    'csmri_error_string': (C.c_char_p, [i32]),
+    'csmri_shutdown': (i32, []),
+    'csmri_gconv': (i32, [C.POINTER(GConvDesc), vp]),
+    'csmri_gconv_stats_rows': (i32, [C.POINTER(GConvDesc)]),
+    'csmri_gconv_slab_bytes': (sz, [C.POINTER(GConvDesc)]),
+    'csmri_gconv_suggest_splitk': (i32, [C.POINTER(GConvDesc)]),
+    'csmri_pack_weight_bytes': (sz, [i32, i32, i32, i32, i32, i32]),
+    'csmri_pack_weight': (i32, [i32, i32, vp, i32, i32, i32, i32, vp, C.POINTER(i32),
+                                C.POINTER(i64), vp]),
+    'csmri_wgrad': (i32, [C.POINTER(WGradDesc), vp]),
+    'csmri_wgrad_slab_bytes': (sz, [C.POINTER(WGradDesc)]),
+    'csmri_wgrad_suggest_splitk': (i32, [C.POINTER(WGradDesc)]),
+    'csmri_fold_pad_grad': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                  i32, vp, i32, f32, vp]),
+    'csmri_dc': (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
+    'csmri_dc_work_bytes': (sz, [i32, i32, i32]),
+    'csmri_nchw_to_nhwc': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),
+    'csmri_nhwc_to_nchw': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    'csmri_mask_to_u8': (i32, [vp, i32, i32, i32, vp, vp]),
+    'csmri_bn_stats_rows': (i32, [i32]),
+    'csmri_bn_stats': (i32, [i32, vp, i32, i32, i32, vp, vp]),
+    'csmri_bn_finalize': (i32, [vp, i32, i32, i32, i64, f32, f32, vp, vp, vp, vp, vp]),
+    'csmri_bn_act': (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, f32,
+                           vp, vp]),
+    'csmri_bn_bwd_reduce': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, f32,
+                                  vp, vp, vp]),
+    'csmri_bn_bwd_apply': (i32, [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32,
+                                 vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, vp]),
+    'csmri_act_bwd': (i32, [i32, vp, i32, vp, i32, vp, i32, i64, i32, f32, vp]),
+    'csmri_maxpool2': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    'csmri_maxpool2_bwd': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'csmri_complex_abs': (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
+    'csmri_complex_abs_bwd': (i32, [vp, i64, vp, i32, i32, i32, i32, vp, i32, vp]),
+    'csmri_minmax_real': (i32, [vp, i32, i64, vp, vp]),
+    'csmri_refine_combine': (i32, [vp, vp, i32, i32, vp, vp, i32, i64, vp, vp, vp]),
+    'csmri_refine_combine_bwd': (i32, [vp, vp, i32, i32, vp, vp, i32, i64, vp, i32, i32, vp,
+                                       vp]),
+    'csmri_loss': (i32, [i32, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp]),
+    'csmri_loss_work_bytes': (sz, []),
+    'csmri_loss_bwd': (i32, [i32, i32, vp, i32, vp, i32, i64, i32, i32, vp, f32, vp, i32, i32,
+                             vp]),
+    'csmri_bce_logits': (i32, [vp, i64, f32, vp, vp, vp]),
+    'csmri_bce_logits_bwd': (i32, [vp, i64, f32, vp, f32, vp, i32, vp]),
+    'csmri_psnr_mse': (i32, [vp, vp, i32, i64, vp, vp]),
+    'csmri_adam': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
+    'csmri_fill_f32': (i32, [vp, i64, f32, vp]),
+    'csmri_cast': (i32, [vp, i32, vp, i32, i64, vp]),
+}
+
+EXPORTS = sorted(_SIGS)
+
+for _name, (_res, _args) in _SIGS.items():
+  _fn = getattr(_lib, _name)          # AttributeError if the .so lacks a declared symbol
+  _fn.restype = _res
+  _fn.argtypes = _args
+
+
+def error_string(code):
+  s = _lib.csmri_error_string(code)
+  return s.decode() if s else 'code %d' % code
+
+
+def call(name, *args):
+  """Call a status-returning entry point; raise RuntimeError on failure."""
+  rc = getattr(_lib, name)(*args)
+  if rc != 0:
+    raise RuntimeError('%s failed: %s (%d)' % (name, error_string(rc), rc))
+
+
+def raw(name):
+  return getattr(_lib, name)

@@ -1,0 +1,691 @@
+"""Host-side operator layer over libcsmri_hip.so.
+
+PyTorch is used here for device memory (caching allocator), streams and the
+autograd tape only -- every tensor op on the training path below is a call into
+the C-ABI library.  Activations are NHWC tensors ``[B,H,W,Cp]`` (Cp = channels
+padded to a multiple of 8, pad channels zero) in the compute dtype
+(torch.bfloat16 or torch.float32); channel slices of wider buffers are allowed
+(``stride(3)==1``, dense in B,H,W).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib
+from .lib import F32, BF16, BORDER_ZERO, BORDER_REFLECT
+
+_EPOCH = [0]          # bumped whenever trainable weights change (optimizer step / load)
+
+
+def bump_weight_epoch():
+  _EPOCH[0] += 1
+
+
+def stream():
+  return torch.cuda.current_stream().cuda_stream
+
+
+def dt_of(t):
+  if t.dtype == torch.bfloat16:
+    return BF16
+  if t.dtype == torch.float32:
+    return F32
+  raise TypeError('unsupported dtype %s' % t.dtype)
+
+
+def torch_dtype(dt):
+  return torch.bfloat16 if dt == BF16 else torch.float32
+
+
+def pad8(c):
+  return (c + 7) // 8 * 8
+
+
+def is_nhwc(t):
+  return (t.dim() == 4 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2) and
+          t.stride(0) == t.shape[1] * t.stride(1))
+
+
+def as_nhwc(t):
+  return t if is_nhwc(t) else t.contiguous()
+
+
+def ptr(t):
+  return 0 if t is None else t.data_ptr()
+
+
+def _need_gpu(t):
+  if not t.is_cuda:
+    raise RuntimeError('csmri_hip ops need device tensors (no CPU fallback)')
+
+
+# ----------------------------------------------------------------------------
+# layout converters
+# ----------------------------------------------------------------------------
+
+
+def nchw_to_nhwc(x, dtype, cpad=None):
+  """fp32 NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] of ``dtype`` (zero padded)."""
+  _need_gpu(x)
+  x = x.contiguous().float()
+  b, c, h, w = x.shape
+  cp = pad8(c) if cpad is None else cpad
+  out = torch.empty(b, h, w, cp, dtype=dtype, device=x.device)
+  lib.call('csmri_nchw_to_nhwc', x.data_ptr(), b, c, h, w, out.data_ptr(), dt_of(out), cp, cp,
+           stream())
+  return out
+
+
+def nhwc_to_nchw(x, c_real):
+  """NHWC (any supported dtype, strided channels ok) -> fp32 NCHW [B,c_real,H,W]."""
+  _need_gpu(x)
+  x = as_nhwc(x)
+  b, h, w, _ = x.shape
+  out = torch.empty(b, c_real, h, w, dtype=torch.float32, device=x.device)
+  lib.call('csmri_nhwc_to_nchw', x.data_ptr(), dt_of(x), x.stride(2), b, c_real, h, w,
+           out.data_ptr(), stream())
+  return out
+
+
+class ToNHWC(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, dtype, cpad):
+    ctx.c = x.shape[1]
+    return nchw_to_nhwc(x, dtype, cpad)
+
+  @staticmethod
+  def backward(ctx, g):
+    return nhwc_to_nchw(g, ctx.c), None, None
+
+
+class ToNCHW(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, c_real):
+    ctx.dtype, ctx.cp = x.dtype, x.shape[3]
+    return nhwc_to_nchw(x, c_real)
+
+  @staticmethod
+  def backward(ctx, g):
+    return nchw_to_nhwc(g, ctx.dtype, ctx.cp), None
+
+
+def mask_to_u8(mask):
+  """[B,2,H,W] fp32 {0,1} -> uint8 [B,H,W]; bit-exact (integer test != 0)."""
+  _need_gpu(mask)
+  mask = mask.contiguous().float()
+  b, _, h, w = mask.shape
+  out = torch.empty(b, h, w, dtype=torch.uint8, device=mask.device)
+  lib.call('csmri_mask_to_u8', mask.data_ptr(), b, h, w, out.data_ptr(), stream())
+  return out
+
+
+# ----------------------------------------------------------------------------
+# convolution layer object (geometry + packed weights)
+# ----------------------------------------------------------------------------
+
+
+class ConvLayer(object):
+  """Geometry and packed-weight cache of one nn.Conv2d-equivalent.
+
+  ``weight``: fp32 tensor/Parameter [Cout,Cin,KH,KW] (reference layout, state-dict
+  contract).  ``pads`` = (left, right, top, bottom) as produced by the reference's
+  SAME-padding rule (models/utils.py:58-85).  ``border``: 'zero' | 'reflection'.
+  """
+
+  def __init__(self, weight, bias, stride, pads, border, dtype, upsample=False, frozen=False):
+    self.weight, self.bias = weight, bias
+    self.cout, self.cin, self.kh, self.kw = weight.shape
+    self.stride, self.pads = stride, tuple(pads)
+    self.border = BORDER_REFLECT if border == 'reflection' else BORDER_ZERO
+    self.upsample = bool(upsample)
+    self.dtype = dtype                      # torch dtype of activations / packed weights
+    self.frozen = frozen
+    self.cin_p, self.cout_p = pad8(self.cin), pad8(self.cout)
+    self._packs = {}
+    self._bias_pad = None
+    self.train_weights = True               # False: skip wgrad (e.g. D during the G backward)
+
+  # -- packs ---------------------------------------------------------------
+  def _pack(self, mode):
+    key = mode
+    ent = self._packs.get(key)
+    epoch = -1 if self.frozen else _EPOCH[0]
+    if ent is not None and ent[0] == epoch and ent[1].device == self.weight.device:
+      return ent[1], ent[2], ent[3]
+    dt = BF16 if self.dtype == torch.bfloat16 else F32
+    nbytes = lib.raw('csmri_pack_weight_bytes')(mode, dt, self.cout, self.cin, self.kh, self.kw)
+    buf = ent[1] if ent is not None and ent[1].device == self.weight.device else \
+        torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
+    kp, cs = C.c_int(0), C.c_longlong(0)
+    w = self.weight.detach()
+    assert w.is_contiguous() and w.dtype == torch.float32
+    lib.call('csmri_pack_weight', mode, dt, w.data_ptr(), self.cout, self.cin, self.kh, self.kw,
+             buf.data_ptr(), C.byref(kp), C.byref(cs), stream())
+    self._packs[key] = (epoch, buf, kp.value, cs.value)
+    return buf, kp.value, cs.value
+
+  def bias_padded(self):
+    if self.bias is None:
+      return None
+    epoch = -1 if self.frozen else _EPOCH[0]
+    if self._bias_pad is None or self._bias_pad[0] != epoch or \
+        self._bias_pad[1].device != self.bias.device:
+      bp = torch.zeros(max(self.cout_p, 128), dtype=torch.float32, device=self.bias.device)
+      bp[:self.cout].copy_(self.bias.detach())
+      self._bias_pad = (epoch, bp)
+    return self._bias_pad[1]
+
+  def out_hw(self, h, w):
+    pl, pr, pt, pb = self.pads
+    hv, wv = (2 * h, 2 * w) if self.upsample else (h, w)
+    return ((hv + pt + pb - self.kh) // self.stride + 1,
+            (wv + pl + pr - self.kw) // self.stride + 1)
+
+
+def _gconv_run(d, want_stats):
+  splitk = lib.raw('csmri_gconv_suggest_splitk')(C.byref(d))
+  if want_stats:
+    splitk = 1
+  d.splitk = splitk
+  keep = []
+  dev = torch.device('cuda', torch.cuda.current_device())
+  if splitk > 1:
+    nbytes = lib.raw('csmri_gconv_slab_bytes')(C.byref(d))
+    slab = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    d.slab = slab.data_ptr()
+    keep.append(slab)
+  stats = None
+  if want_stats:
+    rows = lib.raw('csmri_gconv_stats_rows')(C.byref(d))
+    stats = torch.empty(rows, 2, d.Cout, dtype=torch.float32, device=dev)
+    d.stats_partial = stats.data_ptr()
+  lib.call('csmri_gconv', C.byref(d), stream())
+  return stats
+
+
+def conv_forward(layer, x0, x1=None, use_bias=True, act_slope=1.0, want_stats=False,
+                 out_dtype=None):
+  """y = act(conv(pad(up(cat(x0,x1)))) + bias).  Returns (y, stats_partial|None)."""
+  _need_gpu(x0)
+  x0 = as_nhwc(x0)
+  b, h, w, c0 = x0.shape
+  cin = c0
+  if x1 is not None:
+    x1 = as_nhwc(x1)
+    assert x1.shape[:3] == x0.shape[:3] and x1.dtype == x0.dtype
+    cin += x1.shape[3]
+  assert cin == layer.cin_p, (cin, layer.cin_p)
+  assert x0.dtype == layer.dtype
+  ho, wo = layer.out_hw(h, w)
+  odt = out_dtype or layer.dtype
+  y = torch.empty(b, ho, wo, layer.cout_p, dtype=odt, device=x0.device)
+  wp, kp, _ = layer._pack(0)
+  pl, pr, pt, pb = layer.pads
+  d = lib.GConvDesc()
+  d.dtype, d.out_dtype = dt_of(x0), dt_of(y)
+  d.in0, d.in0_pix_stride = x0.data_ptr(), x0.stride(2)
+  if x1 is not None:
+    d.in1, d.in1_pix_stride, d.c0 = x1.data_ptr(), x1.stride(2), c0
+  d.B, d.Hin, d.Win, d.Cin = b, h, w, cin
+  d.upsample, d.border = int(layer.upsample), layer.border
+  d.TH, d.TW, d.in_s = layer.kh, layer.kw, layer.stride
+  d.dy0, d.dy_step, d.dx0, d.dx_step = -pt, 1, -pl, 1
+  d.w, d.Kp, d.nclass, d.w_class_stride = wp.data_ptr(), kp, 1, 0
+  d.out, d.out_pix_stride, d.Hout_t, d.Wout_t = y.data_ptr(), y.stride(2), ho, wo
+  d.Ho, d.Wo, d.out_sy, d.out_sx, d.out_oy, d.out_ox = ho, wo, 1, 1, 0, 0
+  d.Cout = layer.cout_p
+  bias = layer.bias_padded() if use_bias else None
+  d.bias = ptr(bias)
+  d.act_slope = float(act_slope)
+  stats = _gconv_run(d, want_stats)
+  return y, stats
+
+
+def conv_dgrad(layer, gy, in_hw, g_src=None, g_slope=1.0):
+  """Gradient w.r.t. the (concatenated) conv input.  gy: [B,Ho,Wo,Cout_p].
+  Returns [B,H,W,Cin_p].  Optionally multiplies by lrelu'(g_src) (producer's
+  activation) on the way out."""
+  gy = as_nhwc(gy)
+  b, ho, wo, cg = gy.shape
+  assert cg == layer.cout_p and gy.dtype == layer.dtype
+  h, w = in_hw
+  pl, pr, pt, pb = layer.pads
+  dev = gy.device
+  d = lib.GConvDesc()
+  d.dtype = d.out_dtype = dt_of(gy)
+  d.in0, d.in0_pix_stride = gy.data_ptr(), gy.stride(2)
+  d.B, d.Hin, d.Win, d.Cin = b, ho, wo, layer.cout_p
+  d.upsample, d.border = 0, BORDER_ZERO
+  d.in_s = 1
+  d.Cout = layer.cin_p
+  d.act_slope = 1.0
+  direct = layer.border == BORDER_ZERO and not layer.upsample
+  if layer.stride == 1:
+    wp, kp, _ = layer._pack(1)
+    d.w, d.Kp, d.nclass, d.w_class_stride = wp.data_ptr(), kp, 1, 0
+    d.TH, d.TW = layer.kh, layer.kw
+    d.dy_step = d.dx_step = -1
+    if direct:
+      out = torch.empty(b, h, w, layer.cin_p, dtype=gy.dtype, device=dev)
+      d.dy0, d.dx0 = pt, pl
+      d.Ho, d.Wo, d.Hout_t, d.Wout_t = h, w, h, w
+      if g_src is not None:
+        g_src = as_nhwc(g_src)
+        d.g_src, d.g_pix_stride, d.g_slope, d.g_dtype = g_src.data_ptr(), g_src.stride(2), g_slope, dt_of(g_src)
+    else:
+      hv, wv = (2 * h, 2 * w) if layer.upsample else (h, w)
+      hp, wpad = hv + pt + pb, wv + pl + pr
+      out = torch.empty(b, hp, wpad, layer.cin_p, dtype=gy.dtype, device=dev)
+      d.dy0 = d.dx0 = 0
+      d.Ho, d.Wo, d.Hout_t, d.Wout_t = hp, wpad, hp, wpad
+    d.out_sy = d.out_sx = 1
+    d.out_oy = d.out_ox = 0
+  elif layer.stride == 2:
+    if direct or layer.upsample or layer.kh % 2 or layer.kw % 2:
+      raise RuntimeError('csmri_hip: stride-2 dgrad implemented for even kernels with reflection padding')
+    wp, kp, cs = layer._pack(2)
+    d.w, d.Kp, d.nclass, d.w_class_stride = wp.data_ptr(), kp, 4, cs
+    d.TH, d.TW = layer.kh // 2, layer.kw // 2
+    d.dy_step = d.dx_step = -1
+    d.dy0 = d.dx0 = 0
+    hp, wpad = h + pt + pb, w + pl + pr
+    assert hp % 2 == 0 and wpad % 2 == 0
+    out = torch.empty(b, hp, wpad, layer.cin_p, dtype=gy.dtype, device=dev)
+    d.Ho, d.Wo, d.Hout_t, d.Wout_t = hp // 2, wpad // 2, hp, wpad
+    d.out_sy = d.out_sx = 2
+    d.out_oy = d.out_ox = 0
+  else:
+    raise RuntimeError('unsupported stride')
+  d.out, d.out_pix_stride = out.data_ptr(), out.stride(2)
+  _gconv_run(d, False)
+  if direct:
+    return out
+  dx = torch.empty(b, h, w, layer.cin_p, dtype=gy.dtype, device=dev)
+  gs = as_nhwc(g_src) if g_src is not None else None
+  lib.call('csmri_fold_pad_grad', dt_of(out), out.data_ptr(), dx.data_ptr(), dx.stride(2), b, h, w,
+           layer.cin_p, pt, pb, pl, pr, int(layer.upsample), ptr(gs),
+           gs.stride(2) if gs is not None else 0, float(g_slope), stream())
+  return dx
+
+
+def conv_wgrad(layer, x0, x1, gy, accumulate=True):
+  """Accumulates dW (and db) into layer.weight.grad / layer.bias.grad (fp32)."""
+  x0 = as_nhwc(x0)
+  gy = as_nhwc(gy)
+  b, h, w, c0 = x0.shape
+  _, ho, wo, _ = gy.shape
+  wgt = layer.weight
+  if wgt.grad is None:
+    wgt.grad = torch.zeros_like(wgt)
+  if layer.bias is not None and layer.bias.grad is None:
+    layer.bias.grad = torch.zeros_like(layer.bias)
+  pl, pr, pt, pb = layer.pads
+  d = lib.WGradDesc()
+  d.dtype = dt_of(x0)
+  d.in0, d.in0_pix_stride = x0.data_ptr(), x0.stride(2)
+  if x1 is not None:
+    x1 = as_nhwc(x1)
+    d.in1, d.in1_pix_stride, d.c0 = x1.data_ptr(), x1.stride(2), c0
+  d.B, d.Hin, d.Win, d.Cin = b, h, w, layer.cin_p
+  d.upsample, d.border = int(layer.upsample), layer.border
+  d.KH, d.KW, d.stride, d.pad_t, d.pad_l = layer.kh, layer.kw, layer.stride, pt, pl
+  d.dy, d.dy_pix_stride, d.Ho, d.Wo, d.Cout = gy.data_ptr(), gy.stride(2), ho, wo, layer.cout_p
+  d.Cin_real, d.Cout_real = layer.cin, layer.cout
+  assert wgt.grad.is_contiguous()
+  d.dw = wgt.grad.data_ptr()
+  d.db = layer.bias.grad.data_ptr() if layer.bias is not None else 0
+  d.accumulate = int(accumulate)
+  d.splitk = lib.raw('csmri_wgrad_suggest_splitk')(C.byref(d))
+  nbytes = lib.raw('csmri_wgrad_slab_bytes')(C.byref(d))
+  slab = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)
+  d.slab = slab.data_ptr()
+  lib.call('csmri_wgrad', C.byref(d), stream())
+
+
+def act_bwd(gz, z, slope):
+  gz, z = as_nhwc(gz), as_nhwc(z)
+  b, h, w, c = z.shape
+  out = torch.empty(b, h, w, c, dtype=z.dtype, device=z.device)
+  lib.call('csmri_act_bwd', dt_of(z), gz.data_ptr(), gz.stride(2), z.data_ptr(), z.stride(2),
+           out.data_ptr(), out.stride(2), b * h * w, c, float(slope), stream())
+  return out
+
+
+class ConvAct(torch.autograd.Function):
+  """pad -> conv -> (+bias) -> LeakyReLU/ReLU, one kernel.  inputs: x0, x1|None,
+  weight, bias (the Parameters, so autograd schedules the backward)."""
+
+  @staticmethod
+  def forward(ctx, x0, x1, weight, bias, layer, act_slope, out_dtype):
+    y, _ = conv_forward(layer, x0, x1, True, act_slope, False, out_dtype)
+    ctx.layer, ctx.act_slope = layer, act_slope
+    ctx.c0 = x0.shape[3]
+    ctx.in_hw = (x0.shape[1], x0.shape[2])
+    ctx.save_for_backward(x0, x1, y)
+    ctx.w_req = weight.requires_grad
+    return y
+
+  @staticmethod
+  def backward(ctx, gy):
+    layer = ctx.layer
+    x0, x1, y = ctx.saved_tensors
+    gy = as_nhwc(gy)
+    if gy.dtype != layer.dtype:
+      gy = gy.to(layer.dtype)
+    g = act_bwd(gy, y, ctx.act_slope) if ctx.act_slope != 1.0 else gy
+    if ctx.w_req and layer.train_weights:
+      conv_wgrad(layer, x0, x1, g)
+    gx0 = gx1 = None
+    if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+      gx = conv_dgrad(layer, g, ctx.in_hw)
+      if x1 is None:
+        gx0 = gx
+      else:
+        gx0, gx1 = gx[..., :ctx.c0], gx[..., ctx.c0:]
+    return gx0, gx1, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------
+# conv + BatchNorm(train/eval) + LeakyReLU (+ Dropout2d mask)
+# ----------------------------------------------------------------------------
+
+
+class BNState(object):
+  """Affine params + running buffers of one nn.BatchNorm2d (fp32 tensors)."""
+
+  def __init__(self, weight, bias, running_mean, running_var, eps=1e-5, momentum=0.1):
+    self.weight, self.bias = weight, bias
+    self.running_mean, self.running_var = running_mean, running_var
+    self.eps, self.momentum = eps, momentum
+
+
+def _bn_forward(y, stats, bn, c_real, slope, training, dropmask):
+  b, h, w, cp = y.shape
+  dev = y.device
+  if training:
+    if stats is None:
+      rows = lib.raw('csmri_bn_stats_rows')(b * h * w)
+      stats = torch.empty(rows, 2, cp, dtype=torch.float32, device=dev)
+      lib.call('csmri_bn_stats', dt_of(y), y.data_ptr(), y.stride(2), b * h * w, cp, stats.data_ptr(),
+               stream())
+    mean = torch.empty(cp, dtype=torch.float32, device=dev)
+    invstd = torch.empty(cp, dtype=torch.float32, device=dev)
+    lib.call('csmri_bn_finalize', stats.data_ptr(), stats.shape[0], cp, c_real, b * h * w, bn.eps,
+             bn.momentum, mean.data_ptr(), invstd.data_ptr(), bn.running_mean.data_ptr(),
+             bn.running_var.data_ptr(), stream())
+  else:
+    mean = torch.zeros(cp, dtype=torch.float32, device=dev)
+    invstd = torch.zeros(cp, dtype=torch.float32, device=dev)
+    mean[:c_real] = bn.running_mean
+    invstd[:c_real] = torch.rsqrt(bn.running_var + bn.eps)
+  z = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
+  lib.call('csmri_bn_act', dt_of(y), y.data_ptr(), y.stride(2), z.data_ptr(), z.stride(2), b, h * w, cp,
+           c_real, mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+           float(slope), ptr(dropmask), stream())
+  return z, mean, invstd
+
+
+class ConvBnAct(torch.autograd.Function):
+  """pad -> conv(no bias) -> BatchNorm2d -> LeakyReLU -> channel dropout mask.
+
+  The conv epilogue emits per-channel partial sums (no extra pass for the batch
+  statistics); backward = two-pass BN backward, wgrad, dgrad (+ reflect fold).
+  ``dropmask``: [B,Cp] fp32 in {0, 1/(1-p)} or None."""
+
+  @staticmethod
+  def forward(ctx, x0, x1, weight, gamma, beta, layer, bn, slope, training, dropmask):
+    small = x0.shape[0] * layer.out_hw(x0.shape[1], x0.shape[2])[0] * \
+        layer.out_hw(x0.shape[1], x0.shape[2])[1] < 32768
+    y, stats = conv_forward(layer, x0, x1, False, 1.0, training and not small, None)
+    z, mean, invstd = _bn_forward(y, stats, bn, layer.cout, slope, training, dropmask)
+    ctx.layer, ctx.bn, ctx.slope, ctx.training = layer, bn, slope, training
+    ctx.c0 = x0.shape[3]
+    ctx.in_hw = (x0.shape[1], x0.shape[2])
+    ctx.save_for_backward(x0, x1, y, z, mean, invstd, dropmask)
+    ctx.w_req = weight.requires_grad
+    return z
+
+  @staticmethod
+  def backward(ctx, gz):
+    layer, bn = ctx.layer, ctx.bn
+    x0, x1, y, z, mean, invstd, dropmask = ctx.saved_tensors
+    if not ctx.training:
+      raise RuntimeError('backward through eval-mode BatchNorm is not on the training path')
+    gz = as_nhwc(gz)
+    if gz.dtype != layer.dtype:
+      gz = gz.to(layer.dtype)
+    b, h, w, cp = y.shape
+    dev = y.device
+    rows = lib.raw('csmri_bn_stats_rows')(b * h * w)
+    partial = torch.empty(rows + 1, 2, cp, dtype=torch.float32, device=dev)
+    lib.call('csmri_bn_bwd_reduce', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
+             z.data_ptr(), z.stride(2), b, h * w, cp, mean.data_ptr(), invstd.data_ptr(),
+             float(ctx.slope), ptr(dropmask), partial.data_ptr(), stream())
+    gy = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
+    want_affine = ctx.w_req and layer.train_weights
+    if want_affine:
+      if bn.weight.grad is None:
+        bn.weight.grad = torch.zeros_like(bn.weight)
+      if bn.bias.grad is None:
+        bn.bias.grad = torch.zeros_like(bn.bias)
+    lib.call('csmri_bn_bwd_apply', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
+             z.data_ptr(), z.stride(2), gy.data_ptr(), gy.stride(2), b, h * w, cp, layer.cout,
+             mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), float(ctx.slope), ptr(dropmask),
+             partial.data_ptr(), rows,
+             bn.weight.grad.data_ptr() if want_affine else 0,
+             bn.bias.grad.data_ptr() if want_affine else 0, 1, stream())
+    if want_affine:
+      conv_wgrad(layer, x0, x1, gy)
+    gx0 = gx1 = None
+    if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+      gx = conv_dgrad(layer, gy, ctx.in_hw)
+      if x1 is None:
+        gx0 = gx
+      else:
+        gx0, gx1 = gx[..., :ctx.c0], gx[..., ctx.c0:]
+    return gx0, gx1, None, None, None, None, None, None, None, None
+
+
+class MaxPool2(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    x = as_nhwc(x)
+    b, h, w, c = x.shape
+    y = torch.empty(b, h // 2, w // 2, c, dtype=x.dtype, device=x.device)
+    arg = torch.empty(b, h // 2, w // 2, c, dtype=torch.uint8, device=x.device)
+    lib.call('csmri_maxpool2', dt_of(x), x.data_ptr(), x.stride(2), y.data_ptr(), y.stride(2),
+             arg.data_ptr(), b, h, w, c, stream())
+    ctx.save_for_backward(arg)
+    ctx.shape = (b, h, w, c)
+    return y
+
+  @staticmethod
+  def backward(ctx, gy):
+    arg, = ctx.saved_tensors
+    b, h, w, c = ctx.shape
+    gy = as_nhwc(gy)
+    gx = torch.empty(b, h, w, c, dtype=gy.dtype, device=gy.device)
+    lib.call('csmri_maxpool2_bwd', dt_of(gy), gy.data_ptr(), gy.stride(2), arg.data_ptr(),
+             gx.data_ptr(), gx.stride(2), b, h, w, c, stream())
+    return gx
+
+
+# ----------------------------------------------------------------------------
+# data consistency
+# ----------------------------------------------------------------------------
+
+
+def dc_raw(x, k0, mask_u8, pad_dtype=None):
+  """x, k0: interleaved complex fp32 [B,H,W,2]; mask uint8 [B,H,W]."""
+  _need_gpu(x)
+  assert x.is_contiguous() and x.dtype == torch.float32 and x.shape[3] == 2
+  b, h, w, _ = x.shape
+  out = torch.empty_like(x)
+  out_pad = None
+  if pad_dtype is not None:
+    out_pad = torch.empty(b, h, w, 8, dtype=pad_dtype, device=x.device)
+  lib.call('csmri_dc', x.data_ptr(), ptr(k0), mask_u8.data_ptr(), out.data_ptr(), ptr(out_pad),
+           dt_of(out_pad) if out_pad is not None else 0, 0, b, h, w, stream())
+  return out, out_pad
+
+
+class DataConsistency(torch.autograd.Function):
+  """out = orthoIFFT2((1-m) orthoFFT2(x) + k0); backward = adjoint (k0 := 0).
+  Returns (out fp32 [B,H,W,2], out_pad [B,H,W,8] in pad_dtype or None)."""
+
+  @staticmethod
+  def forward(ctx, x, k0, mask_u8, pad_dtype):
+    out, out_pad = dc_raw(x.contiguous(), k0, mask_u8, pad_dtype)
+    ctx.save_for_backward(mask_u8)
+    ctx.has_pad = out_pad is not None
+    if out_pad is None:
+      return out
+    ctx.mark_non_differentiable(out_pad)
+    return out, out_pad
+
+  @staticmethod
+  def backward(ctx, g, *unused):
+    mask_u8, = ctx.saved_tensors
+    gx, _ = dc_raw(g.contiguous().float(), None, mask_u8, None)
+    return gx, None, None, None
+
+
+# ----------------------------------------------------------------------------
+# complex magnitude, refinement combine, losses, metric, optimizer
+# ----------------------------------------------------------------------------
+
+
+class ComplexAbs(torch.autograd.Function):
+  """|x| of interleaved complex fp32 [B,H,W,2] -> NHWC [B,H,W,8] of ``dtype``.
+  mode 0: channel 0 = |x|; mode 3: channels 0..2 = (|x|-mean_c)/std_c (VGG input)."""
+
+  @staticmethod
+  def forward(ctx, x, dtype, mode):
+    assert x.is_contiguous() and x.dtype == torch.float32
+    b, h, w, _ = x.shape
+    out = torch.empty(b, h, w, 8, dtype=dtype, device=x.device)
+    lib.call('csmri_complex_abs', x.data_ptr(), b * h * w, out.data_ptr(), dt_of(out), 8, 8, mode,
+             stream())
+    ctx.save_for_backward(x)
+    ctx.mode = mode
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    x, = ctx.saved_tensors
+    g = as_nhwc(g)
+    b, h, w, _ = x.shape
+    dx = torch.empty_like(x)
+    lib.call('csmri_complex_abs_bwd', x.data_ptr(), b * h * w, g.data_ptr(), dt_of(g), g.stride(2),
+             3 if ctx.mode == 3 else 1, ctx.mode, dx.data_ptr(), 0, stream())
+    return dx, None, None
+
+
+class RefineCombine(torch.autograd.Function):
+  """RefinementWrapper 'real-penalty-add' tail (refinement_wrapper.py:169-194):
+  pred = cat(unscale(scale(pre_real) + s*u), pre_imag).  pre: fp32 [B,H,W,2]
+  (no grad), u: NHWC [B,H,W,8] channel 0, scale: fp32 [1].
+  Returns (pred [B,H,W,2] fp32, scaled [B,H,W] fp32)."""
+
+  @staticmethod
+  def forward(ctx, pre, u, scale):
+    b, h, w, _ = pre.shape
+    u = as_nhwc(u)
+    mm = torch.empty(b, 2, dtype=torch.float32, device=pre.device)
+    lib.call('csmri_minmax_real', pre.data_ptr(), b, h * w, mm.data_ptr(), stream())
+    pred = torch.empty_like(pre)
+    scaled = torch.empty(b, h, w, dtype=torch.float32, device=pre.device)
+    lib.call('csmri_refine_combine', pre.data_ptr(), u.data_ptr(), dt_of(u), u.stride(2),
+             scale.data_ptr(), mm.data_ptr(), b, h * w, pred.data_ptr(), scaled.data_ptr(), stream())
+    ctx.save_for_backward(u, scale, mm)
+    ctx.mark_non_differentiable(scaled)
+    return pred, scaled
+
+  @staticmethod
+  def backward(ctx, gpred, gscaled):
+    u, scale, mm = ctx.saved_tensors
+    b, h, w, cp = u.shape
+    gpred = gpred.contiguous()
+    du = torch.zeros(b, h, w, cp, dtype=u.dtype, device=u.device)
+    part = torch.empty(1026, dtype=torch.float32, device=u.device)
+    lib.call('csmri_refine_combine_bwd', gpred.data_ptr(), u.data_ptr(), dt_of(u), u.stride(2),
+             scale.data_ptr(), mm.data_ptr(), b, h * w, du.data_ptr(), dt_of(du), du.stride(2),
+             part.data_ptr(), stream())
+    return None, du, part[:1].clone()
+
+
+class MeanLoss(torch.autograd.Function):
+  """mean |a-b| (kind 0) or mean (a-b)^2 (kind 1) over the real channels of NHWC
+  tensors; b may be None (= 0) and never receives a gradient (targets detached)."""
+
+  @staticmethod
+  def forward(ctx, a, b, kind, c_real):
+    a = as_nhwc(a)
+    if b is not None:
+      b = as_nhwc(b)
+      assert b.shape == a.shape and b.dtype == a.dtype
+    bb, h, w, cp = a.shape
+    res = torch.empty(1, dtype=torch.float32, device=a.device)
+    work = torch.empty(lib.raw('csmri_loss_work_bytes')() // 8, dtype=torch.float64, device=a.device)
+    lib.call('csmri_loss', kind, dt_of(a), a.data_ptr(), a.stride(2), ptr(b),
+             b.stride(2) if b is not None else 0, bb * h * w, c_real, res.data_ptr(), work.data_ptr(),
+             stream())
+    ctx.save_for_backward(a, b)
+    ctx.kind, ctx.c_real = kind, c_real
+    return res.reshape(())
+
+  @staticmethod
+  def backward(ctx, g):
+    a, b = ctx.saved_tensors
+    bb, h, w, cp = a.shape
+    coeff = g.reshape(1).float().contiguous()
+    ga = torch.empty(bb, h, w, cp, dtype=a.dtype, device=a.device)
+    lib.call('csmri_loss_bwd', ctx.kind, dt_of(a), a.data_ptr(), a.stride(2), ptr(b),
+             b.stride(2) if b is not None else 0, bb * h * w, cp, ctx.c_real, coeff.data_ptr(), 1.0,
+             ga.data_ptr(), ga.stride(2), 0, stream())
+    return ga, None, None, None
+
+
+class BCELogits(torch.autograd.Function):
+  """mean BCE(sigmoid(logits), target) with torch's log clamp (adversarial_loss.py)."""
+
+  @staticmethod
+  def forward(ctx, logits, target):
+    lg = logits.contiguous().float()
+    res = torch.empty(1, dtype=torch.float32, device=lg.device)
+    lib.call('csmri_bce_logits', lg.data_ptr(), lg.numel(), float(target), 0, res.data_ptr(), stream())
+    ctx.save_for_backward(lg)
+    ctx.target = float(target)
+    return res.reshape(())
+
+  @staticmethod
+  def backward(ctx, g):
+    lg, = ctx.saved_tensors
+    coeff = g.reshape(1).float().contiguous()
+    out = torch.empty_like(lg)
+    lib.call('csmri_bce_logits_bwd', lg.data_ptr(), lg.numel(), ctx.target, coeff.data_ptr(), 1.0,
+             out.data_ptr(), 0, stream())
+    return out, None
+
+
+def sigmoid_prob(logits):
+  lg = logits.detach().contiguous().float()
+  prob = torch.empty_like(lg)
+  res = torch.empty(1, dtype=torch.float32, device=lg.device)
+  lib.call('csmri_bce_logits', lg.data_ptr(), lg.numel(), 0.0, prob.data_ptr(), res.data_ptr(), stream())
+  return prob
+
+
+def psnr_mse(pred, target):
+  """per-image MSE of clamp(|.|,0,1); pred/target interleaved complex [B,H,W,2]."""
+  b, h, w, _ = pred.shape
+  mse = torch.empty(b, dtype=torch.float32, device=pred.device)
+  lib.call('csmri_psnr_mse', pred.contiguous().data_ptr(), target.contiguous().data_ptr(), b, h * w,
+           mse.data_ptr(), stream())
+  return mse
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+  """In-place Adam on flat fp32 buffers."""
+  lib.call('csmri_adam', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
+           float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream())

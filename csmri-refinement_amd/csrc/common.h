@@ -1,0 +1,87 @@
+// Internal helpers shared by the gfx950 kernels of libcsmri_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/csmri_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define CSMRI_CHECK_ARG(cond) do { if (!(cond)) return CSMRI_E_ARG; } while (0)
+#define CSMRI_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+template <int DT> struct DTraits;
+template <> struct DTraits<CSMRI_F32> {
+  typedef float T;
+  static constexpr int ES = 4;    // element bytes
+  static constexpr int VE = 4;    // elements per 16-byte vector
+  static constexpr int BKE = 16;  // elements per 64-byte K chunk
+};
+template <> struct DTraits<CSMRI_BF16> {
+  typedef __bf16 T;
+  static constexpr int ES = 2;
+  static constexpr int VE = 8;
+  static constexpr int BKE = 32;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __uint_as_float(((unsigned int)b) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;                    // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+// typed scalar load/store by runtime dtype
+__device__ __forceinline__ float load_elem(const void* p, long long idx, int dt) {
+  if (dt == CSMRI_F32) return ((const float*)p)[idx];
+  return bf16_bits_to_f32(((const unsigned short*)p)[idx]);
+}
+__device__ __forceinline__ void store_elem(void* p, long long idx, int dt, float v) {
+  if (dt == CSMRI_F32) ((float*)p)[idx] = v;
+  else ((unsigned short*)p)[idx] = f32_to_bf16_bits(v);
+}
+
+// 4 consecutive channels
+__device__ __forceinline__ f32x4_t load4(const void* p, long long idx, int dt) {
+  f32x4_t r;
+  if (dt == CSMRI_F32) {
+    r = *(const f32x4_t*)((const float*)p + idx);
+  } else {
+    u32x2_t u = *(const u32x2_t*)((const unsigned short*)p + idx);
+    r[0] = __uint_as_float(u[0] << 16); r[1] = __uint_as_float(u[0] & 0xffff0000u);
+    r[2] = __uint_as_float(u[1] << 16); r[3] = __uint_as_float(u[1] & 0xffff0000u);
+  }
+  return r;
+}
+__device__ __forceinline__ void store4(void* p, long long idx, int dt, f32x4_t v) {
+  if (dt == CSMRI_F32) {
+    *(f32x4_t*)((float*)p + idx) = v;
+  } else {
+    u32x2_t u;
+    u[0] = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+    u[1] = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+    *(u32x2_t*)((unsigned short*)p + idx) = u;
+  }
+}
+
+__device__ __forceinline__ int reflect_idx(int u, int n) {
+  // mirror without repeating the edge (nn.ReflectionPad2d); valid for |pad| < n
+  u = u < 0 ? -u : u;
+  return u >= n ? 2 * (n - 1) - u : u;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int dtype_size(int dt) { return dt == CSMRI_F32 ? 4 : 2; }
+
+// XCD-aware tile id: blocks are dealt round-robin over the 8 XCDs, so give each
+// XCD a contiguous chunk of the tile space (bijective for any grid size).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int xcd = bid % nx, idx = bid / nx;
+  int q = nwg / nx, r = nwg % nx;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

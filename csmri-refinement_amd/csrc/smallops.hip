@@ -1,0 +1,362 @@
+// Small fused ops around the networks: complex magnitude, per-sample min/max
+// scaling of the refinement wrapper, loss reductions (deterministic two-stage),
+// BCE on logits, PSNR, Adam.  All HBM- or latency-bound.
+#include "common.h"
+
+static inline int grid_for(long long work, int threads = 256) {
+  long long b = (work + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+#define GRID_STRIDE(i, n) \
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// block-wide sum of a double (256 threads); result valid in thread 0
+__device__ double block_sum(double v) {
+  __shared__ double sh[256];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------ complex_abs ----
+__constant__ float c_vgg_mean[3] = {0.485f, 0.456f, 0.406f};
+__constant__ float c_vgg_std[3] = {0.229f, 0.224f, 0.225f};
+
+__global__ void complex_abs_kernel(const float2* x, long long npix, void* out, int dt, int ps, int Cpad,
+                                   int mode) {
+  GRID_STRIDE(p, npix) {
+    const float2 v = x[p];
+    const float a = sqrtf(v.x * v.x + v.y * v.y);
+    for (int c = 0; c < Cpad; ++c) {
+      float o = 0.f;
+      if (mode == 0) o = c == 0 ? a : 0.f;
+      else if (c < 3) o = (a - c_vgg_mean[c]) / c_vgg_std[c];
+      store_elem(out, p * ps + c, dt, o);
+    }
+  }
+}
+extern "C" int csmri_complex_abs(const float* x, long long npix, void* out, int out_dtype,
+                                 int out_pix_stride, int Cpad, int mode, void* stream) {
+  CSMRI_CHECK_ARG(x && out && (mode == 0 || mode == 3) && Cpad >= (mode == 3 ? 3 : 1));
+  hipLaunchKernelGGL(complex_abs_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)x, npix, out, out_dtype, out_pix_stride, Cpad, mode);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+// d|x|/dx = x/|x| (NaN at exactly 0, as in the reference's **0.5)
+__global__ void complex_abs_bwd_kernel(const float2* x, long long npix, const void* g, int gdt, int gps,
+                                       int nch, int mode, float2* dx, int accumulate) {
+  GRID_STRIDE(p, npix) {
+    const float2 v = x[p];
+    const float a = sqrtf(v.x * v.x + v.y * v.y);
+    float s = 0.f;
+    for (int c = 0; c < nch; ++c) {
+      float gv = load_elem(g, p * gps + c, gdt);
+      s += mode == 3 ? gv / c_vgg_std[c] : gv;
+    }
+    float2 r = make_float2(s * v.x / a, s * v.y / a);
+    if (accumulate) { float2 o = dx[p]; r.x += o.x; r.y += o.y; }
+    dx[p] = r;
+  }
+}
+extern "C" int csmri_complex_abs_bwd(const float* x, long long npix, const void* g, int g_dtype,
+                                     int g_pix_stride, int nch, int mode, float* dx, int accumulate,
+                                     void* stream) {
+  CSMRI_CHECK_ARG(x && g && dx && nch >= 1 && nch <= 3);
+  hipLaunchKernelGGL(complex_abs_bwd_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)x, npix, g, g_dtype, g_pix_stride, nch, mode, (float2*)dx, accumulate);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+// ---------------------------------------------------- refinement wrapper ----
+// one workgroup per sample: min of the real channel, then max of (x - min)
+__global__ __launch_bounds__(256) void minmax_real_kernel(const float2* x, long long HW, float* mm) {
+  __shared__ float sh[256];
+  const float2* xb = x + (size_t)blockIdx.x * HW;
+  float mn = INFINITY;
+  for (long long i = threadIdx.x; i < HW; i += 256) mn = fminf(mn, xb[i].x);
+  sh[threadIdx.x] = mn;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] = fminf(sh[threadIdx.x], sh[threadIdx.x + s]); __syncthreads(); }
+  mn = sh[0];
+  __syncthreads();
+  float mx = -INFINITY;
+  for (long long i = threadIdx.x; i < HW; i += 256) mx = fmaxf(mx, xb[i].x - mn);
+  sh[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s]); __syncthreads(); }
+  if (threadIdx.x == 0) { mm[2 * blockIdx.x] = mn; mm[2 * blockIdx.x + 1] = sh[0]; }
+}
+extern "C" int csmri_minmax_real(const float* x, int B, long long HW, float* minmax, void* stream) {
+  CSMRI_CHECK_ARG(x && minmax && B > 0);
+  hipLaunchKernelGGL(minmax_real_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float2*)x, HW, minmax);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+// same operation order as _scale/_unscale: ((x-min)/max*2-1 + s*u + 1)/2*max + min
+__global__ void refine_combine_kernel(const float2* pre, const void* u, int udt, int ups,
+                                      const float* sp, const float* mm, int B, long long HW,
+                                      float2* pred, float* scaled) {
+  const float s = sp[0];
+  GRID_STRIDE(i, (long long)B * HW) {
+    const int b = (int)(i / HW);
+    const float mn = mm[2 * b], mx = mm[2 * b + 1];
+    const float2 p = pre[i];
+    const float uv = load_elem(u, i * ups, udt);
+    float t = (p.x - mn) / mx;
+    t = t * 2.f - 1.f;
+    const float su = s * uv;
+    t = t + su;
+    t = (t + 1.f) / 2.f;
+    t = t * mx + mn;
+    pred[i] = make_float2(t, p.y);
+    if (scaled) scaled[i] = su;
+  }
+}
+extern "C" int csmri_refine_combine(const float* pre, const void* u, int u_dtype, int u_pix_stride,
+                                    const float* scale_param, const float* minmax, int B, long long HW,
+                                    float* pred, float* scaled, void* stream) {
+  CSMRI_CHECK_ARG(pre && u && scale_param && minmax && pred);
+  hipLaunchKernelGGL(refine_combine_kernel, dim3(grid_for((long long)B * HW)), dim3(256), 0,
+                     (hipStream_t)stream, (const float2*)pre, u, u_dtype, u_pix_stride, scale_param,
+                     minmax, B, HW, (float2*)pred, scaled);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+// d pred_real / d u = s*max/2 ; d pred_real / d s = u*max/2.  dscale_partial: [blocks] partials,
+// element 0 receives the total (second stage in the same launch via last-block-free 2 kernels).
+__global__ __launch_bounds__(256) void refine_combine_bwd_kernel(
+    const float2* gpred, const void* u, int udt, int ups, const float* sp, const float* mm, int B,
+    long long HW, void* du, int dudt, int dups, float* partial) {
+  const float s = sp[0];
+  double acc = 0.0;
+  GRID_STRIDE(i, (long long)B * HW) {
+    const int b = (int)(i / HW);
+    const float half_mx = mm[2 * b + 1] * 0.5f;
+    const float g = gpred[i].x;
+    const float uv = load_elem(u, i * ups, udt);
+    store_elem(du, i * dups, dudt, g * s * half_mx);
+    acc += (double)(g * uv * half_mx);
+  }
+  double tot = block_sum(acc);
+  if (threadIdx.x == 0) partial[1 + blockIdx.x] = (float)tot;
+}
+__global__ void sum_partials_kernel(float* partial, int n) {
+  // single thread: deterministic order
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = 0;
+    for (int i = 0; i < n; ++i) t += partial[1 + i];
+    partial[0] = (float)t;
+  }
+}
+extern "C" int csmri_refine_combine_bwd(const float* gpred, const void* u, int u_dtype, int u_pix_stride,
+                                        const float* scale_param, const float* minmax, int B,
+                                        long long HW, void* du, int du_dtype, int du_pix_stride,
+                                        float* dscale_partial, void* stream) {
+  CSMRI_CHECK_ARG(gpred && u && scale_param && minmax && du && dscale_partial);
+  const int blocks = grid_for((long long)B * HW);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(refine_combine_bwd_kernel, dim3(blocks), dim3(256), 0, st, (const float2*)gpred, u,
+                     u_dtype, u_pix_stride, scale_param, minmax, B, HW, du, du_dtype, du_pix_stride,
+                     dscale_partial);
+  CSMRI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, dscale_partial, blocks);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+// ------------------------------------------------------------------ losses ----
+#define LOSS_BLOCKS 512
+extern "C" size_t csmri_loss_work_bytes(void) { return (LOSS_BLOCKS + 1) * sizeof(float) * 2; }
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(int kind, int dt, const void* a, int aps,
+                                                           const void* b, int bps, long long npix,
+                                                           int C_real, float* work) {
+  const int nv = (C_real + 3) >> 2;
+  double acc = 0.0;
+  GRID_STRIDE(i, npix * nv) {
+    const int c = (int)(i % nv) * 4;
+    const long long p = i / nv;
+    if (c + 4 <= C_real) {
+      f32x4_t x = load4(a, p * aps + c, dt);
+      f32x4_t y = b ? load4(b, p * bps + c, dt) : (f32x4_t){0, 0, 0, 0};
+      for (int q = 0; q < 4; ++q) { float d = x[q] - y[q]; acc += kind == 0 ? fabsf(d) : d * d; }
+    } else {
+      for (int q = 0; c + q < C_real; ++q) {
+        float d = load_elem(a, p * aps + c + q, dt) - (b ? load_elem(b, p * bps + c + q, dt) : 0.f);
+        acc += kind == 0 ? fabsf(d) : d * d;
+      }
+    }
+  }
+  double tot = block_sum(acc);
+  if (threadIdx.x == 0) ((double*)work)[1 + blockIdx.x] = tot;
+}
+__global__ void loss_final_kernel(float* work, int n, double inv_count, float* result) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = 0;
+    for (int i = 0; i < n; ++i) t += ((double*)work)[1 + i];
+    result[0] = (float)(t * inv_count);
+  }
+}
+extern "C" int csmri_loss(int kind, int dtype, const void* a, int a_pix_stride, const void* b,
+                          int b_pix_stride, long long npix, int C_real, float* result, float* work,
+                          void* stream) {
+  CSMRI_CHECK_ARG(a && result && work && (kind == 0 || kind == 1) && npix > 0 && C_real > 0);
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = grid_for(npix * ((C_real + 3) / 4));
+  if (blocks > LOSS_BLOCKS) blocks = LOSS_BLOCKS;
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, st, kind, dtype, a, a_pix_stride,
+                     b, b_pix_stride, npix, C_real, work);
+  CSMRI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, work, blocks,
+                     1.0 / ((double)npix * (double)C_real), result);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+__global__ void loss_bwd_kernel(int kind, int dt, const void* a, int aps, const void* b, int bps,
+                                long long npix, int C, int C_real, const float* coeff, float scale,
+                                void* ga, int gaps, int accumulate) {
+  const int nv = C >> 2;
+  const float k = (coeff ? coeff[0] : 1.f) * scale;
+  GRID_STRIDE(i, npix * nv) {
+    const int c = (int)(i % nv) * 4;
+    const long long p = i / nv;
+    f32x4_t x = load4(a, p * aps + c, dt);
+    f32x4_t y = b ? load4(b, p * bps + c, dt) : (f32x4_t){0, 0, 0, 0};
+    f32x4_t g;
+    for (int q = 0; q < 4; ++q) {
+      const float d = x[q] - y[q];
+      float v = kind == 0 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+      g[q] = (c + q < C_real) ? v * k : 0.f;
+    }
+    if (accumulate) g += load4(ga, p * gaps + c, dt);
+    store4(ga, p * gaps + c, dt, g);
+  }
+}
+extern "C" int csmri_loss_bwd(int kind, int dtype, const void* a, int a_pix_stride, const void* b,
+                              int b_pix_stride, long long npix, int C, int C_real, const float* coeff,
+                              float weight, void* ga, int ga_pix_stride, int accumulate, void* stream) {
+  CSMRI_CHECK_ARG(a && ga && C % 4 == 0);
+  const float scale = weight / ((float)npix * (float)C_real);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     kind, dtype, a, a_pix_stride, b, b_pix_stride, npix, C, C_real, coeff, scale, ga,
+                     ga_pix_stride, accumulate);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+// BCE(sigmoid(l), t) with torch's log clamp at -100; one block (n is tiny: B*5*5)
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* l, long long n, float t, float* prob,
+                                                         float* result) {
+  double acc = 0;
+  for (long long i = threadIdx.x; i < n; i += 256) {
+    const float p = 1.f / (1.f + expf(-l[i]));
+    if (prob) prob[i] = p;
+    const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+    acc += (double)(-(t * lp + (1.f - t) * l1p));
+  }
+  double tot = block_sum(acc);
+  if (threadIdx.x == 0) result[0] = (float)(tot / (double)n);
+}
+extern "C" int csmri_bce_logits(const float* logits, long long n, float target, float* prob,
+                                float* result, void* stream) {
+  CSMRI_CHECK_ARG(logits && result && n > 0);
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, n, target, prob, result);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+// d/dl mean BCE = (p - t)/n (un-clamped region); matches autograd of BCE(sigmoid)
+// = (p-t)/(p(1-p)) * p(1-p)
+__global__ void bce_logits_bwd_kernel(const float* l, long long n, float t, const float* coeff, float w,
+                                      float* g, int accumulate) {
+  const float k = (coeff ? coeff[0] : 1.f) * w / (float)n;
+  GRID_STRIDE(i, n) {
+    const float p = 1.f / (1.f + expf(-l[i]));
+    const float v = (p - t) * k;
+    g[i] = accumulate ? g[i] + v : v;
+  }
+}
+extern "C" int csmri_bce_logits_bwd(const float* logits, long long n, float target, const float* coeff,
+                                    float weight, float* glogits, int accumulate, void* stream) {
+  CSMRI_CHECK_ARG(logits && glogits && n > 0);
+  hipLaunchKernelGGL(bce_logits_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits,
+                     n, target, coeff, weight, glogits, accumulate);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+// per-image MSE between clamp(|pred|,0,1) and clamp(|target|,0,1); one block per image
+__global__ __launch_bounds__(256) void psnr_mse_kernel(const float2* pred, const float2* tgt, long long HW,
+                                                       float* mse) {
+  const float2* p = pred + (size_t)blockIdx.x * HW;
+  const float2* t = tgt + (size_t)blockIdx.x * HW;
+  double acc = 0;
+  for (long long i = threadIdx.x; i < HW; i += 256) {
+    float a = fminf(fmaxf(sqrtf(p[i].x * p[i].x + p[i].y * p[i].y), 0.f), 1.f);
+    float b = fminf(fmaxf(sqrtf(t[i].x * t[i].x + t[i].y * t[i].y), 0.f), 1.f);
+    float d = a - b;
+    acc += (double)(d * d);
+  }
+  double tot = block_sum(acc);
+  if (threadIdx.x == 0) mse[blockIdx.x] = (float)(tot / (double)HW);
+}
+extern "C" int csmri_psnr_mse(const float* pred, const float* target, int B, long long HW, float* mse,
+                              void* stream) {
+  CSMRI_CHECK_ARG(pred && target && mse && B > 0);
+  hipLaunchKernelGGL(psnr_mse_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float2*)pred,
+                     (const float2*)target, HW, mse);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+// -------------------------------------------------------------------- Adam ----
+// torch.optim.Adam (2.x): denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= lr/(1-b1^t) * m/denom
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr,
+                            float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+  const float step_size = lr / bc1;
+  GRID_STRIDE(i4, (n + 3) / 4) {
+    const long long i = i4 * 4;
+    if (i + 4 <= n) {
+      f32x4_t pp = *(f32x4_t*)(p + i), gg = *(const f32x4_t*)(g + i), mm = *(f32x4_t*)(m + i), vv = *(f32x4_t*)(v + i);
+      for (int q = 0; q < 4; ++q) {
+        const float gq = gg[q] * gscale;
+        mm[q] = b1 * mm[q] + (1.f - b1) * gq;
+        vv[q] = b2 * vv[q] + (1.f - b2) * gq * gq;
+        pp[q] -= step_size * (mm[q] / (sqrtf(vv[q]) / bc2_sqrt + eps));
+      }
+      *(f32x4_t*)(p + i) = pp; *(f32x4_t*)(m + i) = mm; *(f32x4_t*)(v + i) = vv;
+    } else {
+      for (long long j = i; j < n; ++j) {
+        const float gq = g[j] * gscale;
+        m[j] = b1 * m[j] + (1.f - b1) * gq;
+        v[j] = b2 * v[j] + (1.f - b2) * gq * gq;
+        p[j] -= step_size * (m[j] / (sqrtf(v[j]) / bc2_sqrt + eps));
+      }
+    }
+  }
+}
+extern "C" int csmri_adam(float* p, const float* g, float* m, float* v, long long n, float lr,
+                          float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+  CSMRI_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return CSMRI_E_ALIGN;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                     v, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}

@@ -1,0 +1,309 @@
+// csmri_wgrad: weight gradient of a convolution as an implicit GEMM on MFMA.
+//
+//   dW[(tap,c)][n] = sum_{pixels m} Xg[m][(tap,c)] * dY[m][n]
+//
+// The reduction runs over output pixels, which is the NON-contiguous direction of
+// both NHWC operands.  MFMA fragments need K-contiguous data, so each thread loads
+// a VE x VE block (VE pixels x VE channels, 16 B per pixel), transposes it in
+// registers (v_perm_b32 for bf16, free renaming for fp32) and writes VE rows of
+// "channel-major, pixel-contiguous" data into the same swizzled LDS tile layout the
+// forward kernel uses; the MFMA loop is shared (mma_core.h).
+// Pixels are split over grid.z; every split writes an fp32 slab, a second kernel
+// sums the slabs in fixed order (deterministic) and accumulates into the fp32
+// gradient in the reference's [Cout][Cin][KH][KW] layout.
+#include "mma_core.h"
+
+struct WParams {
+  const char* in0; const char* in1; int ps0, ps1, c0;
+  int B, Hin, Win, Cin, ups, border;
+  int KH, KW, S, pt, pl;
+  const char* dy; int dyps; int Ho, Wo, Cout;
+  float* slab; int splitk; int M, NK, nsteps, steps_per_split, ptiles, qtiles;
+};
+
+template <int DT>
+__device__ __forceinline__ void transpose_block(const u32x4_t* in, u32x4_t* out) {
+  if constexpr (DT == CSMRI_BF16) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        out[c][d] = __builtin_amdgcn_perm(in[2 * d + 1][c >> 1], in[2 * d][c >> 1],
+                                          (c & 1) ? 0x07060302u : 0x05040100u);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[c][e] = in[e][c];
+  }
+}
+
+template <int DT, int BP, int BQ, int WP, int WQ>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
+  using Tr = DTraits<DT>;
+  constexpr int VE = Tr::VE, BKE = Tr::BKE, ES = Tr::ES;
+  constexpr int KC = DT == CSMRI_BF16 ? 2 : 1;
+  constexpr int PS = KC * BKE;             // pixels per K step
+  constexpr int PVEC = BP / VE, QVEC = BQ / VE;
+  constexpr int NBLK = BP + BQ;            // VE x VE blocks per step
+  constexpr int NI = (NBLK + 255) / 256;
+  constexpr int WTP = BP / WP, WTQ = BQ / WQ, FP = WTP / 16, FQ = WTQ / 16;
+  constexpr int TILE_P = BP * 64, TILE_Q = BQ * 64;
+  constexpr int BUF = KC * (TILE_P + TILE_Q);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wp = wid / WQ, wq = wid % WQ;
+  const int t = blockIdx.x;
+  const int ptile = t / p.qtiles, qtile = t - ptile * p.qtiles;
+  const int p0 = ptile * BP, q0 = qtile * BQ;
+  const int ks = blockIdx.z;
+  const int s_begin = ks * p.steps_per_split;
+  const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+  const int HoWo = p.Ho * p.Wo;
+  const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
+
+  // static block assignment
+  bool isP[NI], act[NI];
+  int cvec[NI], pg[NI], dy_[NI], dx_[NI], ci_[NI];
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int v = tid + it * 256;
+    act[it] = v < NBLK;
+    isP[it] = v < BP;
+    if (isP[it]) { cvec[it] = v % PVEC; pg[it] = v / PVEC; }
+    else { const int w = v - BP; cvec[it] = w % QVEC; pg[it] = w / QVEC; }
+    dy_[it] = 0; dx_[it] = 0; ci_[it] = 0;
+    if (isP[it]) {
+      const int col = p0 + cvec[it] * VE;
+      if (col < p.NK) {
+        const int tap = col / p.Cin;
+        ci_[it] = col - tap * p.Cin;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        dy_[it] = ky - p.pt; dx_[it] = kx - p.pl;
+      } else act[it] = false;
+    } else {
+      if (q0 + cvec[it] * VE >= p.Cout) act[it] = false;
+    }
+  }
+
+  u32x4_t blk[NI][VE];
+  auto load_step = [&](int s) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int mb = s * PS + pg[it] * VE;
+      int b = mb / HoWo, r = mb - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+        const bool mv = act[it] && (mb + e) < p.M;
+        if (mv) {
+          if (isP[it]) {
+            int u = oy * p.S + dy_[it], w = ox * p.S + dx_[it];
+            bool ok = true;
+            if (p.border == CSMRI_BORDER_REFLECT) { u = reflect_idx(u, Hv); w = reflect_idx(w, Wv); }
+            else ok = (unsigned)u < (unsigned)Hv && (unsigned)w < (unsigned)Wv;
+            if (p.ups) { u >>= 1; w >>= 1; }
+            if (ok) {
+              const size_t px = (size_t)b * p.Hin * p.Win + (size_t)u * p.Win + w;
+              const int c = ci_[it];
+              const char* src = (c < p.c0) ? p.in0 + (px * p.ps0 + c) * ES
+                                           : p.in1 + (px * p.ps1 + (c - p.c0)) * ES;
+              v = *(const u32x4_t*)src;
+            }
+          } else {
+            v = *(const u32x4_t*)(p.dy + ((size_t)(mb + e) * p.dyps + q0 + cvec[it] * VE) * ES);
+          }
+        }
+        blk[it][e] = v;
+        if (++ox == p.Wo) { ox = 0; if (++oy == p.Ho) { oy = 0; ++b; } }
+      }
+    }
+  };
+  auto store_step = [&](int buf) {
+    char* base = smem + buf * BUF;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      if (tid + it * 256 >= NBLK) continue;
+      u32x4_t tr[VE];
+      transpose_block<DT>(blk[it], tr);
+      const int kc = pg[it] >> 2, chunk = pg[it] & 3;
+      char* tile = isP[it] ? base + kc * TILE_P : base + KC * TILE_P + kc * TILE_Q;
+#pragma unroll
+      for (int c = 0; c < VE; ++c)
+        *(u32x4_t*)(tile + tile_off(cvec[it] * VE + c, chunk)) = tr[c];
+    }
+  };
+
+  MmaCore<DT, FP, FQ> core;
+  core.zero();
+  if (s_begin < s_end) {
+    load_step(s_begin);
+    store_step(0);
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+      const int cur = (s - s_begin) & 1;
+      const bool more = s + 1 < s_end;
+      if (more) load_step(s + 1);
+      const char* base = smem + cur * BUF;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+        core.step(base + kc * TILE_P, base + KC * TILE_P + kc * TILE_Q, wp * WTP, wq * WTQ, lane);
+      if (more) store_step(cur ^ 1);
+      __syncthreads();
+    }
+  }
+  const int g = lane >> 4, r16 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < FQ; ++j) {
+    const int co = q0 + wq * WTQ + j * 16 + r16;
+    if (co >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < FP; ++i) {
+      const int col = p0 + wp * WTP + i * 16 + g * 4;
+      if (col < p.NK)
+        *(f32x4_t*)(p.slab + ((size_t)ks * p.Cout + co) * p.NK + col) = core.acc[i][j];
+    }
+  }
+}
+
+__global__ void wgrad_scatter_kernel(const float* slab, int splitk, int Cout, int NK, int Cin, int KH,
+                                     int KW, int Cout_real, int Cin_real, float* dw, int accumulate) {
+  const long long total = (long long)Cout_real * Cin_real * KH * KW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int kx = (int)(i % KW);
+    long long t = i / KW;
+    const int ky = (int)(t % KH); t /= KH;
+    const int ci = (int)(t % Cin_real);
+    const int co = (int)(t / Cin_real);
+    const size_t off = (size_t)co * NK + (size_t)(ky * KW + kx) * Cin + ci;
+    float s = 0.f;
+    for (int z = 0; z < splitk; ++z) s += slab[(size_t)z * Cout * NK + off];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
+}
+
+// bias gradient: column sums of dY, two deterministic stages
+#define DB_ROWS 256
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int dt, const char* dy, int dyps, long long npix,
+                                                             int C, float* partial) {
+  // thread = channel (C <= 1024 handled by looping), block = pixel range
+  const long long chunk = (npix + gridDim.x - 1) / gridDim.x;
+  const long long a = blockIdx.x * chunk, b = min(npix, a + chunk);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (long long m = a; m < b; ++m) s += load_elem(dy, m * dyps + c, dt);
+    partial[(size_t)blockIdx.x * C + c] = s;
+  }
+}
+__global__ void colsum_final_kernel(const float* partial, int rows, int C, int C_real, float* db, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C_real) return;
+  double s = 0;
+  for (int r = 0; r < rows; ++r) s += partial[(size_t)r * C + c];
+  db[c] = accumulate ? db[c] + (float)s : (float)s;
+}
+
+struct WConfig { int BP, BQ; };
+static WConfig pick_wconfig(const csmri_wgrad_desc* d) {
+  WConfig c;
+  if (d->Cout > 64) { c.BP = 128; c.BQ = 128; }
+  else if (d->Cout > 32) { c.BP = 128; c.BQ = 64; }
+  else if (d->Cout > 16) { c.BP = 256; c.BQ = 32; }
+  else { c.BP = 256; c.BQ = 16; }
+  return c;
+}
+static int wgrad_ps(int dtype) { return dtype == CSMRI_BF16 ? 64 : 16; }
+
+extern "C" int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d) {
+  WConfig c = pick_wconfig(d);
+  const long long NK = (long long)d->KH * d->KW * d->Cin;
+  const long long tiles = (long long)cdiv(NK, c.BP) * cdiv(d->Cout, c.BQ);
+  const int nsteps = cdiv((long long)d->B * d->Ho * d->Wo, wgrad_ps(d->dtype));
+  int sk = (int)((1024 + tiles - 1) / tiles);
+  int maxsk = nsteps / 4; if (maxsk < 1) maxsk = 1;
+  if (sk > maxsk) sk = maxsk;
+  if (sk > 512) sk = 512;
+  return sk < 1 ? 1 : sk;
+}
+extern "C" size_t csmri_wgrad_slab_bytes(const csmri_wgrad_desc* d) {
+  const int sk = d->splitk > 0 ? d->splitk : 1;
+  return ((size_t)sk * d->Cout * d->KH * d->KW * d->Cin + (size_t)DB_ROWS * d->Cout) * sizeof(float);
+}
+
+template <int DT, int BP, int BQ, int WP, int WQ>
+static int launch_wgrad(const WParams& p, hipStream_t st) {
+  constexpr int KC = DT == CSMRI_BF16 ? 2 : 1;
+  constexpr int lds = 2 * KC * (BP + BQ) * 64;
+  static bool attr_set = false;
+  auto kern = wgrad_kernel<DT, BP, BQ, WP, WQ>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.ptiles * p.qtiles, 1, p.splitk), dim3(256), lds, st, p);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
+  CSMRI_CHECK_ARG(d && d->in0 && d->dy && d->dw && d->slab);
+  CSMRI_CHECK_ARG(d->dtype == CSMRI_F32 || d->dtype == CSMRI_BF16);
+  CSMRI_CHECK_ARG(d->Cin > 0 && d->Cin % 8 == 0 && d->Cout > 0 && d->Cout % 8 == 0);
+  CSMRI_CHECK_ARG(d->Cin_real > 0 && d->Cin_real <= d->Cin && d->Cout_real > 0 && d->Cout_real <= d->Cout);
+  CSMRI_CHECK_ARG(d->in0_pix_stride % 8 == 0 && d->dy_pix_stride % 8 == 0);
+  if (d->in1) CSMRI_CHECK_ARG(d->c0 > 0 && d->c0 % 8 == 0 && d->c0 < d->Cin && d->in1_pix_stride % 8 == 0);
+  if (((uintptr_t)d->in0 | (uintptr_t)d->in1 | (uintptr_t)d->dy | (uintptr_t)d->slab) & 15) return CSMRI_E_ALIGN;
+  WConfig c = pick_wconfig(d);
+  WParams p;
+  p.in0 = (const char*)d->in0; p.in1 = (const char*)d->in1; p.ps0 = d->in0_pix_stride; p.ps1 = d->in1_pix_stride;
+  p.c0 = d->in1 ? d->c0 : d->Cin;
+  p.B = d->B; p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.ups = d->upsample; p.border = d->border;
+  p.KH = d->KH; p.KW = d->KW; p.S = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
+  p.dy = (const char*)d->dy; p.dyps = d->dy_pix_stride; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.slab = d->slab; p.splitk = d->splitk > 0 ? d->splitk : 1;
+  p.M = d->B * d->Ho * d->Wo; p.NK = d->KH * d->KW * d->Cin;
+  p.nsteps = cdiv(p.M, wgrad_ps(d->dtype));
+  p.steps_per_split = cdiv(p.nsteps, p.splitk);
+  p.ptiles = cdiv(p.NK, c.BP); p.qtiles = cdiv(d->Cout, c.BQ);
+  hipStream_t st = (hipStream_t)stream;
+  // a split whose step range is empty still has to define its slab: zero everything first
+  // when the split count does not divide evenly (cheap; slabs are small next to activations)
+  if ((long long)p.steps_per_split * (p.splitk - 1) >= p.nsteps) {
+    hipError_t e = hipMemsetAsync(d->slab, 0, (size_t)p.splitk * d->Cout * p.NK * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  int rc;
+#define WG(DT_, BP_, BQ_, WP_, WQ_) rc = launch_wgrad<DT_, BP_, BQ_, WP_, WQ_>(p, st)
+  if (d->dtype == CSMRI_BF16) {
+    if (c.BQ == 128) WG(CSMRI_BF16, 128, 128, 2, 2);
+    else if (c.BQ == 64) WG(CSMRI_BF16, 128, 64, 2, 2);
+    else if (c.BQ == 32) WG(CSMRI_BF16, 256, 32, 4, 1);
+    else WG(CSMRI_BF16, 256, 16, 4, 1);
+  } else {
+    if (c.BQ == 128) WG(CSMRI_F32, 128, 128, 2, 2);
+    else if (c.BQ == 64) WG(CSMRI_F32, 128, 64, 2, 2);
+    else if (c.BQ == 32) WG(CSMRI_F32, 256, 32, 4, 1);
+    else WG(CSMRI_F32, 256, 16, 4, 1);
+  }
+#undef WG
+  if (rc != CSMRI_OK) return rc;
+  const long long total = (long long)d->Cout_real * d->Cin_real * d->KH * d->KW;
+  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(blocks), dim3(256), 0, st, d->slab, p.splitk, d->Cout, p.NK,
+                     d->Cin, d->KH, d->KW, d->Cout_real, d->Cin_real, d->dw, d->accumulate);
+  CSMRI_LAUNCH_CHECK();
+  if (d->db) {
+    float* part = d->slab + (size_t)p.splitk * d->Cout * p.NK;
+    int rows = cdiv(p.M, 512); if (rows > DB_ROWS) rows = DB_ROWS; if (rows < 1) rows = 1;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows), dim3(256), 0, st, d->dtype, p.dy, p.dyps,
+                       (long long)p.M, d->Cout, part);
+    CSMRI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout_real + 63) / 64), dim3(64), 0, st, part, rows,
+                       d->Cout, d->Cout_real, d->db, d->accumulate);
+    CSMRI_LAUNCH_CHECK();
+  }
+  return CSMRI_OK;
+}

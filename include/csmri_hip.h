@@ -1,0 +1,289 @@
+/*
+ * csmri_hip.h -- C-ABI of libcsmri_hip.so, the MI355X (gfx950) operator library
+ * behind the CS-MRI GAN-refinement training path.
+ *
+ * This is the drop-in boundary.  The reference (mseitzer/csmri-refinement) is
+ * pure Python and reaches native code only through torch.nn / pytorch_fft; each
+ * entry point below names the reference call site it replaces (path:line in the
+ * reference tree).  A Python binding (ctypes) lives in
+ * csmri-refinement_amd/csmri_hip/; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers unless named host_*.  The caller owns
+ *     every buffer including workspaces; the library allocates nothing except
+ *     cached FFT twiddle tables (freed by csmri_shutdown).
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it.
+ *   - Return value: 0 = ok, negative = CSMRI_E_* (bad argument / unsupported),
+ *     positive = hipError_t passed through.  No exceptions cross this boundary.
+ *   - Activations are NHWC ("pixel-major"): element (b,y,x,c) of a tensor lives
+ *     at base[((b*H + y)*W + x)*pix_stride + c].  pix_stride >= C allows channel
+ *     slices of wider buffers (concat without copies).  Channel counts seen by
+ *     the GEMM kernels are padded to a multiple of 8; pad channels hold zeros.
+ *   - dtype: CSMRI_F32 (exact fp32 MFMA path, v_mfma_f32_16x16x4_f32) or
+ *     CSMRI_BF16 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+ */
+#ifndef CSMRI_HIP_H
+#define CSMRI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSMRI_F32 0
+#define CSMRI_BF16 1
+
+#define CSMRI_OK 0
+#define CSMRI_E_ARG (-1)
+#define CSMRI_E_UNSUPPORTED (-2)
+#define CSMRI_E_ALIGN (-3)
+
+#define CSMRI_BORDER_ZERO 0
+#define CSMRI_BORDER_REFLECT 1
+
+/* library / device ------------------------------------------------------- */
+int csmri_version(void);
+const char* csmri_error_string(int code);
+int csmri_shutdown(void);
+
+/* ------------------------------------------------------------------------
+ * Gather convolution = implicit-GEMM convolution with MFMA.
+ * Replaces nn.Conv2d forward and its input-gradient, together with the
+ * padding layer in front of it (models/utils.py:58-85) and optional fused
+ * nearest x2 upsampling (models/unet.py:98), bias, LeakyReLU/ReLU
+ * (models/recnet.py:40-48, models/unet.py:48-58, models/discriminators.py:137-150,
+ * torchvision VGG19 features as used by models/vgg.py:35).
+ *
+ *   out[b, oy*out_sy+out_oy, ox*out_sx+out_ox, n] =
+ *       epilogue( sum_{ty<TH, tx<TW, c<Cin}
+ *                 in[b, Y(oy*in_s + dy0 + ty*dy_step), X(ox*in_s + dx0 + tx*dx_step), c]
+ *                 * w[n][(ty*TW+tx)*Cin + c] )
+ *   Y()/X() apply the border rule on the virtual extent (2*Hin if upsample else
+ *   Hin) -- zero: outside -> 0, reflect: mirror without edge repeat -- and then
+ *   halve the coordinate if upsample.
+ *   epilogue(v) = actgrad( act( v + bias[n] ) ):
+ *     act: v<0 ? v*act_slope : v   (act_slope = 1 -> identity, 0 -> ReLU)
+ *     actgrad: multiply by (g_src[b,y,x,n] > 0 ? 1 : g_slope) if g_src != NULL
+ *   The same routine expresses forward convs, stride-1 dgrad (flipped taps),
+ *   and stride-2 dgrad as 4 output-parity classes (nclass = 4: class z uses
+ *   weights w + z*w_class_stride and output offset (z>>1, z&1)).
+ * ---------------------------------------------------------------------- */
+typedef struct csmri_gconv_desc {
+  int dtype;                 /* CSMRI_F32 / CSMRI_BF16: type of in, w */
+  int out_dtype;             /* type of out */
+  /* input: channels [0,c0) from in0, [c0,Cin) from in1 (in1 may be NULL) */
+  const void* in0; const void* in1;
+  int in0_pix_stride, in1_pix_stride, c0;
+  int B, Hin, Win, Cin;      /* Cin: total padded input channels (multiple of 8) */
+  int upsample;              /* 1: input is virtually nearest-upsampled x2 */
+  int border;                /* CSMRI_BORDER_* */
+  /* taps */
+  int TH, TW, in_s, dy0, dy_step, dx0, dx_step;
+  /* weights: [Npad][Kp] row-major, K index = (ty*TW+tx)*Cin + c, zero padded */
+  const void* w; int Kp; int nclass; long long w_class_stride;
+  /* output */
+  void* out; int out_pix_stride; int Hout_t, Wout_t;   /* tensor extents */
+  int Ho, Wo;                /* positions computed per image (GEMM M = B*Ho*Wo) */
+  int out_sy, out_sx, out_oy, out_ox;
+  int Cout;                  /* padded output channels written (multiple of 8) */
+  /* epilogue */
+  const float* bias;         /* [Cout] or NULL */
+  float act_slope;           /* 1 = none */
+  const void* g_src; int g_pix_stride; float g_slope; /* dtype = out_dtype... see .c */
+  int g_dtype;
+  float* stats_partial;      /* NULL or [stats_rows][2][Cout]: per-wave-row sum / sumsq */
+  /* split-K */
+  int splitk;                /* >=1; >1 needs slab */
+  float* slab;               /* [splitk][M][Cout] fp32 workspace */
+} csmri_gconv_desc;
+
+int csmri_gconv(const csmri_gconv_desc* d, void* stream);
+/* rows of stats_partial written by csmri_gconv for this problem (0 if splitk>1) */
+int csmri_gconv_stats_rows(const csmri_gconv_desc* d);
+size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d);
+/* heuristic split-K factor for this shape (>=1) */
+int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d);
+
+/* Weight packing.  w_ref: fp32 [Cout][Cin][KH][KW] (nn.Conv2d layout, state-dict
+ * contract SURVEY A-12).  mode 0: forward taps; mode 1: stride-1 dgrad
+ * (roles of Cout/Cin swapped, taps kept -- the descriptor flips them with
+ * dy_step=-1); mode 2: stride-2 dgrad, 4 parity classes of (KH/2 x KW/2) taps.
+ * Output rows padded to a multiple of 128, K padded to a multiple of 64, zeros. */
+size_t csmri_pack_weight_bytes(int mode, int dtype, int Cout, int Cin, int KH, int KW);
+int csmri_pack_weight(int mode, int dtype, const float* w_ref, int Cout, int Cin,
+                      int KH, int KW, void* out, int* Kp_out, long long* class_stride_out,
+                      void* stream);
+
+/* ------------------------------------------------------------------------
+ * Weight gradient of a convolution (nn.Conv2d backward w.r.t. weight):
+ *   dW[n][c][ky][kx] += sum_{b,oy,ox} dY[b,oy,ox,n] * Xb[b, oy*s+ky-pt, ox*s+kx-pl, c]
+ * with the same border / upsample / two-source gather as csmri_gconv.
+ * Split over pixels (splitk slabs, deterministic), result accumulated into the
+ * fp32 reference-layout gradient.  db (bias grad) optional.
+ * ---------------------------------------------------------------------- */
+typedef struct csmri_wgrad_desc {
+  int dtype;                 /* type of x and dy */
+  const void* in0; const void* in1;
+  int in0_pix_stride, in1_pix_stride, c0;
+  int B, Hin, Win, Cin;      /* padded Cin */
+  int upsample, border;
+  int KH, KW, stride, pad_t, pad_l;
+  const void* dy; int dy_pix_stride; int Ho, Wo; int Cout; /* padded Cout */
+  int Cin_real, Cout_real;
+  float* dw;                 /* fp32 [Cout_real][Cin_real][KH][KW], accumulated into */
+  float* db;                 /* fp32 [Cout_real] accumulated into, or NULL */
+  int splitk; float* slab;   /* [splitk][CoutPad][KH*KW*Cin] fp32 */
+  int accumulate;            /* 0: overwrite dw/db, 1: add */
+} csmri_wgrad_desc;
+
+int csmri_wgrad(const csmri_wgrad_desc* d, void* stream);
+size_t csmri_wgrad_slab_bytes(const csmri_wgrad_desc* d);
+int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d);
+
+/* Fold the gradient w.r.t. a reflect-padded (and optionally x2-upsampled)
+ * tensor back onto the un-padded tensor (backward of nn.ReflectionPad2d +
+ * nn.Upsample(nearest), models/utils.py:58-72, unet.py:98) and optionally apply
+ * the activation derivative of the producer.  gpad: [B, (up?2H:H)+pt+pb,
+ * (up?2W:W)+pl+pr, C] dense; out: [B,H,W,C] with out_pix_stride. */
+int csmri_fold_pad_grad(int dtype, const void* gpad, void* out, int out_pix_stride,
+                        int B, int H, int W, int C, int pt, int pb, int pl, int pr,
+                        int upsample, const void* g_src, int g_pix_stride, float g_slope,
+                        void* stream);
+
+/* ------------------------------------------------------------------------
+ * Data consistency in k-space (fused 2-D FFT + mask merge + inverse FFT).
+ * Replaces DataConsistencyInKspace.perform, Fft2d/Ifft2d and data_consistency
+ * (data/reconstruction/deep_med_lib/my_pytorch/myfft.py:78-163):
+ *     out = orthoIFFT2( (1 - m) * orthoFFT2(x) + k0 )
+ * x, k0, out: interleaved complex fp32 [B][H][W][2]; mask: uint8 [B][H][W]
+ * (1 = sampled).  k0 == NULL gives the adjoint (backward w.r.t. x,
+ * myfft.py:92-102,119-128).  H, W in {32,64,128,256,512}.  work: 2*B*H*W*8 bytes.
+ * out_pad (optional): also write the result as a channel-padded NHWC tensor
+ * [B][H][W][8] of dtype out_pad_dtype (channels 0,1 = re,im; 2..7 = 0) -- the
+ * input layout of the next conv block.
+ * ---------------------------------------------------------------------- */
+int csmri_dc(const float* x, const float* k0, const uint8_t* mask, float* out,
+             void* out_pad, int out_pad_dtype, float* work, int B, int H, int W,
+             void* stream);
+size_t csmri_dc_work_bytes(int B, int H, int W);
+
+/* layout converters (H2D boundary: batch dict tensors are NCHW fp32,
+ * training/base_runner.py:29-41) */
+int csmri_nchw_to_nhwc(const float* src, int B, int C, int H, int W, void* dst,
+                       int dst_dtype, int dst_pix_stride, int Cpad, void* stream);
+int csmri_nhwc_to_nchw(const void* src, int src_dtype, int src_pix_stride, int B,
+                       int C, int H, int W, float* dst, void* stream);
+/* mask [B,2,H,W] fp32 {0,1} -> uint8 [B,H,W] (bit-exact; returns E_ARG semantics
+ * are checked on the host side of the binding) */
+int csmri_mask_to_u8(const float* mask_nchw, int B, int H, int W, uint8_t* dst, void* stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm2d (training) + LeakyReLU + Dropout2d mask, NHWC.
+ * Replaces nn.BatchNorm2d / nn.LeakyReLU / nn.Dropout2d as sequenced in
+ * models/unet.py:48-58,100-118 and models/discriminators.py:129-155.
+ * ---------------------------------------------------------------------- */
+/* per-channel partial sums of a tensor: partial [rows][2][C] (rows returned by
+ * csmri_bn_stats_rows) -- used when the conv epilogue did not produce them */
+int csmri_bn_stats_rows(int npix);
+int csmri_bn_stats(int dtype, const void* y, int pix_stride, int npix, int C,
+                   float* partial, void* stream);
+/* reduce partials -> mean, invstd (saved for backward); update running stats
+ * (momentum, unbiased var) when running_mean != NULL.  C_real channels. */
+int csmri_bn_finalize(const float* partial, int rows, int C, int C_real, long long count,
+                      float eps, float momentum, float* mean, float* invstd,
+                      float* running_mean, float* running_var, void* stream);
+/* z = dropmask[b,c] * lrelu( (y-mean)*invstd*gamma + beta ) ; dropmask NULL = 1.
+ * eval mode: pass running stats as mean and 1/sqrt(var+eps) as invstd. */
+int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride,
+                 int B, int HW, int C, int C_real, const float* mean, const float* invstd,
+                 const float* gamma, const float* beta, float slope,
+                 const float* dropmask, void* stream);
+/* backward, pass 1: partial sums of dyh = dz*mask*lrelu'(z) and dyh*xhat */
+int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride, const void* y,
+                        int y_pix_stride, const void* z, int z_pix_stride, int B, int HW,
+                        int C, const float* mean, const float* invstd, float slope,
+                        const float* dropmask, float* partial, void* stream);
+/* pass 2: finalize dgamma/dbeta (accumulated into fp32 grads if not NULL) and
+ * write dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)) */
+int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, const void* y,
+                       int y_pix_stride, const void* z, int z_pix_stride, void* dy,
+                       int dy_pix_stride, int B, int HW, int C, int C_real,
+                       const float* mean, const float* invstd, const float* gamma,
+                       float slope, const float* dropmask, const float* partial, int rows,
+                       float* dgamma, float* dbeta, int accumulate, void* stream);
+
+/* elementwise activation fwd/bwd with optional bias (used where no BN) */
+int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const void* z, int z_pix_stride,
+                  void* dy, int dy_pix_stride, long long npix, int C, float slope, void* stream);
+
+/* MaxPool2d(2,2) NHWC (models/unet.py:58, torchvision VGG19) */
+int csmri_maxpool2(int dtype, const void* x, int x_pix_stride, void* y, int y_pix_stride,
+                   uint8_t* argmax, int B, int H, int W, int C, void* stream);
+int csmri_maxpool2_bwd(int dtype, const void* dy, int dy_pix_stride, const uint8_t* argmax,
+                       void* dx, int dx_pix_stride, int B, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------
+ * small fused ops of the refinement wrapper / losses / optimizer
+ * ---------------------------------------------------------------------- */
+/* complex_abs (utils/tensor_transforms.py:62-75): x [B,H,W,2] fp32 -> |x| written
+ * to n_out channel-padded outputs.  mode 0: 1 real channel; mode 3: 3 equal
+ * channels normalised (v-mean[c])/std[c] (VGG input, models/vgg.py:66-72). */
+int csmri_complex_abs(const float* x, long long npix, void* out, int out_dtype,
+                      int out_pix_stride, int Cpad, int mode, void* stream);
+/* backward: dx[p] = x[p]/|x[p]| * sum_c g[p][c]*scale[c] */
+int csmri_complex_abs_bwd(const float* x, long long npix, const void* g, int g_dtype,
+                          int g_pix_stride, int nch, int mode, float* dx, int accumulate,
+                          void* stream);
+/* per-sample min and max-of-shifted of channel 0 of x [B,HW,2]:
+ * minmax[b] = (min, max(x-min))   (models/refinement_wrapper.py:51-73) */
+int csmri_minmax_real(const float* x, int B, long long HW, float* minmax, void* stream);
+/* pred = cat( unscale(scale(pre_real) + s*u), pre_imag ); scaled = s*u
+ * (models/refinement_wrapper.py:169-194).  u: [B,HW] values with pix stride. */
+int csmri_refine_combine(const float* pre, const void* u, int u_dtype, int u_pix_stride,
+                         const float* scale_param, const float* minmax, int B, long long HW,
+                         float* pred, float* scaled, void* stream);
+/* backward: du = gpred_real * s*max/2 (+ gu_extra), dscale += sum gpred_real*u*max/2 */
+int csmri_refine_combine_bwd(const float* gpred, const void* u, int u_dtype, int u_pix_stride,
+                             const float* scale_param, const float* minmax, int B,
+                             long long HW, void* du, int du_dtype, int du_pix_stride,
+                             float* dscale_partial, void* stream);
+
+/* deterministic two-stage reductions; result[0] = mean over n_real elements.
+ * kind: 0 = L1 |a-b|, 1 = MSE (a-b)^2.  b == NULL means b = 0.
+ * a, b: NHWC [npix][C] with pix strides; only channels < C_real are counted. */
+int csmri_loss(int kind, int dtype, const void* a, int a_pix_stride, const void* b,
+               int b_pix_stride, long long npix, int C_real, float* result,
+               float* work, void* stream);
+size_t csmri_loss_work_bytes(void);
+/* grad wrt a: g = coeff[0]*w * d/da ; written (or accumulated) into ga */
+int csmri_loss_bwd(int kind, int dtype, const void* a, int a_pix_stride, const void* b,
+                   int b_pix_stride, long long npix, int C, int C_real, const float* coeff,
+                   float weight, void* ga, int ga_pix_stride, int accumulate, void* stream);
+/* BCE on sigmoid(logits) with constant target t (models/adversarial_loss.py:71-98,
+ * F.binary_cross_entropy clamps log at -100): result[0] = mean. */
+int csmri_bce_logits(const float* logits, long long n, float target, float* prob,
+                     float* result, void* stream);
+int csmri_bce_logits_bwd(const float* logits, long long n, float target, const float* coeff,
+                         float weight, float* glogits, int accumulate, void* stream);
+/* PSNR (metrics/image_metrics.py:7-19 with rec_transforms.py:79-85): per image
+ * mse of clamp(|.|,0,1); out[b] = mse_b (host takes 10*log10(1/mse)). */
+int csmri_psnr_mse(const float* pred, const float* target, int B, long long HW,
+                   float* mse, void* stream);
+
+/* Adam (training/optimizers.py:19-22 -> torch.optim.Adam, eps 1e-8, no decay) on a
+ * flat fp32 parameter buffer; step is the 1-based step count. */
+int csmri_adam(float* p, const float* g, float* m, float* v, long long n, float lr,
+               float beta1, float beta2, float eps, int step, float grad_scale,
+               void* stream);
+
+/* misc */
+int csmri_fill_f32(float* p, long long n, float v, void* stream);
+int csmri_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSMRI_HIP_H */

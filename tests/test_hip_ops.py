@@ -1,0 +1,339 @@
+"""GPU parity tests of the C-ABI kernels against the CPU oracle (plain torch fp32).
+
+Tolerances: fp32 path rtol 1e-4 / atol 1e-5 (scaled by the reduction magnitude);
+bf16 path: relative L2 error <= 1e-2 (inputs and weights are rounded to bf16
+before the oracle runs so only accumulation order / output rounding differ).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import csmri_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+  import csmri_hip
+  assert torch.cuda.is_available()
+  return csmri_hip
+
+
+def to_dev_nhwc(x, dtype, cp=None):
+  """CPU NCHW fp32 -> GPU NHWC padded (built with torch only, independent of our converters)."""
+  b, c, h, w = x.shape
+  cp = cp or (c + 7) // 8 * 8
+  t = torch.zeros(b, h, w, cp, dtype=torch.float32)
+  t[..., :c] = x.permute(0, 2, 3, 1)
+  return t.to(dtype).cuda()
+
+
+def from_dev_nhwc(t, c):
+  return t.float().cpu()[..., :c].permute(0, 3, 1, 2).contiguous()
+
+
+def rel_l2(a, b):
+  return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check(name, got, ref, dtype):
+  err = rel_l2(got, ref)
+  mx = float((got - ref).abs().max())
+  print('%-40s rel_l2 %.3e  max_abs %.3e  ref_max %.3e' % (name, err, mx, float(ref.abs().max())))
+  if dtype == torch.float32:
+    assert err < 2e-5, name
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5 * max(1.0, float(ref.abs().max()))), name
+  else:
+    assert err < 1e-2, name
+
+
+CONV_CASES = [
+    # name, cin, cout, k, stride, border, upsample, H, W, B
+    ('recnet_first', 2, 32, 3, 1, 'zero', False, 32, 32, 2),
+    ('recnet_mid', 32, 32, 3, 1, 'zero', False, 32, 48, 2),
+    ('recnet_last', 32, 2, 3, 1, 'zero', False, 32, 32, 2),
+    ('unet_k4', 32, 64, 4, 1, 'reflection', False, 32, 32, 2),
+    ('unet_up', 64, 32, 4, 1, 'reflection', True, 16, 16, 2),
+    ('unet_head', 32, 1, 1, 1, 'zero', False, 32, 32, 2),
+    ('disc_s2', 16, 128, 4, 2, 'reflection', False, 32, 32, 2),
+    ('disc_first', 1, 64, 4, 2, 'reflection', False, 64, 64, 2),
+    ('disc_deep', 256, 256, 4, 1, 'reflection', False, 8, 8, 2),
+    ('disc_final', 64, 1, 4, 1, 'none', False, 8, 8, 2),
+    ('vgg', 64, 128, 3, 1, 'zero', False, 24, 40, 1),
+    ('odd_m', 8, 24, 3, 1, 'zero', False, 13, 7, 3),
+]
+
+
+def make_layer(hip, case, dtype, seed=0):
+  name, cin, cout, k, stride, border, up, h, w, b = case
+  g = torch.Generator().manual_seed(seed)
+  wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+  bias = torch.randn(cout, generator=g) * 0.1
+  x = torch.randn(b, cin, h, w, generator=g)
+  if border == 'none':
+    pads, mode = (0, 0, 0, 0), 'zero'
+  else:
+    pads, mode = O.same_padding(k, stride), border
+  if dtype == torch.bfloat16:
+    wt, x = wt.bfloat16().float(), x.bfloat16().float()
+  wd = torch.nn.Parameter(wt.clone().cuda())
+  bd = torch.nn.Parameter(bias.clone().cuda())
+  layer = hip.ops.ConvLayer(wd, bd, stride, pads, mode, dtype, upsample=up)
+  return layer, wt, bias, x, pads, mode
+
+
+def ref_conv(x, wt, bias, stride, pads, mode, up, slope):
+  if up:
+    x = F.interpolate(x, scale_factor=2, mode='nearest')
+  y = F.conv2d(O.pad2d(x, pads, mode), wt, bias, stride=stride)
+  return F.leaky_relu(y, slope) if slope != 1.0 else y
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_bwd(hip, case, dtype):
+  ops = hip.ops
+  name, cin, cout, k, stride, border, up, h, w, b = case
+  layer, wt, bias, x, pads, mode = make_layer(hip, case, dtype)
+  slope = 0.2
+  xd = to_dev_nhwc(x, dtype).requires_grad_(True)
+  y = ops.ConvAct.apply(xd, None, layer.weight, layer.bias, layer, slope, None)
+  xr = x.clone().requires_grad_(True)
+  wr = wt.clone().requires_grad_(True)
+  br = bias.clone().requires_grad_(True)
+  yr = ref_conv(xr, wr, br, stride, pads, mode, up, slope)
+  check(name + ' fwd', from_dev_nhwc(y, cout), yr.detach(), dtype)
+  # pad channels of the output must be exactly zero
+  assert float(y[..., cout:].float().abs().max()) == 0.0 if y.shape[3] > cout else True
+  g = torch.randn(yr.shape, generator=torch.Generator().manual_seed(5))
+  if dtype == torch.bfloat16:
+    g = g.bfloat16().float()
+  yr.backward(g)
+  y.backward(to_dev_nhwc(g, dtype, y.shape[3]))
+  torch.cuda.synchronize()
+  check(name + ' dgrad', from_dev_nhwc(xd.grad, cin), xr.grad, dtype)
+  check(name + ' wgrad', layer.weight.grad.cpu(), wr.grad, dtype)
+  check(name + ' bgrad', layer.bias.grad.cpu(), br.grad, dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_conv_two_source_concat(hip, dtype):
+  ops = hip.ops
+  g = torch.Generator().manual_seed(3)
+  b, h, w = 2, 16, 16
+  xa, xb = torch.randn(b, 16, h, w, generator=g), torch.randn(b, 24, h, w, generator=g)
+  wt = torch.randn(40, 40, 4, 4, generator=g) / math.sqrt(40 * 16)
+  if dtype == torch.bfloat16:
+    xa, xb, wt = xa.bfloat16().float(), xb.bfloat16().float(), wt.bfloat16().float()
+  pads = O.same_padding(4, 1)
+  layer = ops.ConvLayer(torch.nn.Parameter(wt.cuda()), None, 1, pads, 'reflection', dtype)
+  # sources are channel slices of wider buffers (pixel stride > channels)
+  wide_a = torch.zeros(b, h, w, 32, dtype=dtype, device='cuda')
+  wide_a[..., 8:24] = to_dev_nhwc(xa, dtype)
+  a = wide_a[..., 8:24].requires_grad_(True)
+  bb = to_dev_nhwc(xb, dtype).requires_grad_(True)
+  y = ops.ConvAct.apply(a, bb, layer.weight, None, layer, 1.0, None)
+  xr = torch.cat((xa, xb), 1).requires_grad_(True)
+  wr = wt.clone().requires_grad_(True)
+  yr = F.conv2d(O.pad2d(xr, pads, 'reflection'), wr)
+  check('concat fwd', from_dev_nhwc(y, 40), yr.detach(), dtype)
+  gg = torch.randn(yr.shape, generator=g)
+  if dtype == torch.bfloat16:
+    gg = gg.bfloat16().float()
+  yr.backward(gg)
+  y.backward(to_dev_nhwc(gg, dtype))
+  check('concat dgrad a', from_dev_nhwc(a.grad, 16), xr.grad[:, :16], dtype)
+  check('concat dgrad b', from_dev_nhwc(bb.grad, 24), xr.grad[:, 16:], dtype)
+  check('concat wgrad', layer.weight.grad.cpu(), wr.grad, dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 16, 32, 64, 64), (2, 64, 128, 8, 8)], ids=['stats_fused', 'stats_standalone'])
+def test_conv_bn_act(hip, dtype, shape):
+  ops = hip.ops
+  b, cin, cout, h, w = shape
+  g = torch.Generator().manual_seed(11)
+  x = torch.randn(b, cin, h, w, generator=g)
+  wt = torch.randn(cout, cin, 4, 4, generator=g) / math.sqrt(cin * 16)
+  gamma = 1 + 0.1 * torch.randn(cout, generator=g)
+  beta = 0.1 * torch.randn(cout, generator=g)
+  keep = torch.bernoulli(torch.full((b, cout), 0.5), generator=g) * 2.0
+  if dtype == torch.bfloat16:
+    x, wt = x.bfloat16().float(), wt.bfloat16().float()
+  pads = O.same_padding(4, 1)
+  layer = ops.ConvLayer(torch.nn.Parameter(wt.cuda()), None, 1, pads, 'reflection', dtype)
+  bn = ops.BNState(torch.nn.Parameter(gamma.cuda()), torch.nn.Parameter(beta.cuda()),
+                   torch.zeros(cout).cuda(), torch.ones(cout).cuda())
+  xd = to_dev_nhwc(x, dtype).requires_grad_(True)
+  z = ops.ConvBnAct.apply(xd, None, layer.weight, bn.weight, bn.bias, layer, bn, 0.2, True, keep.cuda())
+  xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+  gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+  rm, rv = torch.zeros(cout), torch.ones(cout)
+  yr = F.conv2d(O.pad2d(xr, pads, 'reflection'), wr)
+  zr = F.leaky_relu(F.batch_norm(yr, rm, rv, gr, br, True, 0.1, 1e-5), 0.2) * keep[:, :, None, None]
+  tol_dtype = dtype
+  check('bn fwd', from_dev_nhwc(z, cout), zr.detach(), tol_dtype)
+  check('bn running_mean', bn.running_mean.cpu(), rm, torch.float32 if dtype == torch.float32 else dtype)
+  check('bn running_var', bn.running_var.cpu(), rv, torch.float32 if dtype == torch.float32 else dtype)
+  gz = torch.randn(zr.shape, generator=g)
+  if dtype == torch.bfloat16:
+    gz = gz.bfloat16().float()
+  zr.backward(gz)
+  z.backward(to_dev_nhwc(gz, dtype))
+  # bf16 stores y,z rounded, so BN backward sees slightly different operands
+  lo = torch.float32 if dtype == torch.float32 else torch.bfloat16
+  check('bn dgrad', from_dev_nhwc(xd.grad, cin), xr.grad, lo)
+  check('bn wgrad', layer.weight.grad.cpu(), wr.grad, lo)
+  check('bn dgamma', bn.weight.grad.cpu(), gr.grad, lo)
+  check('bn dbeta', bn.bias.grad.cpu(), br.grad, lo)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_maxpool(hip, dtype):
+  ops = hip.ops
+  x = torch.randn(2, 16, 12, 20, generator=torch.Generator().manual_seed(2))
+  if dtype == torch.bfloat16:
+    x = x.bfloat16().float()
+  xd = to_dev_nhwc(x, dtype).requires_grad_(True)
+  y = ops.MaxPool2.apply(xd)
+  xr = x.clone().requires_grad_(True)
+  yr = F.max_pool2d(xr, 2, 2)
+  assert torch.equal(from_dev_nhwc(y, 16), yr.detach())
+  g = torch.randn(yr.shape, generator=torch.Generator().manual_seed(4))
+  if dtype == torch.bfloat16:
+    g = g.bfloat16().float()
+  yr.backward(g)
+  y.backward(to_dev_nhwc(g, dtype))
+  assert torch.equal(from_dev_nhwc(xd.grad, 16), xr.grad)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 64), (1, 256, 256), (2, 128, 64), (1, 512, 512), (3, 32, 32)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_dc(hip, shape):
+  ops = hip.ops
+  b, h, w = shape
+  g = torch.Generator().manual_seed(h * 7 + w)
+  x = torch.randn(b, 2, h, w, generator=g)
+  m2 = (torch.rand(b, 1, h, w, generator=g) < 0.3).float().expand(b, 2, h, w).contiguous()
+  k0 = torch.randn(b, 2, h, w, generator=g) * m2
+  gy = torch.randn(b, 2, h, w, generator=g)
+  ref = O.dc_layer(x.double(), k0.double(), m2.double()).float()
+  refg = O.dc_adjoint(gy.double(), m2.double()).float()
+  xd = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+  k0d = k0.permute(0, 2, 3, 1).contiguous().cuda()
+  mu8 = ops.mask_to_u8(m2.cuda())
+  assert torch.equal(mu8.cpu(), m2[:, 0].to(torch.uint8))      # integer mask: bit exact
+  out, pad = ops.DataConsistency.apply(xd, k0d, mu8, torch.bfloat16)
+  got = out.detach().cpu().permute(0, 3, 1, 2)
+  err = rel_l2(got, ref)
+  print('dc %s fwd rel_l2 %.3e max_abs %.3e' % (shape, err, float((got - ref).abs().max())))
+  assert err < 5e-6
+  assert torch.allclose(got, ref, rtol=1e-4, atol=2e-5)
+  assert torch.equal(pad[..., :2].float().cpu(), out.detach().bfloat16().float().cpu())
+  assert float(pad[..., 2:].float().abs().max()) == 0.0
+  out.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
+  gg = xd.grad.cpu().permute(0, 3, 1, 2)
+  assert rel_l2(gg, refg) < 5e-6
+  assert torch.allclose(gg, refg, rtol=1e-4, atol=2e-5)
+  # linearity + fixed point: DC(x) with k0 = mask*FFT(x) returns x
+  kx = torch.fft.fft2(torch.complex(x[:, 0], x[:, 1]), norm='ortho')
+  kx = torch.stack((kx.real, kx.imag), 1) * m2
+  out2, _ = ops.dc_raw(xd.detach(), kx.permute(0, 2, 3, 1).contiguous().cuda(), mu8)
+  assert torch.allclose(out2.cpu(), xd.detach().cpu(), atol=2e-5)
+
+
+def test_layout_roundtrip(hip):
+  ops = hip.ops
+  x = torch.randn(2, 3, 8, 12)
+  for dt in (torch.float32, torch.bfloat16):
+    t = ops.nchw_to_nhwc(x.cuda(), dt)
+    assert t.shape == (2, 8, 12, 8)
+    ref = x.to(dt).float()
+    assert torch.equal(from_dev_nhwc(t, 3), ref)
+    assert float(t[..., 3:].float().abs().max()) == 0
+    back = ops.nhwc_to_nchw(t, 3).cpu()
+    assert torch.equal(back, ref)
+
+
+def test_small_ops(hip):
+  ops = hip.ops
+  g = torch.Generator().manual_seed(9)
+  b, h, w = 2, 16, 24
+  pre = torch.randn(b, 2, h, w, generator=g)
+  u = torch.randn(b, 1, h, w, generator=g)
+  scale = torch.tensor([0.37])
+  # refinement combine vs oracle scale/unscale
+  pre_d = pre.permute(0, 2, 3, 1).contiguous().cuda()
+  ud = to_dev_nhwc(u, torch.float32).requires_grad_(True)
+  sd = scale.clone().cuda().requires_grad_(True)
+  pred, scaled = ops.RefineCombine.apply(pre_d, ud, sd)
+  ur, sr = u.clone().requires_grad_(True), scale.clone().requires_grad_(True)
+  rs, mn, mx = O.scale_minmax(pre[:, 0:1].contiguous())
+  outr = O.unscale_minmax(rs + sr * ur, mn, mx)
+  predr = torch.cat((outr, pre[:, 1:2]), 1)
+  assert torch.allclose(pred.detach().cpu().permute(0, 3, 1, 2), predr.detach(), atol=1e-6, rtol=1e-5)
+  gp = torch.randn(predr.shape, generator=g)
+  predr.backward(gp)
+  pred.backward(gp.permute(0, 2, 3, 1).contiguous().cuda())
+  assert torch.allclose(from_dev_nhwc(ud.grad, 1), ur.grad, atol=1e-6, rtol=1e-5)
+  assert torch.allclose(sd.grad.cpu(), sr.grad, atol=1e-4, rtol=1e-4)
+  # complex abs (+ VGG normalisation) fwd/bwd
+  xc = torch.randn(b, 2, h, w, generator=g)
+  xd = xc.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+  a3 = ops.ComplexAbs.apply(xd, torch.float32, 3)
+  xr = xc.clone().requires_grad_(True)
+  ar = O.complex_abs(xr)
+  mean = torch.tensor(O.VGG_MEAN).view(1, 3, 1, 1)
+  std = torch.tensor(O.VGG_STD).view(1, 3, 1, 1)
+  a3r = (torch.cat((ar, ar, ar), 1) - mean) / std
+  assert torch.allclose(from_dev_nhwc(a3, 3), a3r.detach(), atol=1e-5, rtol=1e-5)
+  g3 = torch.randn(a3r.shape, generator=g)
+  a3r.backward(g3)
+  a3.backward(to_dev_nhwc(g3, torch.float32))
+  assert torch.allclose(xd.grad.cpu().permute(0, 3, 1, 2), xr.grad, atol=1e-5, rtol=1e-4)
+  # losses
+  for kind, fn in ((0, F.l1_loss), (1, F.mse_loss)):
+    a = torch.randn(2, 5, 6, 7, generator=g)
+    bt = torch.randn(2, 5, 6, 7, generator=g)
+    ad = to_dev_nhwc(a, torch.float32).requires_grad_(True)
+    bd = to_dev_nhwc(bt, torch.float32)
+    l = ops.MeanLoss.apply(ad, bd, kind, 5)
+    ar_ = a.clone().requires_grad_(True)
+    lr = fn(ar_, bt)
+    assert abs(l.item() - lr.item()) < 1e-6
+    (l * 3.0).backward()
+    (lr * 3.0).backward()
+    assert torch.allclose(from_dev_nhwc(ad.grad, 5), ar_.grad, atol=1e-7, rtol=1e-5)
+  # BCE on logits
+  lg = torch.randn(2, 1, 5, 5, generator=g) * 3
+  for t in (0.0, 0.9, 1.0):
+    ld = lg.clone().cuda().requires_grad_(True)
+    l = ops.BCELogits.apply(ld, t)
+    lr_ = lg.clone().requires_grad_(True)
+    p = torch.sigmoid(lr_)
+    ref = F.binary_cross_entropy(p, torch.full_like(p, t))
+    assert abs(l.item() - ref.item()) < 1e-6
+    l.backward()
+    ref.backward()
+    assert torch.allclose(ld.grad.cpu(), lr_.grad, atol=1e-7, rtol=1e-4)
+  # PSNR
+  pr = torch.rand(3, 2, 16, 16, generator=g) * 1.2
+  tg = torch.rand(3, 2, 16, 16, generator=g)
+  mse = ops.psnr_mse(pr.permute(0, 2, 3, 1).contiguous().cuda(), tg.permute(0, 2, 3, 1).contiguous().cuda())
+  val = float(np.mean(10 * np.log10(1.0 / mse.cpu().double().numpy())))
+  assert abs(val - O.psnr_batch(pr, tg)) < 1e-4
+  # Adam vs torch.optim.Adam, 3 steps
+  p0 = torch.randn(1001, generator=g)
+  pt = p0.clone().requires_grad_(True)
+  opt = torch.optim.Adam([pt], 2e-4, betas=(0.5, 0.999))
+  pd, m, v = p0.clone().cuda(), torch.zeros(1001).cuda(), torch.zeros(1001).cuda()
+  for step in range(1, 4):
+    gr = torch.randn(1001, generator=g)
+    pt.grad = gr.clone()
+    opt.step()
+    ops.adam_step(pd, gr.cuda(), m, v, 2e-4, 0.5, 0.999, 1e-8, step)
+  assert torch.allclose(pd.cpu(), pt.detach(), atol=1e-7, rtol=1e-6)
