@@ -7,6 +7,11 @@ non-zero status.  Build with ``python __graft_entry__.py`` (or ``make -C csrc``)
 import ctypes as C
 import os
 
+# torch first: the library must bind to the HIP runtime torch has loaded (streams and
+# device pointers are shared with it); loading libamdhip64 on our own beforehand gives
+# this process a second runtime that sees no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libcsmri_hip.so')
 
@@ -74,7 +79,7 @@ _SIGS = {
     'csmri_wgrad_suggest_splitk': (i32, [C.POINTER(WGradDesc)]),
     'csmri_fold_pad_grad': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                   i32, vp, i32, f32, vp]),
-    'csmri_dc': (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
+    'csmri_dc': (i32, [vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
     'csmri_dc_work_bytes': (sz, [i32, i32, i32]),
     'csmri_nchw_to_nhwc': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),
     'csmri_nhwc_to_nchw': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
@@ -107,6 +112,7 @@ _SIGS = {
     'csmri_adam': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
     'csmri_fill_f32': (i32, [vp, i64, f32, vp]),
     'csmri_cast': (i32, [vp, i32, vp, i32, i64, vp]),
+    'csmri_copy_channels': (i32, [vp, i32, i32, i32, vp, i32, i32, i32, i64, vp]),
 }
 
 EXPORTS = sorted(_SIGS)

@@ -182,7 +182,35 @@ class ConvLayer(object):
             (wv + pl + pr - self.kw) // self.stride + 1)
 
 
-def _gconv_run(d, want_stats):
+PROFILE = None        # bench.py sets this to a list to collect per-launch HIP event timings
+
+
+def _tile_label(kind, dt, cout_p):
+  bn = 128 if cout_p > 64 else 64 if cout_p > 32 else 32 if cout_p > 16 else 16
+  return '%s_%s_bn%d' % (kind, 'bf16' if dt == BF16 else 'f32', bn)
+
+
+class _Timed(object):
+  """HIP-event bracket on the current stream around one library launch."""
+
+  def __init__(self, label, flops):
+    self.rec = None
+    if PROFILE is not None:
+      self.rec = (label, flops, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+  def __enter__(self):
+    if self.rec is not None:
+      self.rec[2].record()
+    return self
+
+  def __exit__(self, *exc):
+    if self.rec is not None:
+      self.rec[3].record()
+      PROFILE.append(self.rec)
+    return False
+
+
+def _gconv_run(d, want_stats, flops=0.0):
   splitk = lib.raw('csmri_gconv_suggest_splitk')(C.byref(d))
   if want_stats:
     splitk = 1
@@ -199,7 +227,8 @@ def _gconv_run(d, want_stats):
     rows = lib.raw('csmri_gconv_stats_rows')(C.byref(d))
     stats = torch.empty(rows, 2, d.Cout, dtype=torch.float32, device=dev)
     d.stats_partial = stats.data_ptr()
-  lib.call('csmri_gconv', C.byref(d), stream())
+  with _Timed(_tile_label('gconv', d.dtype, d.Cout) + ('_splitk' if splitk > 1 else ''), flops):
+    lib.call('csmri_gconv', C.byref(d), stream())
   return stats
 
 
@@ -237,7 +266,7 @@ def conv_forward(layer, x0, x1=None, use_bias=True, act_slope=1.0, want_stats=Fa
   bias = layer.bias_padded() if use_bias else None
   d.bias = ptr(bias)
   d.act_slope = float(act_slope)
-  stats = _gconv_run(d, want_stats)
+  stats = _gconv_run(d, want_stats, 2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw)
   return y, stats
 
 
@@ -297,7 +326,7 @@ def conv_dgrad(layer, gy, in_hw, g_src=None, g_slope=1.0):
   else:
     raise RuntimeError('unsupported stride')
   d.out, d.out_pix_stride = out.data_ptr(), out.stride(2)
-  _gconv_run(d, False)
+  _gconv_run(d, False, 2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw)
   if direct:
     return out
   dx = torch.empty(b, h, w, layer.cin_p, dtype=gy.dtype, device=dev)
@@ -339,7 +368,9 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
   nbytes = lib.raw('csmri_wgrad_slab_bytes')(C.byref(d))
   slab = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)
   d.slab = slab.data_ptr()
-  lib.call('csmri_wgrad', C.byref(d), stream())
+  with _Timed(_tile_label('wgrad', d.dtype, d.Cout),
+              2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw):
+    lib.call('csmri_wgrad', C.byref(d), stream())
 
 
 def act_bwd(gz, z, slope):
@@ -362,7 +393,8 @@ class ConvAct(torch.autograd.Function):
     ctx.c0 = x0.shape[3]
     ctx.in_hw = (x0.shape[1], x0.shape[2])
     ctx.save_for_backward(x0, x1, y)
-    ctx.w_req = weight.requires_grad
+    # captured at forward time: a later pass may toggle layer.train_weights
+    ctx.w_req = weight.requires_grad and layer.train_weights
     return y
 
   @staticmethod
@@ -373,7 +405,7 @@ class ConvAct(torch.autograd.Function):
     if gy.dtype != layer.dtype:
       gy = gy.to(layer.dtype)
     g = act_bwd(gy, y, ctx.act_slope) if ctx.act_slope != 1.0 else gy
-    if ctx.w_req and layer.train_weights:
+    if ctx.w_req:
       conv_wgrad(layer, x0, x1, g)
     gx0 = gx1 = None
     if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
@@ -442,7 +474,7 @@ class ConvBnAct(torch.autograd.Function):
     ctx.c0 = x0.shape[3]
     ctx.in_hw = (x0.shape[1], x0.shape[2])
     ctx.save_for_backward(x0, x1, y, z, mean, invstd, dropmask)
-    ctx.w_req = weight.requires_grad
+    ctx.w_req = weight.requires_grad and layer.train_weights
     return z
 
   @staticmethod
@@ -462,7 +494,7 @@ class ConvBnAct(torch.autograd.Function):
              z.data_ptr(), z.stride(2), b, h * w, cp, mean.data_ptr(), invstd.data_ptr(),
              float(ctx.slope), ptr(dropmask), partial.data_ptr(), stream())
     gy = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
-    want_affine = ctx.w_req and layer.train_weights
+    want_affine = ctx.w_req
     if want_affine:
       if bn.weight.grad is None:
         bn.weight.grad = torch.zeros_like(bn.weight)
@@ -515,29 +547,44 @@ class MaxPool2(torch.autograd.Function):
 # ----------------------------------------------------------------------------
 
 
+def copy_channels(x, c_dst, dtype=None):
+  """Channel slice / zero-pad / cast of an NHWC tensor into a dense [B,H,W,c_dst]."""
+  x = as_nhwc(x)
+  b, h, w, c = x.shape
+  out = torch.empty(b, h, w, c_dst, dtype=dtype or x.dtype, device=x.device)
+  lib.call('csmri_copy_channels', x.data_ptr(), dt_of(x), x.stride(2), min(c, c_dst), out.data_ptr(),
+           dt_of(out), c_dst, c_dst, b * h * w, stream())
+  return out
+
+
 def dc_raw(x, k0, mask_u8, pad_dtype=None):
-  """x, k0: interleaved complex fp32 [B,H,W,2]; mask uint8 [B,H,W]."""
+  """x: interleaved complex fp32 [B,H,W,2] or channels 0,1 of a [B,H,W,8] fp32
+  conv output; k0: dense [B,H,W,2]; mask uint8 [B,H,W].  Returns (out [B,H,W,2]
+  fp32, channel-padded copy [B,H,W,8] of pad_dtype or None)."""
   _need_gpu(x)
-  assert x.is_contiguous() and x.dtype == torch.float32 and x.shape[3] == 2
+  x = as_nhwc(x)
+  assert x.dtype == torch.float32 and x.shape[3] >= 2
   b, h, w, _ = x.shape
-  out = torch.empty_like(x)
+  out = torch.empty(b, h, w, 2, dtype=torch.float32, device=x.device)
   out_pad = None
   if pad_dtype is not None:
     out_pad = torch.empty(b, h, w, 8, dtype=pad_dtype, device=x.device)
-  lib.call('csmri_dc', x.data_ptr(), ptr(k0), mask_u8.data_ptr(), out.data_ptr(), ptr(out_pad),
-           dt_of(out_pad) if out_pad is not None else 0, 0, b, h, w, stream())
+  lib.call('csmri_dc', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
+           ptr(out_pad), dt_of(out_pad) if out_pad is not None else 0, 0, b, h, w, stream())
   return out, out_pad
 
 
 class DataConsistency(torch.autograd.Function):
   """out = orthoIFFT2((1-m) orthoFFT2(x) + k0); backward = adjoint (k0 := 0).
-  Returns (out fp32 [B,H,W,2], out_pad [B,H,W,8] in pad_dtype or None)."""
+  x may be the fp32 [B,H,W,8] output of a conv block (channels 0,1 are read in
+  place).  Returns out fp32 [B,H,W,2] and, if pad_dtype is given, the same result
+  as a channel-padded [B,H,W,8] tensor (the next conv block's input layout)."""
 
   @staticmethod
   def forward(ctx, x, k0, mask_u8, pad_dtype):
-    out, out_pad = dc_raw(x.contiguous(), k0, mask_u8, pad_dtype)
+    out, out_pad = dc_raw(x, k0, mask_u8, pad_dtype)
     ctx.save_for_backward(mask_u8)
-    ctx.has_pad = out_pad is not None
+    ctx.cx = x.shape[3]
     if out_pad is None:
       return out
     ctx.mark_non_differentiable(out_pad)
@@ -546,8 +593,11 @@ class DataConsistency(torch.autograd.Function):
   @staticmethod
   def backward(ctx, g, *unused):
     mask_u8, = ctx.saved_tensors
-    gx, _ = dc_raw(g.contiguous().float(), None, mask_u8, None)
-    return gx, None, None, None
+    g = as_nhwc(g)
+    if g.dtype != torch.float32:
+      g = copy_channels(g, 2, torch.float32)
+    gx, gpad = dc_raw(g, None, mask_u8, torch.float32 if ctx.cx == 8 else None)
+    return (gpad if ctx.cx == 8 else gx), None, None, None
 
 
 # ----------------------------------------------------------------------------

@@ -9,6 +9,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
+// Launch wrapper: clear any stale (sticky-free) error left by earlier, unrelated HIP
+// calls of the host process so that CSMRI_LAUNCH_CHECK reports THIS launch only.
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kern_, grid_, block_, lds_, stream_, ...) \
+  do { (void)hipGetLastError(); kern_<<<(grid_), (block_), (lds_), (stream_)>>>(__VA_ARGS__); } while (0)
+
 #define CSMRI_CHECK_ARG(cond) do { if (!(cond)) return CSMRI_E_ARG; } while (0)
 #define CSMRI_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 

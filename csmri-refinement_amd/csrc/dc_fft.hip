@@ -92,7 +92,7 @@ __device__ __forceinline__ void build_twiddles(float2* tw, int N, int tid) {
 
 // passes 1 and 3: FFT along W for DC_T rows per workgroup.
 __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(
-    const float2* src, float2* dst, void* out_pad, int out_pad_dt,
+    const float* src, int src_ps, float2* dst, void* out_pad, int out_pad_dt,
     int W, int sign, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float2* a = (float2*)smem;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(
   build_twiddles(tw, W, tid);
   for (int idx = tid; idx < DC_T * W; idx += DC_THREADS) {
     const int r = idx / W, n = idx - r * W;
-    a[n * DC_TP + r] = src[(row0 + r) * W + n];
+    a[n * DC_TP + r] = *(const float2*)(src + ((row0 + r) * W + n) * (size_t)src_ps);
   }
   __syncthreads();
   float2* res = fft_tile(a, b, tw, W, sign, tid);
@@ -171,11 +171,11 @@ extern "C" size_t csmri_dc_work_bytes(int B, int H, int W) {
   return 0;  // the three passes run in place on `out`
 }
 
-extern "C" int csmri_dc(const float* x, const float* k0, const uint8_t* mask, float* out,
-                        void* out_pad, int out_pad_dtype, float* work, int B, int H, int W,
-                        void* stream) {
+extern "C" int csmri_dc(const float* x, int x_pix_stride, const float* k0, const uint8_t* mask,
+                        float* out, void* out_pad, int out_pad_dtype, float* work, int B, int H,
+                        int W, void* stream) {
   (void)work;
-  CSMRI_CHECK_ARG(x && mask && out && B > 0);
+  CSMRI_CHECK_ARG(x && mask && out && B > 0 && x_pix_stride >= 2 && x_pix_stride % 2 == 0);
   if (!is_pow2_in_range(H) || !is_pow2_in_range(W)) return CSMRI_E_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)k0 | (uintptr_t)out_pad) & 15) return CSMRI_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
@@ -195,13 +195,13 @@ extern "C" int csmri_dc(const float* x, const float* k0, const uint8_t* mask, fl
   }
   const int row_blocks = B * H / DC_T, col_blocks = B * (W / DC_T);
   hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
-                     (const float2*)x, (float2*)out, (void*)nullptr, 0, W, -1, 1.0f);
+                     x, x_pix_stride, (float2*)out, (void*)nullptr, 0, W, -1, 1.0f);
   CSMRI_LAUNCH_CHECK();
   hipLaunchKernelGGL(dc_cols_kernel, dim3(col_blocks), dim3(DC_THREADS), lds_cols, st,
                      (float2*)out, (const float2*)k0, mask, H, W, scale);
   CSMRI_LAUNCH_CHECK();
   hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
-                     (const float2*)out, (float2*)out, out_pad, out_pad_dtype, W, +1, scale);
+                     (const float*)out, 2, (float2*)out, out_pad, out_pad_dtype, W, +1, scale);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -130,10 +130,21 @@ extern "C" int csmri_pack_weight(int mode, int dtype, const float* w_ref, int Co
 
 // -------------------------------------------------------------- BatchNorm ----
 // partial[row][0][c] = sum, partial[row][1][c] = sum of squares over the row's pixels
-#define BN_MAX_ROWS 512
+#define BN_MAX_ROWS 2048
 extern "C" int csmri_bn_stats_rows(int npix) {
-  int r = (npix + 255) / 256;
+  int r = (npix + 127) / 128;
   return r < 1 ? 1 : (r > BN_MAX_ROWS ? BN_MAX_ROWS : r);
+}
+
+// block-wide sum of two doubles (blockDim.x == 256); result valid in thread 0
+__device__ __forceinline__ void block_sum2(double& a, double& b) {
+  __shared__ double sa[4], sb[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sa[w] = a; sb[w] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) { a = sa[0] + sa[1] + sa[2] + sa[3]; b = sb[0] + sb[1] + sb[2] + sb[3]; }
 }
 
 // generic two-quantity per-channel partial reduction; F gives (q0, q1) per element vector
@@ -146,8 +157,10 @@ __device__ void channel_partials(long long npix, int C, int rows, float* partial
   const long long chunk = (npix + rows - 1) / rows;
   const long long p0 = blockIdx.x * chunk, p1 = min(npix, p0 + chunk);
   f32x4_t a = (f32x4_t){0, 0, 0, 0}, b = (f32x4_t){0, 0, 0, 0};
-  if (pl < lanes)
+  if (pl < lanes) {
+#pragma unroll 4
     for (long long p = p0 + pl; p < p1; p += lanes) f(p, cv * 4, a, b);
+  }
   for (int q = 0; q < 4; ++q) { red[0][threadIdx.x][q] = a[q]; red[1][threadIdx.x][q] = b[q]; }
   __syncthreads();
   if (pl == 0) {
@@ -183,10 +196,12 @@ extern "C" int csmri_bn_stats(int dtype, const void* y, int pix_stride, int npix
 __global__ void bn_finalize_kernel(const float* partial, int rows, int C, int C_real, double count,
                                    float eps, float momentum, float* mean, float* invstd,
                                    float* rmean, float* rvar) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // one 256-thread block per channel: fixed-order tree over the partial rows
+  const int c = blockIdx.x;
   double s1 = 0, s2 = 0;
-  for (int r = 0; r < rows; ++r) { s1 += partial[(size_t)r * 2 * C + c]; s2 += partial[(size_t)r * 2 * C + C + c]; }
+  for (int r = threadIdx.x; r < rows; r += 256) { s1 += partial[(size_t)r * 2 * C + c]; s2 += partial[(size_t)r * 2 * C + C + c]; }
+  block_sum2(s1, s2);
+  if (threadIdx.x != 0) return;
   const double m = s1 / count;
   double var = s2 / count - m * m;
   if (var < 0) var = 0;
@@ -202,7 +217,7 @@ extern "C" int csmri_bn_finalize(const float* partial, int rows, int C, int C_re
                                  float eps, float momentum, float* mean, float* invstd,
                                  float* running_mean, float* running_var, void* stream) {
   CSMRI_CHECK_ARG(partial && mean && invstd && rows > 0 && count > 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream,
                      partial, rows, C, C_real, (double)count, eps, momentum, mean, invstd,
                      running_mean, running_var);
   CSMRI_LAUNCH_CHECK();
@@ -279,10 +294,11 @@ extern "C" int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride,
 
 __global__ void bn_bwd_finalize_kernel(float* partial, int rows, int C, int C_real, float* dgamma,
                                        float* dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double s1 = 0, s2 = 0;
-  for (int r = 0; r < rows; ++r) { s1 += partial[(size_t)r * 2 * C + c]; s2 += partial[(size_t)r * 2 * C + C + c]; }
+  for (int r = threadIdx.x; r < rows; r += 256) { s1 += partial[(size_t)r * 2 * C + c]; s2 += partial[(size_t)r * 2 * C + C + c]; }
+  block_sum2(s1, s2);
+  if (threadIdx.x != 0) return;
   // totals go to a separate tail region [rows][2][C] -> index rows
   partial[(size_t)rows * 2 * C + c] = (float)s1;
   partial[(size_t)rows * 2 * C + C + c] = (float)s2;
@@ -325,7 +341,7 @@ extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, 
                                   float* dgamma, float* dbeta, int accumulate, void* stream) {
   CSMRI_CHECK_ARG(dz && y && z && dy && partial && rows > 0);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (float*)partial,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (float*)partial,
                      rows, C, C_real, dgamma, dbeta, accumulate);
   CSMRI_LAUNCH_CHECK();
   long long n = (long long)B * HW * (C / 4);
@@ -484,6 +500,24 @@ extern "C" int csmri_cast(const void* src, int src_dtype, void* dst, int dst_dty
   CSMRI_CHECK_ARG(src && dst);
   hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, src_dtype,
                      dst, dst_dtype, n);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+__global__ void copy_channels_kernel(const void* s, int sdt, int sps, int cs, void* d, int ddt, int dps,
+                                     int cd, long long npix) {
+  GRID_STRIDE(i, npix * cd) {
+    const int c = (int)(i % cd);
+    const long long p = i / cd;
+    store_elem(d, p * dps + c, ddt, c < cs ? load_elem(s, p * sps + c, sdt) : 0.f);
+  }
+}
+extern "C" int csmri_copy_channels(const void* src, int src_dtype, int src_pix_stride, int C_src, void* dst,
+                                   int dst_dtype, int dst_pix_stride, int C_dst, long long npix,
+                                   void* stream) {
+  CSMRI_CHECK_ARG(src && dst && C_src > 0 && C_dst > 0 && npix > 0);
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(npix * C_dst)), dim3(256), 0, (hipStream_t)stream,
+                     src, src_dtype, src_pix_stride, C_src, dst, dst_dtype, dst_pix_stride, C_dst, npix);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -169,18 +169,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
 
 __global__ void wgrad_scatter_kernel(const float* slab, int splitk, int Cout, int NK, int Cin, int KH,
                                      int KW, int Cout_real, int Cin_real, float* dw, int accumulate) {
-  const long long total = (long long)Cout_real * Cin_real * KH * KW;
+  // iterate in slab order (channel fastest) so the split-K reads coalesce; the
+  // scattered fp32 write into [Cout][Cin][KH][KW] is the small side
+  const long long total = (long long)Cout_real * NK;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int kx = (int)(i % KW);
-    long long t = i / KW;
-    const int ky = (int)(t % KH); t /= KH;
-    const int ci = (int)(t % Cin_real);
-    const int co = (int)(t / Cin_real);
-    const size_t off = (size_t)co * NK + (size_t)(ky * KW + kx) * Cin + ci;
-    float s = 0.f;
-    for (int z = 0; z < splitk; ++z) s += slab[(size_t)z * Cout * NK + off];
-    dw[i] = accumulate ? dw[i] + s : s;
+    const int co = (int)(i / NK), k = (int)(i - (long long)co * NK);
+    const int tap = k / Cin, ci = k - tap * Cin;
+    if (ci >= Cin_real) continue;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* p = slab + i;
+    const size_t zs = (size_t)Cout * NK;
+    int z = 0;
+    for (; z + 4 <= splitk; z += 4) {
+      s0 += p[(size_t)z * zs]; s1 += p[(size_t)(z + 1) * zs];
+      s2 += p[(size_t)(z + 2) * zs]; s3 += p[(size_t)(z + 3) * zs];
+    }
+    for (; z < splitk; ++z) s0 += p[(size_t)z * zs];
+    const float s = (s0 + s1) + (s2 + s3);
+    const size_t o = ((size_t)co * Cin_real + ci) * KH * KW + tap;
+    dw[o] = accumulate ? dw[o] + s : s;
   }
 }
 
@@ -188,13 +196,28 @@ __global__ void wgrad_scatter_kernel(const float* slab, int splitk, int Cout, in
 #define DB_ROWS 256
 __global__ __launch_bounds__(256) void colsum_partial_kernel(int dt, const char* dy, int dyps, long long npix,
                                                              int C, float* partial) {
-  // thread = channel (C <= 1024 handled by looping), block = pixel range
+  // block = pixel range; threads = (channel vector, pixel lane), LDS tree over lanes
+  __shared__ float red[256][4];
+  const int nv = C >> 2;
   const long long chunk = (npix + gridDim.x - 1) / gridDim.x;
   const long long a = blockIdx.x * chunk, b = min(npix, a + chunk);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (long long m = a; m < b; ++m) s += load_elem(dy, m * dyps + c, dt);
-    partial[(size_t)blockIdx.x * C + c] = s;
+  for (int v0 = 0; v0 < nv; v0 += 256) {
+    const int nvv = min(256, nv - v0);          // vectors handled this round
+    int lanes = 256 / nvv;
+    const int cv = threadIdx.x % nvv, pl = threadIdx.x / nvv;
+    f32x4_t s = (f32x4_t){0, 0, 0, 0};
+    if (pl < lanes) {
+#pragma unroll 4
+      for (long long m = a + pl; m < b; m += lanes) s += load4(dy, m * dyps + (v0 + cv) * 4, dt);
+    }
+    for (int q = 0; q < 4; ++q) red[threadIdx.x][q] = s[q];
+    __syncthreads();
+    if (pl == 0 && cv < nvv) {
+      for (int l = 1; l < lanes; ++l)
+        for (int q = 0; q < 4; ++q) s[q] += red[l * nvv + cv][q];
+      *(f32x4_t*)(partial + (size_t)blockIdx.x * C + (v0 + cv) * 4) = s;
+    }
+    __syncthreads();
   }
 }
 __global__ void colsum_final_kernel(const float* partial, int rows, int C, int C_real, float* db, int accumulate) {

@@ -1,0 +1,86 @@
+"""Synthetic undersampled k-space batches following the reference's forward model.
+
+  img (real, [0,1])  --fft2 ortho-->  k_full  --mask-->  kspace  --ifft2 ortho-->  inp
+  (rec_transforms.py:18-57, compressed_sensing.py:460-512, dnn_io.py:4-61,
+   myImageTransformations.py:1196-1238); Cartesian variable-density mask with 8 centre
+  lines, constant along W, ifftshift-ed (compressed_sensing.py:82-123).
+All arithmetic in numpy complex128 like the reference, then packed to float32."""
+import numpy as np
+import torch
+
+
+def cartesian_mask(shape, acc, sample_n=8, rng=None):
+  """(N, nx, ny) 0/1 mask, un-centred.  Row pdf: gaussian + uniform floor, the
+  sample_n centre rows forced, nx//acc rows in total."""
+  rng = np.random if rng is None else rng
+  n, nx, ny = shape
+  grid = np.arange(nx) - nx / 2
+  pdf = np.exp(-(0.5 / (nx / 10.) ** 2) * grid ** 2) + (nx / (2. * acc)) / nx
+  n_lines = nx // acc
+  lo, hi = nx // 2 - sample_n // 2, nx // 2 + sample_n // 2
+  if sample_n:
+    pdf[lo:hi] = 0
+    pdf /= pdf.sum()
+    n_lines -= sample_n
+  rows = np.zeros((n, nx))
+  for i in range(n):
+    rows[i, rng.choice(nx, int(n_lines), False, pdf)] = 1
+  if sample_n:
+    rows[:, lo:hi] = 1
+  mask = np.repeat(rows[:, :, None], ny, axis=2)
+  return np.fft.ifftshift(mask, axes=(-1, -2))
+
+
+def phantom(h, w, seed):
+  """Seeded smooth random field plus a few ellipses, strictly positive, max 1."""
+  rs = np.random.RandomState(seed)
+  spec = np.fft.fft2(rs.rand(h, w))
+  fy, fx = np.fft.fftfreq(h)[:, None], np.fft.fftfreq(w)[None, :]
+  img = np.real(np.fft.ifft2(spec * np.exp(-(fy ** 2 + fx ** 2) * (h * 0.35) ** 2)))
+  img = (img - img.min()) / (img.max() - img.min() + 1e-12)
+  yy, xx = np.mgrid[0:h, 0:w]
+  for _ in range(4):
+    cy, cx = rs.uniform(0.25, 0.75) * h, rs.uniform(0.25, 0.75) * w
+    ry, rx = rs.uniform(0.05, 0.25) * h, rs.uniform(0.05, 0.25) * w
+    img = img + rs.uniform(0.2, 0.8) * (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1)
+  img = img + 0.02
+  return img / np.max(np.abs(img))
+
+
+def _pack(z):
+  return np.stack((np.real(z), np.imag(z))).astype(np.float32)
+
+
+def synth_sample(h, w, acc, seed, sample_n=8):
+  img = phantom(h, w, seed)
+  mask = cartesian_mask((1, h, w), acc, sample_n, np.random.RandomState(seed + 7919))[0]
+  k_u = mask * np.fft.fft2(img.astype(np.complex128), norm='ortho')
+  x_u = np.fft.ifft2(k_u, norm='ortho')
+  return _pack(x_u), _pack(k_u), _pack(mask * (1 + 1j)), _pack(img.astype(np.complex128))
+
+
+def synth_batch(b, h, w, acc=4, seed=0, sample_n=8):
+  parts = [synth_sample(h, w, acc, seed + 1000 + i, sample_n) for i in range(b)]
+  return {k: torch.from_numpy(np.stack([p[j] for p in parts]))
+          for j, k in enumerate(('inp', 'kspace', 'mask', 'target'))}
+
+
+class SyntheticLoader(object):
+  """Minimal DataLoader stand-in: ``len``, ``iter``, ``batch_size``.  Batches are
+  generated once (``distinct`` of them, pinned) and cycled."""
+
+  def __init__(self, batch_size, h, w, num_batches, acc=4, seed=0, distinct=2, pin=True):
+    self.batch_size, self.num_batches = batch_size, num_batches
+    self.batches = []
+    for i in range(max(1, min(distinct, num_batches))):
+      bt = synth_batch(batch_size, h, w, acc, seed + 100000 * i)
+      if pin and torch.cuda.is_available():
+        bt = {k: v.pin_memory() for k, v in bt.items()}
+      self.batches.append(bt)
+
+  def __len__(self):
+    return self.num_batches
+
+  def __iter__(self):
+    for i in range(self.num_batches):
+      yield self.batches[i % len(self.batches)]

@@ -1,0 +1,147 @@
+"""CNN (PatchGAN-style) discriminator, MI355X-native.
+
+Drop-in for the configured path of reference models/discriminators.py:50-247:
+[reflection pad -> conv k x k (stride 1|2) -> (BatchNorm) -> LeakyReLU ->
+(Dropout2d)] per layer, final conv without padding, outputs prob/logits/features.
+State-dict keys follow the reference's Sequential slots (convs.{1,4,8,12,17,22},
+BN at convs.{5,9,13,18,23}, final_conv.0).  Options the hot-path config never
+sets (fc layers, weight norm, instance norm, average pooling) raise.
+
+features are NHWC device tensors (post-dropout, as the reference's in-place
+Dropout2d makes them -- SURVEY A-7); ``feature_channels`` gives the real channel
+count of each for the feature-matching loss."""
+import torch
+import torch.nn as nn
+
+from csmri_hip import ops
+from models.utils import (ConvParams, BNParams, same_padding, need_bias, default_compute_dtype,
+                          COMPUTE_DTYPES)
+from models.weight_inits import initialize_weights
+
+REQUIRED_PARAMS = ['num_inputs', 'num_filters_per_layer', 'strides']
+OPTIONAL_PARAMS = ['kernel_sizes', 'fc_layers', 'spatial_shape', 'act_fn', 'relu_leakiness',
+                   'use_norm_layers', 'norm_layer', 'use_weightnorm', 'padding',
+                   'final_conv_kernel_size', 'final_average_pooling', 'use_biases',
+                   'compute_features', 'dropout_after', 'dropout_prob', 'compute_dtype']
+
+
+def construct_model(conf, model_name, **kwargs):
+  if model_name != 'CNNDiscriminator':
+    raise ValueError('Unknown discriminator {}'.format(model_name))
+  params = conf.to_param_dict(REQUIRED_PARAMS, OPTIONAL_PARAMS)
+  model = CNNDiscriminator(**params)
+  initialize_weights(model, conf.get_attr('weight_init', default={}))
+  return model
+
+
+class CNNDiscriminator(nn.Module):
+  DEFAULT_RELU_LEAKINESS = 0.2
+
+  def __init__(self, num_inputs, num_filters_per_layer, strides, kernel_sizes=None, fc_layers=(),
+               spatial_shape=None, act_fn='lrelu', relu_leakiness=DEFAULT_RELU_LEAKINESS,
+               use_norm_layers=True, norm_layer='batch', use_weightnorm=False, padding='zero',
+               final_conv_kernel_size=1, use_biases=True, final_average_pooling=False,
+               compute_features=False, dropout_after=(), dropout_prob=0.5, compute_dtype=None):
+    super(CNNDiscriminator, self).__init__()
+    if len(fc_layers) > 0 or use_weightnorm or final_average_pooling or norm_layer != 'batch' \
+        or act_fn != 'lrelu':
+      raise NotImplementedError('CNNDiscriminator option outside the hot path')
+    if kernel_sizes is None:
+      kernel_sizes = 3
+    if isinstance(kernel_sizes, int):
+      kernel_sizes = [kernel_sizes] * len(num_filters_per_layer)
+    assert len(num_filters_per_layer) == len(strides) == len(kernel_sizes)
+    dtype = COMPUTE_DTYPES.get(compute_dtype, compute_dtype) or default_compute_dtype()
+    self.dtype = dtype
+    self.compute_features = compute_features
+    self.slope = relu_leakiness
+    self.dropout_prob = dropout_prob
+    self.num_inputs = num_inputs
+
+    slots, self._layers = {}, []
+    slot, cin = 0, num_inputs
+    for li, (f, k, s) in enumerate(zip(num_filters_per_layer, kernel_sizes, strides)):
+      has_bn = use_norm_layers != 'not-first' and bool(use_norm_layers)
+      use_bias = use_biases and need_bias(use_norm_layers, norm_layer)
+      if use_norm_layers == 'not-first':
+        use_norm_layers = True
+      conv = ConvParams(cin, f, k, bias=use_bias)
+      conv.make_layer(s, same_padding(k, s), padding, dtype)
+      slots[str(slot + 1)] = conv                       # slot: pad
+      bn = None
+      if has_bn:
+        bn = BNParams(f)
+        slots[str(slot + 2)] = bn
+      slot += 4 if has_bn else 3                        # (pad, conv, [bn], act)
+      drop = li in dropout_after
+      if drop:
+        slot += 1
+      self._layers.append((conv, bn, drop, f))
+      cin = f
+    self.convs = nn.ModuleDict(slots)
+    fin = ConvParams(cin, 1, final_conv_kernel_size, bias=use_biases)
+    fin.make_layer(1, (0, 0, 0, 0), 'zero', dtype)
+    self.final_conv = nn.ModuleDict({'0': fin})
+    self.injected_dropout = None      # list of [B,C] masks consumed in order (parity tests)
+    self.last_dropout_masks = []
+
+  def weight_init_params(self, user_weight_init=None):
+    return {'conv_weight': ('normal', 0.0, 0.02), 'batchnorm_weight': ('normal', 1.0, 0.02)}
+
+  def set_wgrad(self, enabled):
+    """Disable weight-gradient kernels (generator phase: D's .grad is discarded by the
+    reference anyway, SURVEY A-5)."""
+    for conv, _, _, _ in self._layers:
+      conv.layer.train_weights = enabled
+    self.final_conv['0'].layer.train_weights = enabled
+
+  def _dropmask(self, b, c, device):
+    if self.injected_dropout:
+      m = self.injected_dropout.pop(0).to(device=device, dtype=torch.float32).reshape(b, -1)
+    else:
+      p = self.dropout_prob
+      m = torch.bernoulli(torch.full((b, c), 1.0 - p, device=device)) / (1.0 - p)
+    cp = ops.pad8(c)
+    if cp != c:
+      m = torch.nn.functional.pad(m, (0, cp - c))
+    self.last_dropout_masks.append(m)
+    return m.contiguous()
+
+  def forward(self, inp=None, nhwc=None):
+    """inp: [B,num_inputs,H,W] fp32 (reference API) -- or ``nhwc=`` an NHWC tensor
+    [B,H,W,pad8(num_inputs)] already in the compute dtype (internal fast path)."""
+    x = nhwc if nhwc is not None else ops.ToNHWC.apply(inp, self.dtype, ops.pad8(self.num_inputs))
+    feats, chans = [], []
+    for conv, bn, drop, f in self._layers:
+      if bn is None:
+        x = ops.ConvAct.apply(x, None, conv.weight, conv.bias, conv.layer, self.slope, None)
+      else:
+        mask = self._dropmask(x.shape[0], f, x.device) if (drop and self.training) else None
+        x = ops.ConvBnAct.apply(x, None, conv.weight, bn.weight, bn.bias, conv.layer,
+                                bn.state(self.training), self.slope, self.training, mask)
+      feats.append(x)
+      chans.append(f)
+    fin = self.final_conv['0']
+    lg = ops.ConvAct.apply(x, None, fin.weight, fin.bias, fin.layer, 1.0, torch.float32)
+    logits = ops.ToNCHW.apply(lg, 1)
+    out = {'prob': _Sigmoid.apply(logits), 'logits': logits}
+    if self.compute_features:
+      out['features'] = feats + [lg]
+      out['feature_channels'] = chans + [1]
+    return out
+
+
+class _Sigmoid(torch.autograd.Function):
+  """prob = sigmoid(logits).  The GAN criterion consumes ``logits`` directly (fused
+  BCE-on-logits kernel); prob is kept for the API and the accuracy metric."""
+
+  @staticmethod
+  def forward(ctx, logits):
+    p = ops.sigmoid_prob(logits)
+    ctx.save_for_backward(p)
+    return p
+
+  @staticmethod
+  def backward(ctx, g):
+    p, = ctx.saved_tensors
+    return g * p * (1 - p)

@@ -1,0 +1,165 @@
+"""RecNet: cascade of conv blocks and k-space data-consistency layers
+(Schlemper et al. deep cascade), MI355X-native.
+
+Drop-in for the reference's models/recnet.py: same constructor arguments,
+``forward(inp, kspace, mask)`` with [B,2,H,W] fp32 tensors, same state-dict keys
+(``conv_blocks.{b}.layers.{1,4,7}.{weight,bias}``, recnet.py:29-62,121-134).
+Internally activations are NHWC in the compute dtype, every conv is one
+implicit-GEMM MFMA kernel with padding/bias/LeakyReLU fused, and each DC layer is
+the fused FFT/merge/iFFT of csmri_dc whose last pass also emits the next block's
+channel-padded input."""
+import torch
+import torch.nn as nn
+
+from csmri_hip import ops
+from models.utils import ConvParams, same_padding, default_compute_dtype
+from models.weight_inits import initialize_weights
+
+RECNET_REQUIRED_PARAMS = ['num_blocks', 'num_convs', 'num_filters']
+RECNET_OPTIONAL_PARAMS = ['num_final_outputs', 'dilations_per_conv', 'kernel_size',
+                          'relu_leakiness', 'padding', 'use_refinement', 'skip_final_dc',
+                          'return_intermediate_recs', 'compute_dtype']
+
+
+def construct_model(conf, model_name, **kwargs):
+  params = conf.to_param_dict(RECNET_REQUIRED_PARAMS, RECNET_OPTIONAL_PARAMS)
+  model = RecNet(**params)
+  for block in model.conv_blocks:
+    initialize_weights(block, conf.get_attr('weight_init', default={}))
+  return model
+
+
+class ConvBlock(nn.Module):
+  """(pad, conv, LeakyReLU) x (n-1), pad, conv -- reference recnet.py:29-62.
+  Sequential slot of conv i is 3*i+1 (pad, conv, act triplets)."""
+
+  def __init__(self, num_convs, num_filters, kernel_size, relu_leakiness, padding='zero',
+               num_inputs=2, num_outputs=2, dtype=None):
+    super(ConvBlock, self).__init__()
+    self.slope = relu_leakiness
+    self.num_convs = num_convs
+    dtype = dtype or default_compute_dtype()
+    convs = {}
+    cin = num_inputs
+    for i in range(num_convs):
+      cout = num_filters if i < num_convs - 1 else num_outputs
+      cp = ConvParams(cin, cout, kernel_size, bias=True)
+      cp.make_layer(1, same_padding(kernel_size, 1), padding, dtype)
+      convs[str(3 * i + 1)] = cp
+      cin = cout
+    self.layers = nn.ModuleDict(convs)
+    self.num_outputs = num_outputs
+
+  def weight_init_params(self, user_weight_init=None):
+    first = self.layers['1']
+    return {'conv_weight': ('he_normal', RecNet.DEFAULT_RELU_LEAKINESS),
+            first: {'weight': ('xavier', 1.0)}}
+
+  def forward(self, x):
+    """x: NHWC [B,H,W,8] compute dtype.  Returns interleaved complex fp32
+    [B,H,W,2] when the block ends in 2 channels (feeds DC), else NHWC."""
+    n = self.num_convs
+    for i in range(n):
+      cp = self.layers[str(3 * i + 1)]
+      last = i == n - 1
+      x = ops.ConvAct.apply(x, None, cp.weight, cp.bias, cp.layer,
+                            1.0 if last else self.slope,
+                            torch.float32 if last else None)
+    return x
+
+
+class RecNet(nn.Module):
+  DEFAULT_RELU_LEAKINESS = 0.01
+
+  def __init__(self, num_blocks, num_convs, num_filters, num_final_outputs=2,
+               dilations_per_conv=1, kernel_size=3, relu_leakiness=DEFAULT_RELU_LEAKINESS,
+               padding='zero', use_refinement=False, skip_final_dc=False,
+               return_intermediate_recs=False, compute_dtype=None):
+    super(RecNet, self).__init__()
+    if isinstance(num_filters, int):
+      num_filters = [num_filters] * num_blocks
+    assert len(num_filters) == num_blocks, 'Number of given filters must match number of blocks'
+    if not (dilations_per_conv == 1 or all(d == 1 for d in dilations_per_conv)):
+      raise NotImplementedError('dilated RecNet convolutions are outside the hot path')
+    if num_final_outputs != 2:
+      raise NotImplementedError('RecNet with num_final_outputs != 2 is outside the hot path')
+    from models.utils import COMPUTE_DTYPES
+    dtype = COMPUTE_DTYPES.get(compute_dtype, compute_dtype) or default_compute_dtype()
+    self.dtype = dtype
+    self.conv_blocks = nn.ModuleList([
+        ConvBlock(num_convs, nf, kernel_size, relu_leakiness, padding, dtype=dtype)
+        for nf in num_filters])
+    # plain python list in the reference (recnet.py:128-134): no parameters/buffers
+    self.dc_layers = list(range(num_blocks if not skip_final_dc else num_blocks - 1))
+    self.use_refinement = use_refinement
+    self.skip_final_dc = skip_final_dc
+    self.return_intermediate_recs = return_intermediate_recs
+
+  def forward(self, inp, kspace, mask):
+    """inp, kspace, mask: [B,2,H,W] fp32 (re, im planes).  Returns [B,2,H,W]."""
+    x_pad = ops.ToNHWC.apply(inp, self.dtype, 8)             # conv input layout
+    x_c = ops.ToNHWC.apply(inp, torch.float32, 2)            # interleaved complex
+    k0 = ops.nchw_to_nhwc(kspace, torch.float32, 2)
+    m8 = ops.mask_to_u8(mask)
+    recs = []
+    nb = len(self.conv_blocks)
+    for idx, block in enumerate(self.conv_blocks):
+      y = block(x_pad)                                       # fp32 [B,H,W,8], ch 0,1 = re,im
+      if self.use_refinement:
+        y = y + _CastPad.apply(x_c, torch.float32)
+      if idx < len(self.dc_layers):
+        want_pad = self.dtype if idx < nb - 1 else None
+        res = ops.DataConsistency.apply(y, k0, m8, want_pad)
+        if want_pad is not None:
+          x_c, x_pad_next = res
+          x_pad = _PadAlias.apply(x_c, x_pad_next)
+        else:
+          x_c = res
+        if self.return_intermediate_recs:
+          recs.append(ops.ToNCHW.apply(x_c, 2))
+      else:
+        x_c = _Slice2.apply(y)
+        if idx < nb - 1:
+          x_pad = _CastPad.apply(x_c, self.dtype)
+    out = ops.ToNCHW.apply(x_c, 2)
+    if self.return_intermediate_recs:
+      return {'pred': out, 'reconstructions': recs}
+    return out
+
+
+class _PadAlias(torch.autograd.Function):
+  """The DC kernel writes its result twice: fp32 complex and channel-padded in the
+  conv dtype.  This node ties the padded copy to the fp32 result for autograd:
+  grad(x_c) = first two channels of grad(padded)."""
+
+  @staticmethod
+  def forward(ctx, x_c, x_pad):
+    return x_pad.view_as(x_pad)
+
+  @staticmethod
+  def backward(ctx, g):
+    return ops.copy_channels(g, 2, torch.float32), None
+
+
+class _CastPad(torch.autograd.Function):
+  """[B,H,W,2] fp32 -> channel-padded [B,H,W,8] of ``dtype``."""
+
+  @staticmethod
+  def forward(ctx, x_c, dtype):
+    return ops.copy_channels(x_c, 8, dtype)
+
+  @staticmethod
+  def backward(ctx, g):
+    return ops.copy_channels(g, 2, torch.float32), None
+
+
+class _Slice2(torch.autograd.Function):
+  """channels 0,1 of a [B,H,W,8] fp32 tensor as dense interleaved complex."""
+
+  @staticmethod
+  def forward(ctx, y):
+    return ops.copy_channels(y, 2, torch.float32)
+
+  @staticmethod
+  def backward(ctx, g):
+    return ops.copy_channels(g, 8, torch.float32)

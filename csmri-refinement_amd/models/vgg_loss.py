@@ -1,0 +1,48 @@
+"""VGG perceptual loss for complex images (reference models/vgg_loss.py:13-65).
+
+|pred| and |target| -> 3 equal channels -> ImageNet normalisation -> VGG19
+features -> criterion (MSE by default through criteria.py:15-28) between the
+block features; the target branch carries no gradient.  Magnitude, replication
+and normalisation are one kernel; the feature loss is a deterministic two-stage
+reduction."""
+import torch
+import torch.nn as nn
+
+from csmri_hip import ops
+
+_KIND = {'L1': 0, 'MSE': 1}
+
+
+class VGGLoss(nn.Module):
+  def __init__(self, loss_name, cuda, blocks=-1, criterion='L1', weights=None, seed=0):
+    super(VGGLoss, self).__init__()
+    if loss_name != 'VGG19':
+      raise ValueError('Unknown VGG loss {}'.format(loss_name))
+    from models.vgg import VGG19
+    if blocks == -1:
+      blocks = [VGG19.LAST_FEATURE_MAP]
+    elif not isinstance(blocks, list):
+      blocks = [blocks]
+    self.vgg = VGG19(blocks, requires_grad=False, seed=seed)
+    self.kind = _KIND[criterion]
+    self.weights = list(weights) if weights is not None else [1.] * len(blocks)
+    assert len(self.weights) == len(blocks)
+
+  def forward(self, prediction, target):
+    """prediction / target: interleaved complex fp32 [B,H,W,2] (internal layout) or
+    [B,2,H,W] fp32 (reference layout)."""
+    if prediction.shape[-1] != 2:
+      assert prediction.shape[1] == 2, 'only complex (2-channel) inputs are on the hot path'
+      prediction = ops.ToNHWC.apply(prediction, torch.float32, 2)
+    if target.shape[-1] != 2:
+      target = ops.nchw_to_nhwc(target.detach(), torch.float32, 2)
+    dt = self.vgg.dtype
+    p_in = ops.ComplexAbs.apply(prediction, dt, 3)
+    with torch.no_grad():
+      t_in = ops.ComplexAbs.apply(target.detach().contiguous(), dt, 3)
+      t_feats = self.vgg.forward_nhwc(t_in)
+    p_feats = self.vgg.forward_nhwc(p_in)
+    loss = 0
+    for wgt, pf, tf in zip(self.weights, p_feats, t_feats):
+      loss = loss + wgt * ops.MeanLoss.apply(pf, tf.detach(), self.kind, pf.shape[3])
+    return loss

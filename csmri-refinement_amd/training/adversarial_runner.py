@@ -1,0 +1,272 @@
+"""Adversarial (GAN refinement) runner -- reference training/adversarial_runner.py.
+
+One training step (reference :322-389):
+  out_gen = G(inp, kspace, mask)
+  D phase : D(|pred|.detach() via image pool), D(|target|)  -> GAN_disc
+  G phase : D(|pred|) again with gradient               -> GAN_gen, FeatureMatching
+            VGG19 perceptual loss, FeaturePenalty
+  update D (zero_grad, backward, Adam), then update G (backward THROUGH the already
+  updated D, Adam).
+Semantics kept (SURVEY A-3/A-4/A-5/A-7): three train-mode D forwards (BN running
+stats move three times, three dropout draws); the generator backward sees D's
+post-update weights and BN affine parameters with the pre-update saved activations
+and batch statistics (torch-0.3.1 behaviour, "faithful" ordering (A)); D weight
+gradients of the generator pass are not computed (the reference discards them).
+
+Scheduling differs (results do not): the D backward is issued as soon as the D losses
+exist, its gradient bucket is all-reduced on RCCL's stream while the third D forward
+and the two VGG forwards run, and loss scalars stay on the device (one readback per
+logging interval instead of one blocking .data[0] per loss)."""
+from collections import OrderedDict
+import logging
+
+import torch
+
+import utils
+from metrics import get_metric_fn, get_loss_metric
+from models import construct_model
+from models.criteria import get_criterion
+from training.adversarial_training import get_discriminator_input_fn
+from training.base_runner import BaseRunner
+from training.optimizers import get_optimizer
+from training import distributed as dist_utils
+from utils.checkpoints import initialize_pretrained_model
+from utils.config import Configuration
+
+
+def build_runner(conf, cuda, mode):
+  gen_conf = Configuration.from_dict(conf.generator_model, conf)
+  gen_model = construct_model(gen_conf, gen_conf.name, cuda)
+  val_metric_fns = {name: get_metric_fn(conf, name, cuda, 'test')
+                    for name in conf.get_attr('validation_metrics', default=[]) if name == 'psnr'}
+  if mode != 'train':
+    gen_model = utils.cudaify(gen_model, cuda)
+    return AdversarialRunner(gen_model, cuda=cuda, val_metric_fns=val_metric_fns)
+
+  disc_dict = dict(conf.discriminator_model)
+  disc_dict.setdefault('name', 'CNNDiscriminator')      # shipped config lacks it (SURVEY A-1)
+  disc_conf = Configuration.from_dict(disc_dict, conf)
+  disc_model = construct_model(disc_conf, disc_conf.name, cuda)
+
+  gen_adv = OrderedDict((n, get_criterion(conf, n, cuda, loss_type='gen'))
+                        for n in conf.generator_adversarial_losses)
+  gen_crit = OrderedDict((n, get_criterion(conf, n, cuda)) for n in conf.generator_losses)
+  disc_adv = OrderedDict((n, get_criterion(conf, n, cuda, loss_type='disc'))
+                         for n in conf.discriminator_losses)
+  gen_model, disc_model = utils.cudaify([gen_model, disc_model], cuda)
+  for crit in list(gen_adv.values()) + list(gen_crit.values()) + list(disc_adv.values()):
+    utils.cudaify(crit, cuda)
+  if gen_conf.has_attr('pretrained_weights'):
+    initialize_pretrained_model(gen_conf, gen_model, cuda, conf.file)
+  if disc_conf.has_attr('pretrained_weights'):
+    initialize_pretrained_model(disc_conf, disc_model, cuda, conf.file)
+  dist_utils.broadcast_module(gen_model)
+  dist_utils.broadcast_module(disc_model)
+
+  gen_opt_conf = Configuration.from_dict(conf.generator_optimizer, conf)
+  disc_opt_conf = Configuration.from_dict(conf.discriminator_optimizer, conf)
+  for oc in (gen_opt_conf, disc_opt_conf):
+    if oc.has_attr('lr_scheduler') or oc.get_attr('updates_per_step', 1) != 1:
+      raise NotImplementedError('lr schedulers / multiple updates per step are outside the hot '
+                                'path (SURVEY 8f rank 4)')
+  if conf.get_attr('pretrain_generator_epochs') or conf.get_attr('pretrain_discriminator_epochs'):
+    raise NotImplementedError('pretraining schedules are outside the hot path (SURVEY 8f rank 4)')
+  # Important: construct optimizers after moving the models to the GPU
+  gen_optimizer = get_optimizer(gen_opt_conf, gen_opt_conf.name, gen_model.parameters())
+  disc_optimizer = get_optimizer(disc_opt_conf, disc_opt_conf.name, disc_model.parameters())
+
+  train_gen_metric_fns = {n: get_metric_fn(conf, n, cuda, 'train')
+                          for n in conf.get_attr('train_generator_metrics', default=[])}
+  train_disc_metric_fns = {n: get_metric_fn(conf, n, cuda, 'train')
+                           for n in conf.get_attr('train_discriminator_metrics', default=[])}
+  disc_input_fn = get_discriminator_input_fn(conf, disc_conf, dtype_fn=lambda: disc_model.dtype)
+  val_disc_input_fn = get_discriminator_input_fn(conf, disc_conf, no_pool=True,
+                                                 dtype_fn=lambda: disc_model.dtype)
+  return AdversarialRunner(gen_model, disc_model, gen_optimizer, disc_optimizer, None, None,
+                           gen_adv, gen_crit, disc_adv,
+                           conf.get_attr('generator_loss_weights', {}),
+                           conf.get_attr('discriminator_loss_weights', {}), cuda,
+                           train_gen_metric_fns, train_disc_metric_fns, val_metric_fns, {},
+                           disc_input_fn=disc_input_fn, val_disc_input_fn=val_disc_input_fn)
+
+
+class AdversarialRunner(BaseRunner):
+  def __init__(self, gen_model, disc_model=None, gen_optimizer=None, disc_optimizer=None,
+               gen_lr_scheduler=None, disc_lr_scheduler=None, gen_adv_criteria=None,
+               gen_criteria=None, disc_adv_criteria=None, gen_loss_weights=None,
+               disc_loss_weights=None, cuda='', train_gen_metric_fns=None,
+               train_disc_metric_fns=None, val_metric_fns=None, val_disc_metric_fns=None,
+               output_transform=None, train_input_batch_transform=None,
+               test_input_batch_transform=None, gen_updates_per_step=1, disc_updates_per_step=1,
+               disc_input_fn=None, val_disc_input_fn=None, pretrain_generator_epochs=None,
+               pretrain_discriminator_epochs=None):
+    super(AdversarialRunner, self).__init__(cuda)
+    self.gen, self.disc = gen_model, disc_model
+    self.gen_optimizer, self.disc_optimizer = gen_optimizer, disc_optimizer
+    self.train_gen_metric_fns = train_gen_metric_fns or {}
+    self.train_disc_metric_fns = train_disc_metric_fns or {}
+    self.val_metric_fns = val_metric_fns or {}
+    self.val_disc_metric_fns = val_disc_metric_fns or {}
+    self.train_model_input_fn = self._get_model_input_fn(self.gen, train_input_batch_transform)
+    self.test_model_input_fn = self._get_model_input_fn(self.gen, test_input_batch_transform)
+    assert gen_updates_per_step == 1 and disc_updates_per_step == 1
+    self._train_step = self._train_single_step
+    self.disc_input_fn, self.val_disc_input_fn = disc_input_fn, val_disc_input_fn
+    self.gen_adv_criteria = OrderedDict(gen_adv_criteria or {})
+    self.gen_criteria = OrderedDict(gen_criteria or {})
+    self.disc_adv_criteria = OrderedDict(disc_adv_criteria or {})
+    self.gen_loss_weights = self._get_loss_weights(gen_loss_weights or {}, self.gen_adv_criteria,
+                                                   self.gen_criteria)
+    self.disc_loss_weights = self._get_loss_weights(disc_loss_weights or {},
+                                                    self.disc_adv_criteria)
+    self.discriminator_enabled = True
+    self.generator_enabled = True
+    self.pool_decisions = None            # optional injected image-pool decisions (tests)
+
+  # -- reference surface -------------------------------------------------------
+  def get_named_outputs(self, data):
+    batch, out_gen = data[0], data[1]
+    pred = out_gen['pred'] if isinstance(out_gen, dict) else out_gen
+    return {'input': batch['inp'], 'prediction': pred, 'target': batch['target'],
+            'disc_fake': data[2]}
+
+  def get_named_models(self):
+    return {'generator': self.gen, 'discriminator': self.disc}
+
+  def state_dict(self):
+    return {'generator': self.gen.state_dict(), 'discriminator': self.disc.state_dict(),
+            'gen_optimizer': self.gen_optimizer.state_dict(),
+            'disc_optimizer': self.disc_optimizer.state_dict()}
+
+  def load_state_dict(self, state_dict):
+    from csmri_hip import ops
+    self.gen.load_state_dict(state_dict['generator'])
+    if self.disc is not None:
+      assert 'discriminator' in state_dict, 'Incompatible checkpoint'
+      self.disc.load_state_dict(state_dict['discriminator'])
+    ops.bump_weight_epoch()
+    if self.gen_optimizer is not None:
+      assert 'gen_optimizer' in state_dict, 'Incompatible checkpoint'
+      self.gen_optimizer.load_state_dict(state_dict['gen_optimizer'])
+    if self.disc_optimizer is not None:
+      assert 'disc_optimizer' in state_dict, 'Incompatible checkpoint'
+      self.disc_optimizer.load_state_dict(state_dict['disc_optimizer'])
+
+  def __str__(self):
+    s = 'Generator:\n' + str(self.gen)
+    if self.disc is not None:
+      s += '\nDiscriminator:\n' + str(self.disc)
+    return s
+
+  def predict(self, batch):
+    return self.gen(*self.train_model_input_fn(batch, use_batch_transform=False))
+
+  @staticmethod
+  def _weighted_total(losses, weights):
+    return torch.sum(torch.stack(losses) * weights)
+
+  def _update_step(self, optimizer, losses, weights):
+    """zero_grad; backward; all-reduce; Adam (reference :314-320)."""
+    total = self._weighted_total(losses, weights)
+    optimizer.zero_grad()
+    total.backward()
+    optimizer.start_allreduce()
+    optimizer.step()
+    return total.detach()
+
+  def _train_single_step(self, loader):
+    batch = self._request_data(loader)
+    if batch is None:
+      return 0, None, None
+    loss_metrics = {}
+    gen_inp = self.train_model_input_fn(batch)
+    out_gen = self.gen(*gen_inp)
+
+    # ---- discriminator phase (:331-347) ------------------------------------
+    out_disc_fake_d = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp[0], out_gen,
+                                                         is_real_input=False, detach=True,
+                                                         pool_decisions=self.pool_decisions))
+    out_disc_real = self.disc(nhwc=self.disc_input_fn(batch['target'], gen_inp[0], out_gen,
+                                                      is_real_input=True, detach=True))
+    disc_losses = []
+    for name, criterion in self.disc_adv_criteria.items():
+      loss = criterion(out_disc_fake_d, out_disc_real)
+      disc_losses.append(loss)
+      loss_metrics['disc_loss_' + name] = get_loss_metric(loss.detach())
+    total_disc = self._weighted_total(disc_losses, self.disc_loss_weights)
+    # D backward now (it only fills D's gradient bucket; no state changes), so that
+    # the bucket's all-reduce overlaps the generator-phase forwards below
+    self.disc_optimizer.zero_grad()
+    total_disc.backward()
+    self.disc_optimizer.start_allreduce()
+    loss_metrics['disc_loss'] = get_loss_metric(total_disc.detach())
+
+    # ---- generator phase forward (:349-370) --------------------------------
+    self.disc.set_wgrad(False)
+    out_disc_fake = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp[0], out_gen,
+                                                      is_real_input=False, detach=False))
+    self.disc.set_wgrad(True)
+    gen_losses = []
+    for name, criterion in self.gen_adv_criteria.items():
+      loss = criterion(out_disc_fake, out_disc_real)
+      gen_losses.append(loss)
+      loss_metrics['gen_loss_' + name] = get_loss_metric(loss.detach())
+    for name, criterion in self.gen_criteria.items():
+      loss = criterion(out_gen, batch)
+      gen_losses.append(loss)
+      loss_metrics['gen_loss_' + name] = get_loss_metric(loss.detach())
+
+    # ---- updates (:372-383): D step first, then G backward through the updated D
+    self.disc_optimizer.step()
+    total_gen = self._weighted_total(gen_losses, self.gen_loss_weights)
+    self.gen_optimizer.zero_grad()
+    total_gen.backward()
+    self.gen_optimizer.start_allreduce()
+    self.gen_optimizer.step()
+    loss_metrics['gen_loss'] = get_loss_metric(total_gen.detach())
+    return 1, loss_metrics, (batch, out_gen, out_disc_fake, out_disc_real)
+
+  def _val_step(self, loader, compute_metrics=True):
+    batch = self._request_data(loader, volatile=True)
+    if batch is None:
+      return None, None
+    gen_inp = self.test_model_input_fn(batch)
+    out_gen = self.gen(*gen_inp)
+    out_disc_fake = out_disc_real = None
+    if self.disc is not None and self.val_disc_input_fn is not None:
+      out_disc_fake = self.disc(nhwc=self.val_disc_input_fn(out_gen, gen_inp[0], out_gen,
+                                                            is_real_input=False, detach=True))
+      out_disc_real = self.disc(nhwc=self.val_disc_input_fn(batch['target'], gen_inp[0], out_gen,
+                                                            is_real_input=True, detach=True))
+    loss_metrics = {}
+    if compute_metrics:
+      for name, criterion in self.gen_criteria.items():
+        loss_metrics['gen_loss_' + name] = get_loss_metric(criterion(out_gen, batch).detach())
+    return loss_metrics, (batch, out_gen, out_disc_fake, out_disc_real)
+
+  def _compute_train_metrics(self, data):
+    metrics = {}
+    for name, fn in self.train_gen_metric_fns.items():
+      metrics['gen_' + name] = fn(data[1], data[0])
+    if data[2] is not None:
+      for name, fn in self.train_disc_metric_fns.items():
+        metrics['disc_' + name] = fn(data[2]['prob'], data[3]['prob'], transform=False)
+    return metrics
+
+  def _compute_test_metrics(self, data):
+    metrics = {}
+    for name, fn in self.val_metric_fns.items():
+      metrics['gen_' + name] = fn(data[1], data[0])
+    if data[2] is not None:
+      for name, fn in self.val_disc_metric_fns.items():
+        metrics['disc_' + name] = fn(data[2]['prob'], data[3]['prob'], transform=False)
+    return metrics
+
+  def _set_train(self):
+    self.gen.train()
+    self.disc.train()
+
+  def _set_test(self):
+    self.gen.eval()
+    if self.disc is not None:
+      self.disc.eval()

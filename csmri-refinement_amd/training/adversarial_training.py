@@ -1,0 +1,58 @@
+"""Discriminator input function (reference training/adversarial_training.py:21-135).
+
+Configured path: input_method 'simple-magnitude' (|complex image|), image pool of
+generated images queried only for detached fake inputs.  The magnitude is computed
+by one kernel straight into the discriminator's NHWC input layout."""
+import torch
+
+from csmri_hip import ops
+from utils.image_pool import ImagePool
+
+DEFAULT_INPUT_METHOD = 'simple'
+
+
+def _as_complex_nhwc(t, detach):
+  """[B,2,H,W] fp32 or internal [B,H,W,2] -> interleaved complex [B,H,W,2]."""
+  if t.shape[-1] == 2 and t.dim() == 4 and t.shape[1] != 2:
+    return t.detach() if detach else t
+  if detach:
+    return ops.nchw_to_nhwc(t.detach(), torch.float32, 2)
+  return ops.ToNHWC.apply(t, torch.float32, 2)
+
+
+def _build_input_fn(method, dtype_fn, image_pool=None, pool_label_swapping=False):
+  if method not in ('simple-magnitude',):
+    raise NotImplementedError("discriminator input_method '%s' is outside the hot path" % method)
+
+  def input_wrapper(prediction_or_target, inp, out_gen, is_real_input, detach=False,
+                    pool_decisions=None):
+    if isinstance(prediction_or_target, dict):
+      fast = prediction_or_target.get('_nhwc')
+      pred = fast['pred'] if fast is not None else prediction_or_target['pred']
+    else:
+      pred = prediction_or_target
+    xc = _as_complex_nhwc(pred, detach)
+    mag = ops.ComplexAbs.apply(xc.contiguous(), dtype_fn(), 0)       # [B,H,W,8], channel 0
+    if detach:
+      mag = mag.detach()
+      if image_pool is not None and (not is_real_input or pool_label_swapping):
+        mag = image_pool.query(mag, pool_decisions)
+    return mag
+
+  return input_wrapper
+
+
+def get_discriminator_input_fn(conf, disc_conf, no_pool=False, dtype_fn=None):
+  from models.utils import default_compute_dtype
+  image_pool = None
+  if disc_conf.get_attr('use_image_pool', default=False) and not no_pool:
+    pool_size = disc_conf.get_attr('image_pool_size', default=5 * conf.batch_size)
+    image_pool = ImagePool(pool_size, disc_conf.get_attr('image_pool_sample_prob', default=0.5))
+  for key in ('normalize_input', 'scale_input_zero_one', 'strip_bg_class'):
+    if disc_conf.get_attr(key, default=False):
+      raise NotImplementedError("discriminator option '%s' is outside the hot path" % key)
+  fn = _build_input_fn(disc_conf.get_attr('input_method', default=DEFAULT_INPUT_METHOD),
+                       dtype_fn or default_compute_dtype, image_pool,
+                       disc_conf.get_attr('image_pool_label_swapping', default=False))
+  fn.image_pool = image_pool
+  return fn

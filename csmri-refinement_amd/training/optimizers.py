@@ -1,0 +1,95 @@
+"""Optimizer factory (reference training/optimizers.py:5-24 -> torch.optim.Adam).
+
+FlatAdam keeps all trainable parameters of a model in ONE contiguous fp32 buffer
+(the Parameters become views), their gradients in a second one, and runs Adam as a
+single fused kernel over the flat buffers; the same flat gradient buffer is the
+RCCL all-reduce bucket.  Update rule and state_dict layout follow torch.optim.Adam
+(eps 1e-8, no weight decay, no amsgrad)."""
+import torch
+import torch.nn as nn
+
+from csmri_hip import ops
+from training.distributed import GradBucket
+
+
+class FlatAdam(object):
+  def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
+    self.params = [p for p in params if p.requires_grad]
+    assert len(self.params) > 0, 'optimizer got no trainable parameters'
+    dev = self.params[0].device
+    if dev.type != 'cuda':
+      raise RuntimeError('FlatAdam runs on the GPU only (construct it after moving the model)')
+    self.lr, self.betas, self.eps = lr, tuple(betas), eps
+    self.offsets, total = [], 0
+    for p in self.params:
+      self.offsets.append(total)
+      total += (p.numel() + 3) // 4 * 4            # keep every view 16-byte aligned
+    self.numel = total
+    self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+    for p, off in zip(self.params, self.offsets):
+      n = p.numel()
+      self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+      p.data = self.flat_p[off:off + n].view_as(p)
+      p.grad = self.flat_g[off:off + n].view_as(p)
+    self.step_count = 0
+    self.bucket = GradBucket(self.flat_g)
+    self.param_groups = [{'lr': lr, 'betas': self.betas, 'eps': eps, 'weight_decay': 0,
+                          'amsgrad': False, 'params': list(range(len(self.params)))}]
+    ops.bump_weight_epoch()
+
+  def zero_grad(self):
+    self.flat_g.zero_()
+    for p, off in zip(self.params, self.offsets):   # re-attach if something replaced .grad
+      if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+        p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+
+  def start_allreduce(self):
+    self.bucket.start()
+
+  def step(self):
+    scale = self.bucket.wait()
+    self.step_count += 1
+    ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq,
+                  self.param_groups[0]['lr'], self.betas[0], self.betas[1], self.eps,
+                  self.step_count, scale)
+    ops.bump_weight_epoch()
+
+  # -- torch.optim.Adam compatible state ---------------------------------------
+  def state_dict(self):
+    state = {}
+    if self.step_count > 0:
+      for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+        n = p.numel()
+        state[i] = {'step': torch.tensor(float(self.step_count)),
+                    'exp_avg': self.exp_avg[off:off + n].view_as(p).clone(),
+                    'exp_avg_sq': self.exp_avg_sq[off:off + n].view_as(p).clone()}
+    return {'state': state, 'param_groups': [dict(g) for g in self.param_groups]}
+
+  def load_state_dict(self, sd):
+    for i, st in sd['state'].items():
+      i = int(i)
+      off, n = self.offsets[i], self.params[i].numel()
+      self.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
+      self.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+      self.step_count = int(st['step'])
+    if sd.get('param_groups'):
+      self.param_groups[0]['lr'] = sd['param_groups'][0].get('lr', self.lr)
+
+
+def get_optimizer(conf, optimizer_name, variables_or_model):
+  if isinstance(variables_or_model, nn.Module):
+    variables = variables_or_model.parameters()
+    if isinstance(variables, dict):
+      assert conf.has_attr('parameter_key'), 'Parameter key unspecfied, but model requires one.'
+      variables = variables[conf.parameter_key]
+  else:
+    variables = variables_or_model
+  if optimizer_name == 'Adam':
+    return FlatAdam(variables, conf.learning_rate,
+                    betas=(conf.get_attr('beta1', default=0.9), conf.get_attr('beta2', default=0.999)))
+  if optimizer_name == 'RMSProp':
+    raise NotImplementedError('RMSProp is outside the hot path (configs use Adam)')
+  raise ValueError('Unknown optimizer {}'.format(optimizer_name))

@@ -1,0 +1,125 @@
+"""Standard (single model, e.g. RecNet + MSE) runner -- reference training/runner.py.
+
+_train_step: zero_grad -> forward -> criteria -> weighted sum -> backward (which runs
+the adjoint of every data-consistency layer) -> all-reduce -> fused Adam."""
+import torch
+
+from metrics import get_metric_fn, get_loss_metric
+from models import construct_model
+from models.criteria import get_criterion
+from training.base_runner import BaseRunner
+from training.optimizers import get_optimizer
+from training import distributed as dist_utils
+from utils.checkpoints import initialize_pretrained_model
+from utils.config import Configuration
+import utils
+
+
+def build_runner(conf, cuda, mode='train'):
+  model_conf = Configuration.from_dict(conf.model, conf)
+  model = construct_model(model_conf, model_conf.name, cuda)
+  val_metric_fns = {name: get_metric_fn(conf, name, cuda, 'test')
+                    for name in conf.get_attr('validation_metrics', default=[])
+                    if name in ('psnr',)}
+  model = utils.cudaify(model, cuda)
+  if mode != 'train':
+    return Runner(model, cuda=cuda, val_metric_fns=val_metric_fns)
+  criteria = {}
+  if conf.has_attr('loss_name'):
+    criteria[conf.loss_name] = get_criterion(conf, conf.loss_name, cuda)
+  else:
+    for loss_name in conf.losses:
+      criteria[loss_name] = get_criterion(conf, loss_name, cuda)
+  assert len(criteria) > 0, 'Need at least one loss to optimize something!'
+  if model_conf.has_attr('pretrained_weights'):
+    initialize_pretrained_model(model_conf, model, cuda, conf.file)
+  dist_utils.broadcast_module(model)
+  opt_conf = Configuration.from_dict(conf.optimizer, conf)
+  if opt_conf.has_attr('lr_scheduler'):
+    raise NotImplementedError('lr schedulers are outside the hot path (SURVEY 8f)')
+  optimizer = get_optimizer(opt_conf, opt_conf.name, model.parameters())
+  train_metric_fns = {name: get_metric_fn(conf, name, cuda, 'train')
+                      for name in conf.get_attr('train_metrics', default=[])}
+  return Runner(model, criteria, conf.get_attr('loss_weights', {}), optimizer, None, cuda,
+                train_metric_fns, val_metric_fns)
+
+
+class Runner(BaseRunner):
+  def __init__(self, model, criteria=None, loss_weights=None, optimizer=None, lr_scheduler=None,
+               cuda='', train_metric_fns=None, val_metric_fns=None, output_transform=None,
+               train_input_batch_transform=None, test_input_batch_transform=None):
+    super(Runner, self).__init__(cuda)
+    self.model = model
+    self.criteria = criteria or {}
+    self.loss_weights = self._get_loss_weights(loss_weights or {}, self.criteria)
+    self.optimizer = optimizer
+    self.train_metric_fns = train_metric_fns or {}
+    self.val_metric_fns = val_metric_fns or {}
+    self.train_model_input_fn = self._get_model_input_fn(model, train_input_batch_transform)
+    self.test_model_input_fn = self._get_model_input_fn(model, test_input_batch_transform)
+
+  def get_named_outputs(self, data):
+    batch, out = data[0], data[1]
+    pred = out['pred'] if isinstance(out, dict) else out
+    return {'input': batch['inp'], 'prediction': pred, 'target': batch['target']}
+
+  def get_named_models(self):
+    return {'model': self.model}
+
+  def state_dict(self):
+    return {'model': self.model.state_dict(), 'optimizer': self.optimizer.state_dict()}
+
+  def load_state_dict(self, state_dict):
+    self.model.load_state_dict(state_dict['model'])
+    from csmri_hip import ops
+    ops.bump_weight_epoch()
+    if self.optimizer is not None:
+      assert 'optimizer' in state_dict, 'Incompatible checkpoint'
+      self.optimizer.load_state_dict(state_dict['optimizer'])
+
+  def __str__(self):
+    return 'Model:\n' + str(self.model)
+
+  def predict(self, batch):
+    return self.model(*self.train_model_input_fn(batch, use_batch_transform=False))
+
+  def _train_step(self, loader):
+    batch = self._request_data(loader)
+    if batch is None:
+      return 0, None, None
+    self.optimizer.zero_grad()
+    out = self.model(*self.train_model_input_fn(batch))
+    losses, loss_metrics = [], {}
+    for name, criterion in self.criteria.items():
+      loss = criterion(out, batch)
+      losses.append(loss)
+      loss_metrics['loss_' + name] = get_loss_metric(loss.detach())
+    total = torch.sum(torch.stack(losses) * self.loss_weights)
+    total.backward()
+    self.optimizer.start_allreduce()
+    self.optimizer.step()
+    loss_metrics['loss'] = get_loss_metric(total.detach())
+    return 1, loss_metrics, (batch, out)
+
+  def _val_step(self, loader, compute_metrics=True):
+    batch = self._request_data(loader, volatile=True)
+    if batch is None:
+      return None, None
+    out = self.model(*self.test_model_input_fn(batch))
+    loss_metrics = {}
+    if compute_metrics:
+      for name, criterion in self.criteria.items():
+        loss_metrics['loss_' + name] = get_loss_metric(criterion(out, batch).detach())
+    return loss_metrics, (batch, out)
+
+  def _compute_train_metrics(self, data):
+    return {name: fn(data[1], data[0]) for name, fn in self.train_metric_fns.items()}
+
+  def _compute_test_metrics(self, data):
+    return {name: fn(data[1], data[0]) for name, fn in self.val_metric_fns.items()}
+
+  def _set_train(self):
+    self.model.train()
+
+  def _set_test(self):
+    self.model.eval()

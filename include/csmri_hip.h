@@ -158,14 +158,16 @@ int csmri_fold_pad_grad(int dtype, const void* gpad, void* out, int out_pix_stri
  * Replaces DataConsistencyInKspace.perform, Fft2d/Ifft2d and data_consistency
  * (data/reconstruction/deep_med_lib/my_pytorch/myfft.py:78-163):
  *     out = orthoIFFT2( (1 - m) * orthoFFT2(x) + k0 )
- * x, k0, out: interleaved complex fp32 [B][H][W][2]; mask: uint8 [B][H][W]
+ * x: interleaved complex fp32, pixel p at x + p*x_pix_stride (2 = dense; 8 reads
+ * channels 0,1 of a channel-padded conv output directly); k0, out: dense
+ * interleaved complex fp32 [B][H][W][2]; mask: uint8 [B][H][W]
  * (1 = sampled).  k0 == NULL gives the adjoint (backward w.r.t. x,
  * myfft.py:92-102,119-128).  H, W in {32,64,128,256,512}.  work: 2*B*H*W*8 bytes.
  * out_pad (optional): also write the result as a channel-padded NHWC tensor
  * [B][H][W][8] of dtype out_pad_dtype (channels 0,1 = re,im; 2..7 = 0) -- the
  * input layout of the next conv block.
  * ---------------------------------------------------------------------- */
-int csmri_dc(const float* x, const float* k0, const uint8_t* mask, float* out,
+int csmri_dc(const float* x, int x_pix_stride, const float* k0, const uint8_t* mask, float* out,
              void* out_pad, int out_pad_dtype, float* work, int B, int H, int W,
              void* stream);
 size_t csmri_dc_work_bytes(int B, int H, int W);
@@ -282,6 +284,10 @@ int csmri_adam(float* p, const float* g, float* m, float* v, long long n, float 
 /* misc */
 int csmri_fill_f32(float* p, long long n, float v, void* stream);
 int csmri_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream);
+/* dst[p*dst_ps + c] = (c < C_src ? src[p*src_ps + c] : 0) for c < C_dst: channel
+ * slice / zero-pad / dtype cast of an NHWC tensor in one pass */
+int csmri_copy_channels(const void* src, int src_dtype, int src_pix_stride, int C_src, void* dst,
+                        int dst_dtype, int dst_pix_stride, int C_dst, long long npix, void* stream);
 
 #ifdef __cplusplus
 }

@@ -152,10 +152,12 @@ def test_conv_two_source_concat(hip, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
-@pytest.mark.parametrize('shape', [(2, 16, 32, 64, 64), (2, 64, 128, 8, 8)], ids=['stats_fused', 'stats_standalone'])
+@pytest.mark.parametrize('shape', [(2, 16, 32, 64, 64, 1), (2, 64, 128, 8, 8, 1), (2, 8, 16, 64, 64, 2),
+                                   (2, 8, 8, 32, 32, 1), (8, 32, 64, 32, 32, 2)],
+                         ids=['stats_fused', 'stats_standalone', 'c16_s2', 'c8', 'c64_s2'])
 def test_conv_bn_act(hip, dtype, shape):
   ops = hip.ops
-  b, cin, cout, h, w = shape
+  b, cin, cout, h, w, stride = shape
   g = torch.Generator().manual_seed(11)
   x = torch.randn(b, cin, h, w, generator=g)
   wt = torch.randn(cout, cin, 4, 4, generator=g) / math.sqrt(cin * 16)
@@ -164,8 +166,8 @@ def test_conv_bn_act(hip, dtype, shape):
   keep = torch.bernoulli(torch.full((b, cout), 0.5), generator=g) * 2.0
   if dtype == torch.bfloat16:
     x, wt = x.bfloat16().float(), wt.bfloat16().float()
-  pads = O.same_padding(4, 1)
-  layer = ops.ConvLayer(torch.nn.Parameter(wt.cuda()), None, 1, pads, 'reflection', dtype)
+  pads = O.same_padding(4, stride)
+  layer = ops.ConvLayer(torch.nn.Parameter(wt.cuda()), None, stride, pads, 'reflection', dtype)
   bn = ops.BNState(torch.nn.Parameter(gamma.cuda()), torch.nn.Parameter(beta.cuda()),
                    torch.zeros(cout).cuda(), torch.ones(cout).cuda())
   xd = to_dev_nhwc(x, dtype).requires_grad_(True)
@@ -173,7 +175,7 @@ def test_conv_bn_act(hip, dtype, shape):
   xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
   gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
   rm, rv = torch.zeros(cout), torch.ones(cout)
-  yr = F.conv2d(O.pad2d(xr, pads, 'reflection'), wr)
+  yr = F.conv2d(O.pad2d(xr, pads, 'reflection'), wr, stride=stride)
   zr = F.leaky_relu(F.batch_norm(yr, rm, rv, gr, br, True, 0.1, 1e-5), 0.2) * keep[:, :, None, None]
   tol_dtype = dtype
   check('bn fwd', from_dev_nhwc(z, cout), zr.detach(), tol_dtype)
