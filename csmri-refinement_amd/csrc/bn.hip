@@ -1,0 +1,268 @@
+// BatchNorm2d (training) + LeakyReLU + Dropout2d mask on NHWC tensors: batch statistics,
+// normalise+activate, and the two-pass backward.  HBM-bound: every kernel streams its
+// tensors once with 8/16-byte channel vectors; per-channel constants live in registers
+// (a thread owns a fixed group of 4 channels), reductions are deterministic two-stage
+// (per-block partial rows -> fixed-order tree in the finalize kernels).
+#include "common.h"
+
+#define BN_MAX_ROWS 2048
+extern "C" int csmri_bn_stats_rows(int npix) {
+  int r = (npix + 127) / 128;
+  return r < 1 ? 1 : (r > BN_MAX_ROWS ? BN_MAX_ROWS : r);
+}
+static bool bn_channels_ok(int C) { return C >= 8 && C <= 1024 && (C & (C - 1)) == 0; }
+
+template <int DT> __device__ __forceinline__ f32x4_t ld4(const void* p, long long idx) {
+  f32x4_t r;
+  if constexpr (DT == CSMRI_F32) {
+    r = *(const f32x4_t*)((const float*)p + idx);
+  } else {
+    u32x2_t u = *(const u32x2_t*)((const unsigned short*)p + idx);
+    r[0] = __uint_as_float(u[0] << 16); r[1] = __uint_as_float(u[0] & 0xffff0000u);
+    r[2] = __uint_as_float(u[1] << 16); r[3] = __uint_as_float(u[1] & 0xffff0000u);
+  }
+  return r;
+}
+template <int DT> __device__ __forceinline__ void st4(void* p, long long idx, f32x4_t v) {
+  store4(p, idx, DT, v);
+}
+
+// block-wide sum of two doubles (blockDim.x == 256); result valid in thread 0
+__device__ __forceinline__ void block_sum2(double& a, double& b) {
+  __shared__ double sa[4], sb[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sa[w] = a; sb[w] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) { a = sa[0] + sa[1] + sa[2] + sa[3]; b = sb[0] + sb[1] + sb[2] + sb[3]; }
+}
+
+// write one partial row: reduce the per-thread (a, b) over the pixel lanes of the block
+__device__ __forceinline__ void write_partial_row(f32x4_t a, f32x4_t b, int nv, int lanes, int cv,
+                                                  int pl, int C, float* partial) {
+  __shared__ float red[2][256][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { red[0][threadIdx.x][q] = a[q]; red[1][threadIdx.x][q] = b[q]; }
+  __syncthreads();
+  if (pl == 0) {
+    for (int l = 1; l < lanes; ++l)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a[q] += red[0][l * nv + cv][q]; b[q] += red[1][l * nv + cv][q]; }
+    float* row = partial + (size_t)blockIdx.x * 2 * C;
+    *(f32x4_t*)(row + cv * 4) = a;
+    *(f32x4_t*)(row + C + cv * 4) = b;
+  }
+}
+
+// ---- forward statistics (when the conv epilogue did not produce them) -------------
+template <int DT>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const void* y, int ps, int npix, int C, int rows,
+                                                       float* partial) {
+  const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv;
+  const int chunk = (npix + rows - 1) / rows, p0 = blockIdx.x * chunk, p1 = min(npix, p0 + chunk);
+  f32x4_t a = (f32x4_t){0, 0, 0, 0}, b = a;
+#pragma unroll 4
+  for (int p = p0 + pl; p < p1; p += lanes) {
+    f32x4_t v = ld4<DT>(y, (long long)p * ps + cv * 4);
+    a += v; b += v * v;
+  }
+  write_partial_row(a, b, nv, lanes, cv, pl, C, partial);
+}
+extern "C" int csmri_bn_stats(int dtype, const void* y, int pix_stride, int npix, int C, float* partial,
+                              void* stream) {
+  CSMRI_CHECK_ARG(y && partial && npix > 0);
+  if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
+  const int rows = csmri_bn_stats_rows(npix);
+  if (dtype == CSMRI_BF16)
+    hipLaunchKernelGGL(bn_stats_kernel<CSMRI_BF16>, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, pix_stride, npix, C, rows, partial);
+  else
+    hipLaunchKernelGGL(bn_stats_kernel<CSMRI_F32>, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, pix_stride, npix, C, rows, partial);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int rows, int C, int C_real,
+                                                          double count, float eps, float momentum, float* mean,
+                                                          float* invstd, float* rmean, float* rvar) {
+  const int c = blockIdx.x;       // one block per channel, fixed-order tree over the rows
+  double s1 = 0, s2 = 0;
+  for (int r = threadIdx.x; r < rows; r += 256) { s1 += partial[(size_t)r * 2 * C + c]; s2 += partial[(size_t)r * 2 * C + C + c]; }
+  block_sum2(s1, s2);
+  if (threadIdx.x != 0) return;
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  if (var < 0) var = 0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean && c < C_real) {
+    const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+  }
+}
+extern "C" int csmri_bn_finalize(const float* partial, int rows, int C, int C_real, long long count, float eps,
+                                 float momentum, float* mean, float* invstd, float* running_mean,
+                                 float* running_var, void* stream) {
+  CSMRI_CHECK_ARG(partial && mean && invstd && rows > 0 && count > 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, rows, C, C_real,
+                     (double)count, eps, momentum, mean, invstd, running_mean, running_var);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+// ---- z = drop[b,c] * lrelu((y-mean)*invstd*gamma + beta) ---------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void bn_act_kernel(const void* y, int yps, void* z, int zps, int B, int HW,
+                                                     int C, int C_real, const float* mean, const float* invstd,
+                                                     const float* gamma, const float* beta, float slope,
+                                                     const float* drop) {
+  const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool ok = c + q < C_real;
+    sc[q] = ok ? invstd[c + q] * gamma[c + q] : 0.f;
+    sh[q] = ok ? beta[c + q] - mean[c + q] * sc[q] : 0.f;
+  }
+  const int npix = B * HW;
+  for (int p = blockIdx.x * lanes + pl; p < npix; p += gridDim.x * lanes) {
+    f32x4_t v = ld4<DT>(y, (long long)p * yps + c), o;
+    f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+    if (drop) dm = *(const f32x4_t*)(drop + (size_t)(p / HW) * C + c);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // same operation order as (y-mean)*invstd*gamma+beta up to one rounding
+      float t = (v[q] - (c + q < C_real ? mean[c + q] : 0.f));
+      t = t * sc[q] + (c + q < C_real ? beta[c + q] : 0.f);
+      t = t < 0.f ? t * slope : t;
+      o[q] = t * dm[q];
+    }
+    st4<DT>(z, (long long)p * zps + c, o);
+  }
+}
+extern "C" int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride, int B, int HW,
+                            int C, int C_real, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, float slope, const float* dropmask, void* stream) {
+  CSMRI_CHECK_ARG(y && z && mean && invstd && gamma && beta);
+  if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
+  const int lanes = 256 / (C / 4);
+  int blocks = (B * HW + lanes - 1) / lanes; if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CSMRI_BF16)
+    hipLaunchKernelGGL(bn_act_kernel<CSMRI_BF16>, dim3(blocks), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask);
+  else
+    hipLaunchKernelGGL(bn_act_kernel<CSMRI_F32>, dim3(blocks), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+// ---- backward pass 1: partials of dyh = dz*drop*lrelu'(z) and dyh*xhat -------------
+template <int DT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dz, int dzps, const void* y, int yps,
+                                                            const void* z, int zps, int npix, int HW, int C,
+                                                            const float* mean, const float* invstd, float slope,
+                                                            const float* drop, int rows, float* partial) {
+  const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
+  const f32x4_t mu = *(const f32x4_t*)(mean + c), is = *(const f32x4_t*)(invstd + c);
+  const int chunk = (npix + rows - 1) / rows, p0 = blockIdx.x * chunk, p1 = min(npix, p0 + chunk);
+  f32x4_t a = (f32x4_t){0, 0, 0, 0}, b = a;
+#pragma unroll 4
+  for (int p = p0 + pl; p < p1; p += lanes) {
+    f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c),
+            zz = ld4<DT>(z, (long long)p * zps + c);
+    f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+    if (drop) dm = *(const f32x4_t*)(drop + (size_t)(p / HW) * C + c);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float d = g[q] * (zz[q] > 0.f ? 1.f : slope) * dm[q];
+      a[q] += d;
+      b[q] += d * (yy[q] - mu[q]) * is[q];
+    }
+  }
+  write_partial_row(a, b, nv, lanes, cv, pl, C, partial);
+}
+extern "C" int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride, const void* y, int y_pix_stride,
+                                   const void* z, int z_pix_stride, int B, int HW, int C, const float* mean,
+                                   const float* invstd, float slope, const float* dropmask, float* partial,
+                                   void* stream) {
+  CSMRI_CHECK_ARG(dz && y && z && partial);
+  if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
+  const int npix = B * HW, rows = csmri_bn_stats_rows(npix);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CSMRI_BF16)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<CSMRI_BF16>, dim3(rows), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, npix, HW, C, mean, invstd, slope, dropmask, rows, partial);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<CSMRI_F32>, dim3(rows), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, npix, HW, C, mean, invstd, slope, dropmask, rows, partial);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* partial, int rows, int C, int C_real,
+                                                              float* dgamma, float* dbeta, int accumulate) {
+  const int c = blockIdx.x;
+  double s1 = 0, s2 = 0;
+  for (int r = threadIdx.x; r < rows; r += 256) { s1 += partial[(size_t)r * 2 * C + c]; s2 += partial[(size_t)r * 2 * C + C + c]; }
+  block_sum2(s1, s2);
+  if (threadIdx.x != 0) return;
+  partial[(size_t)rows * 2 * C + c] = (float)s1;          // totals row (index `rows`)
+  partial[(size_t)rows * 2 * C + C + c] = (float)s2;
+  if (c < C_real) {
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+  }
+}
+
+// ---- backward pass 2: dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)) ----
+template <int DT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dz, int dzps, const void* y, int yps,
+                                                           const void* z, int zps, void* dy, int dyps, int npix,
+                                                           int HW, int C, int C_real, const float* mean,
+                                                           const float* invstd, const float* gamma, float slope,
+                                                           const float* drop, const float* totals, float inv_count) {
+  const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
+  const f32x4_t mu = *(const f32x4_t*)(mean + c), is = *(const f32x4_t*)(invstd + c);
+  float gs[4], m1[4], m2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    gs[q] = c + q < C_real ? gamma[c + q] * is[q] : 0.f;
+    m1[q] = totals[c + q] * inv_count;
+    m2[q] = totals[C + c + q] * inv_count;
+  }
+  for (int p = blockIdx.x * lanes + pl; p < npix; p += gridDim.x * lanes) {
+    f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c),
+            zz = ld4<DT>(z, (long long)p * zps + c), o;
+    f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+    if (drop) dm = *(const f32x4_t*)(drop + (size_t)(p / HW) * C + c);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float d = g[q] * (zz[q] > 0.f ? 1.f : slope) * dm[q];
+      const float xh = (yy[q] - mu[q]) * is[q];
+      o[q] = gs[q] * (d - m1[q] - xh * m2[q]);
+    }
+    st4<DT>(dy, (long long)p * dyps + c, o);
+  }
+}
+// partial must hold (rows + 1) * 2 * C floats (the extra row receives the totals)
+extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, const void* y, int y_pix_stride,
+                                  const void* z, int z_pix_stride, void* dy, int dy_pix_stride, int B, int HW,
+                                  int C, int C_real, const float* mean, const float* invstd, const float* gamma,
+                                  float slope, const float* dropmask, const float* partial, int rows,
+                                  float* dgamma, float* dbeta, int accumulate, void* stream) {
+  CSMRI_CHECK_ARG(dz && y && z && dy && partial && rows > 0);
+  if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (float*)partial, rows, C, C_real, dgamma,
+                     dbeta, accumulate);
+  CSMRI_LAUNCH_CHECK();
+  const int npix = B * HW, lanes = 256 / (C / 4);
+  int blocks = (npix + lanes - 1) / lanes; if (blocks > 4096) blocks = 4096;
+  const float* totals = partial + (size_t)rows * 2 * C;
+  const float inv = 1.0f / ((float)B * (float)HW);
+  if (dtype == CSMRI_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<CSMRI_BF16>, dim3(blocks), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<CSMRI_F32>, dim3(blocks), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}

@@ -128,231 +128,6 @@ extern "C" int csmri_pack_weight(int mode, int dtype, const float* w_ref, int Co
   return CSMRI_OK;
 }
 
-// -------------------------------------------------------------- BatchNorm ----
-// partial[row][0][c] = sum, partial[row][1][c] = sum of squares over the row's pixels
-#define BN_MAX_ROWS 2048
-extern "C" int csmri_bn_stats_rows(int npix) {
-  int r = (npix + 127) / 128;
-  return r < 1 ? 1 : (r > BN_MAX_ROWS ? BN_MAX_ROWS : r);
-}
-
-// block-wide sum of two doubles (blockDim.x == 256); result valid in thread 0
-__device__ __forceinline__ void block_sum2(double& a, double& b) {
-  __shared__ double sa[4], sb[4];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { sa[w] = a; sb[w] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) { a = sa[0] + sa[1] + sa[2] + sa[3]; b = sb[0] + sb[1] + sb[2] + sb[3]; }
-}
-
-// generic two-quantity per-channel partial reduction; F gives (q0, q1) per element vector
-template <class F>
-__device__ void channel_partials(long long npix, int C, int rows, float* partial, F f) {
-  __shared__ float red[2][256][4];
-  const int nv = C >> 2;                       // channel vectors
-  const int lanes = 256 / nv;                  // pixel lanes per block (nv <= 256, power of 2)
-  const int cv = threadIdx.x % nv, pl = threadIdx.x / nv;
-  const long long chunk = (npix + rows - 1) / rows;
-  const long long p0 = blockIdx.x * chunk, p1 = min(npix, p0 + chunk);
-  f32x4_t a = (f32x4_t){0, 0, 0, 0}, b = (f32x4_t){0, 0, 0, 0};
-  if (pl < lanes) {
-#pragma unroll 4
-    for (long long p = p0 + pl; p < p1; p += lanes) f(p, cv * 4, a, b);
-  }
-  for (int q = 0; q < 4; ++q) { red[0][threadIdx.x][q] = a[q]; red[1][threadIdx.x][q] = b[q]; }
-  __syncthreads();
-  if (pl == 0) {
-    for (int l = 1; l < lanes; ++l)
-      for (int q = 0; q < 4; ++q) { a[q] += red[0][l * nv + cv][q]; b[q] += red[1][l * nv + cv][q]; }
-    float* row = partial + (size_t)blockIdx.x * 2 * C;
-    *(f32x4_t*)(row + cv * 4) = a;
-    *(f32x4_t*)(row + C + cv * 4) = b;
-  }
-}
-
-__global__ __launch_bounds__(256) void bn_stats_kernel(int dt, const void* y, int ps, long long npix,
-                                                       int C, int rows, float* partial) {
-  channel_partials(npix, C, rows, partial, [&](long long p, int c, f32x4_t& a, f32x4_t& b) {
-    f32x4_t v = load4(y, p * ps + c, dt);
-    a += v; b += v * v;
-  });
-}
-
-static bool bn_channels_ok(int C) { return C >= 8 && C <= 1024 && (C & (C - 1)) == 0; }
-
-extern "C" int csmri_bn_stats(int dtype, const void* y, int pix_stride, int npix, int C,
-                              float* partial, void* stream) {
-  CSMRI_CHECK_ARG(y && partial && npix > 0);
-  if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
-  const int rows = csmri_bn_stats_rows(npix);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dtype, y,
-                     pix_stride, (long long)npix, C, rows, partial);
-  CSMRI_LAUNCH_CHECK();
-  return CSMRI_OK;
-}
-
-__global__ void bn_finalize_kernel(const float* partial, int rows, int C, int C_real, double count,
-                                   float eps, float momentum, float* mean, float* invstd,
-                                   float* rmean, float* rvar) {
-  // one 256-thread block per channel: fixed-order tree over the partial rows
-  const int c = blockIdx.x;
-  double s1 = 0, s2 = 0;
-  for (int r = threadIdx.x; r < rows; r += 256) { s1 += partial[(size_t)r * 2 * C + c]; s2 += partial[(size_t)r * 2 * C + C + c]; }
-  block_sum2(s1, s2);
-  if (threadIdx.x != 0) return;
-  const double m = s1 / count;
-  double var = s2 / count - m * m;
-  if (var < 0) var = 0;
-  mean[c] = (float)m;
-  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (rmean && c < C_real) {
-    const double unbiased = count > 1 ? var * count / (count - 1) : var;
-    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
-  }
-}
-extern "C" int csmri_bn_finalize(const float* partial, int rows, int C, int C_real, long long count,
-                                 float eps, float momentum, float* mean, float* invstd,
-                                 float* running_mean, float* running_var, void* stream) {
-  CSMRI_CHECK_ARG(partial && mean && invstd && rows > 0 && count > 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream,
-                     partial, rows, C, C_real, (double)count, eps, momentum, mean, invstd,
-                     running_mean, running_var);
-  CSMRI_LAUNCH_CHECK();
-  return CSMRI_OK;
-}
-
-__global__ void bn_act_kernel(int dt, const void* y, int yps, void* z, int zps, int B, long long HW,
-                              int C, int C_real, const float* mean, const float* invstd,
-                              const float* gamma, const float* beta, float slope, const float* drop) {
-  const int nv = C >> 2;
-  GRID_STRIDE(i, (long long)B * HW * nv) {
-    const int c = (int)(i % nv) * 4;
-    const long long p = i / nv;
-    const int b = (int)(p / HW);
-    f32x4_t v = load4(y, p * yps + c, dt), o;
-    for (int q = 0; q < 4; ++q) {
-      const int cc = c + q;
-      float t = 0.f;
-      if (cc < C_real) {
-        t = (v[q] - mean[cc]) * invstd[cc] * gamma[cc] + beta[cc];
-        t = t < 0.f ? t * slope : t;
-        if (drop) t *= drop[(size_t)b * C + cc];
-      }
-      o[q] = t;
-    }
-    store4(z, p * zps + c, dt, o);
-  }
-}
-extern "C" int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride,
-                            int B, int HW, int C, int C_real, const float* mean, const float* invstd,
-                            const float* gamma, const float* beta, float slope, const float* dropmask,
-                            void* stream) {
-  CSMRI_CHECK_ARG(y && z && mean && invstd && gamma && beta && C % 4 == 0);
-  long long n = (long long)B * HW * (C / 4);
-  hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dtype, y,
-                     y_pix_stride, z, z_pix_stride, B, (long long)HW, C, C_real, mean, invstd, gamma,
-                     beta, slope, dropmask);
-  CSMRI_LAUNCH_CHECK();
-  return CSMRI_OK;
-}
-
-// dyh = dz * drop * lrelu'(z); partials of (dyh, dyh * xhat)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    int dt, const void* dz, int dzps, const void* y, int yps, const void* z, int zps, int B,
-    long long HW, int C, const float* mean, const float* invstd, float slope, const float* drop,
-    int rows, float* partial, int C_real) {
-  channel_partials((long long)B * HW, C, rows, partial, [&](long long p, int c, f32x4_t& a, f32x4_t& b2) {
-    f32x4_t g = load4(dz, p * dzps + c, dt), yy = load4(y, p * yps + c, dt), zz = load4(z, p * zps + c, dt);
-    const int b = (int)(p / HW);
-    for (int q = 0; q < 4; ++q) {
-      const int cc = c + q;
-      if (cc >= C_real) continue;
-      float d = g[q] * (zz[q] > 0.f ? 1.f : slope);
-      if (drop) d *= drop[(size_t)b * C_real + cc];
-      a[q] += d;
-      b2[q] += d * (yy[q] - mean[cc]) * invstd[cc];
-    }
-  });
-}
-extern "C" int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride, const void* y,
-                                   int y_pix_stride, const void* z, int z_pix_stride, int B, int HW,
-                                   int C, const float* mean, const float* invstd, float slope,
-                                   const float* dropmask, float* partial, void* stream) {
-  CSMRI_CHECK_ARG(dz && y && z && partial);
-  if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
-  const int rows = csmri_bn_stats_rows(B * HW);
-  // note: C_real == C here is fine because pad channels carry zero gradients
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dtype, dz,
-                     dz_pix_stride, y, y_pix_stride, z, z_pix_stride, B, (long long)HW, C, mean, invstd,
-                     slope, dropmask, rows, partial, C);
-  CSMRI_LAUNCH_CHECK();
-  return CSMRI_OK;
-}
-
-__global__ void bn_bwd_finalize_kernel(float* partial, int rows, int C, int C_real, float* dgamma,
-                                       float* dbeta, int accumulate) {
-  const int c = blockIdx.x;
-  double s1 = 0, s2 = 0;
-  for (int r = threadIdx.x; r < rows; r += 256) { s1 += partial[(size_t)r * 2 * C + c]; s2 += partial[(size_t)r * 2 * C + C + c]; }
-  block_sum2(s1, s2);
-  if (threadIdx.x != 0) return;
-  // totals go to a separate tail region [rows][2][C] -> index rows
-  partial[(size_t)rows * 2 * C + c] = (float)s1;
-  partial[(size_t)rows * 2 * C + C + c] = (float)s2;
-  if (c < C_real) {
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
-  }
-}
-__global__ void bn_bwd_apply_kernel(int dt, const void* dz, int dzps, const void* y, int yps,
-                                    const void* z, int zps, void* dy, int dyps, int B, long long HW,
-                                    int C, int C_real, const float* mean, const float* invstd,
-                                    const float* gamma, float slope, const float* drop,
-                                    const float* totals, float inv_count) {
-  const int nv = C >> 2;
-  GRID_STRIDE(i, (long long)B * HW * nv) {
-    const int c = (int)(i % nv) * 4;
-    const long long p = i / nv;
-    const int b = (int)(p / HW);
-    f32x4_t g = load4(dz, p * dzps + c, dt), yy = load4(y, p * yps + c, dt), zz = load4(z, p * zps + c, dt), o;
-    for (int q = 0; q < 4; ++q) {
-      const int cc = c + q;
-      float r = 0.f;
-      if (cc < C_real) {
-        float d = g[q] * (zz[q] > 0.f ? 1.f : slope);
-        if (drop) d *= drop[(size_t)b * C + cc];
-        const float xh = (yy[q] - mean[cc]) * invstd[cc];
-        r = gamma[cc] * invstd[cc] * (d - totals[cc] * inv_count - xh * totals[C + cc] * inv_count);
-      }
-      o[q] = r;
-    }
-    store4(dy, p * dyps + c, dt, o);
-  }
-}
-// partial must hold (rows + 1) * 2 * C floats (the extra row receives the totals)
-extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, const void* y,
-                                  int y_pix_stride, const void* z, int z_pix_stride, void* dy,
-                                  int dy_pix_stride, int B, int HW, int C, int C_real,
-                                  const float* mean, const float* invstd, const float* gamma,
-                                  float slope, const float* dropmask, const float* partial, int rows,
-                                  float* dgamma, float* dbeta, int accumulate, void* stream) {
-  CSMRI_CHECK_ARG(dz && y && z && dy && partial && rows > 0);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (float*)partial,
-                     rows, C, C_real, dgamma, dbeta, accumulate);
-  CSMRI_LAUNCH_CHECK();
-  long long n = (long long)B * HW * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n)), dim3(256), 0, st, dtype, dz,
-                     dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, B,
-                     (long long)HW, C, C_real, mean, invstd, gamma, slope, dropmask,
-                     partial + (size_t)rows * 2 * C, 1.0f / ((float)B * (float)HW));
-  CSMRI_LAUNCH_CHECK();
-  return CSMRI_OK;
-}
-
 __global__ void act_bwd_kernel(int dt, const void* dz, int dzps, const void* z, int zps, void* dy,
                                int dyps, long long npix, int C, float slope) {
   const int nv = C >> 2;
