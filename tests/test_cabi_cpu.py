@@ -1,0 +1,119 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/csmri_hip.h declares, rejects bad arguments without touching a GPU, and the
+product fails loudly (no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, PKG
+
+
+def header_symbols():
+  txt = open(os.path.join(ROOT, 'include', 'csmri_hip.h')).read()
+  txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+  return sorted(set(re.findall(r'\b(csmri_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+  import csmri_hip
+  syms = header_symbols()
+  assert len(syms) >= 40
+  for s in syms:
+    assert hasattr(csmri_hip.lib._lib, s), 'libcsmri_hip.so lacks %s' % s
+  # and the binding covers the whole header
+  assert set(syms) == set(csmri_hip.lib.EXPORTS), set(syms) ^ set(csmri_hip.lib.EXPORTS)
+  assert csmri_hip.lib.raw('csmri_version')() >= 100
+
+
+def test_argument_validation_needs_no_gpu():
+  import ctypes as C
+  import csmri_hip
+  lib = csmri_hip.lib
+  d = lib.GConvDesc()
+  assert lib.raw('csmri_gconv')(C.byref(d), None) == -1            # CSMRI_E_ARG
+  w = lib.WGradDesc()
+  assert lib.raw('csmri_wgrad')(C.byref(w), None) == -1
+  assert lib.raw('csmri_dc')(None, 2, None, None, None, None, 0, None, 1, 64, 64, None) == -1
+  assert lib.raw('csmri_adam')(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) == -1
+  assert b'bad argument' in lib.raw('csmri_error_string')(-1)
+  assert lib.raw('csmri_pack_weight_bytes')(0, lib.BF16, 32, 2, 3, 3) == 128 * 128 * 2
+  assert lib.raw('csmri_pack_weight_bytes')(2, lib.F32, 64, 16, 4, 4) == 4 * 128 * 256 * 4
+  assert lib.raw('csmri_bn_stats_rows')(524288) == 2048
+
+
+def test_no_cpu_fallback():
+  import csmri_hip
+  x = torch.zeros(1, 2, 8, 8)
+  with pytest.raises(RuntimeError):
+    csmri_hip.ops.nchw_to_nhwc(x, torch.bfloat16)
+  import utils
+  with pytest.raises(RuntimeError):
+    utils.device_for('')
+
+
+def test_product_never_imports_the_oracle():
+  bad = []
+  for root, _, files in os.walk(PKG):
+    for fn in files:
+      if fn.endswith('.py'):
+        src = open(os.path.join(root, fn)).read()
+        if 'csmri_oracle' in src or 'import oracle' in src:
+          bad.append(os.path.join(root, fn))
+  assert not bad, bad
+
+
+def test_configuration_semantics(tmp_path):
+  from utils.config import Configuration
+  base = tmp_path / 'base.json'
+  base.write_text('{"seed": 3, "a": 1, "nested": {"x": 1}}')
+  top = tmp_path / 'top.json'
+  top.write_text('{"#include": "base.json", "b": [1, 2], "include": {"sub": "base.json"}}')
+  conf = Configuration.from_json(str(top))
+  assert conf.seed == 3 and conf.a == 1 and conf.b == [1, 2] and conf.sub['a'] == 1
+  conf.update({'lr': '0.5', 'flag': 'True', 'n': '7', 'lst': '[1, 2.5, x]', 'seed': '9'})
+  assert conf.lr == 0.5 and conf.flag is True and conf.n == 7 and conf.lst == [1, 2.5, 'x'] and conf.seed == 9
+  assert conf.get_attr('missing', default=4) == 4 and conf.get_attr('missing', alternative='a') == 1
+  assert conf.to_param_dict(['a'], ['b', 'zzz'], {'a': 'alpha'}) == {'alpha': 1, 'b': [1, 2]}
+  for name in ('1-recnet.json', '2-refinement.json'):
+    c = Configuration.from_json(os.path.join(PKG, 'configs', name))
+    assert c.runner_type in ('standard', 'adversarial')
+  ref = '/root/reference/configs/2-refinement.json'
+  if os.path.exists(ref):       # the reference's own config loads unchanged (build container only)
+    c = Configuration.from_json(ref)
+    assert c.generator_model['learnable_model']['encode_filters'] == [32, 64, 128]
+
+
+def test_model_state_dict_key_space():
+  """SURVEY App. A-12 key space of the full-width models (constructed on CPU)."""
+  from utils.config import Configuration
+  from models import construct_model
+  conf = Configuration.from_json(os.path.join(PKG, 'configs', '2-refinement.json'))
+  g = construct_model(Configuration.from_dict(conf.generator_model, conf), 'RefinementWrapper', cuda='0')
+  d = construct_model(Configuration.from_dict(conf.discriminator_model, conf), 'CNNDiscriminator')
+  gk, dk = set(g.state_dict()), set(d.state_dict())
+  assert 'scale' in gk and 'pretrained_model.conv_blocks.2.layers.7.bias' in gk
+  assert 'learnable_model.concat_decode_units.1.decode.0.encode.5.weight' in gk
+  assert 'learnable_model.encode_units.0.encode.2.running_var' in gk and 'learnable_model.head.0.bias' in gk
+  assert {'convs.%d.weight' % i for i in (1, 4, 8, 12, 17, 22)} <= dk and 'convs.1.bias' in dk
+  assert {'convs.%d.running_mean' % i for i in (5, 9, 13, 18, 23)} <= dk
+  assert {'final_conv.0.weight', 'final_conv.0.bias'} <= dk and 'convs.4.bias' not in dk
+  assert sum(p.numel() for p in g.parameters()) == 920034 and len(list(g.parameters())) == 39
+  assert sum(p.numel() for p in d.parameters()) == 27941697
+  assert float(g.scale) == 0.0
+  assert g.pretrained_model.conv_blocks[0].layers['1'].weight.shape == (32, 2, 3, 3)
+
+
+def test_image_pool_semantics():
+  import random
+  from utils.image_pool import ImagePool
+  import csmri_oracle as O
+  random.seed(5)
+  a, b = ImagePool(4), O.ImagePool(4)
+  for step in range(6):
+    x = torch.arange(3 * 2, dtype=torch.float32).reshape(3, 1, 2, 1) + 100 * step
+    dec = a.decide(3)
+    ra = a.query(x, dec)
+    rb = b.query(x, [(u, i) for u, i in dec])
+    assert torch.equal(ra, rb), step
