@@ -42,6 +42,7 @@ def parse():
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--no-roofline', action='store_true')
   p.add_argument('--batch', type=int, default=PER_GPU_BATCH)
+  p.add_argument('--no-graphs', action='store_true', help='eager launches instead of hipGraph replay')
   return p.parse_args()
 
 
@@ -124,6 +125,7 @@ def roofline(runner, loader, steps=2):
   """Instrumented steps: HIP events around every conv-library launch."""
   import torch
   from csmri_hip import ops
+  runner.disable_graphs()       # per-launch events need eager launches
   ops.PROFILE = []
   runner.train_epoch(DeviceLoader(loader.batches, steps), 1)
   torch.cuda.synchronize()
@@ -183,6 +185,9 @@ def main():
   psnr_hip = PSNRMetric()({'pred': out0['pred'][:2]}, {'target': batches[0]['target'][:2]}).value
   # undo the BN running-stat update of that probe forward? it does not affect training outputs
 
+  if not args.no_graphs:
+    # capture the step once (3 eager steps inside); the timed region replays hipGraphs
+    runner.enable_graphs(batches[0])
   loader = DeviceLoader(batches, args.warmup)
   if args.warmup > 0:
     runner.train_epoch(loader, 1)
@@ -211,6 +216,7 @@ def main():
       'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+      'launch_mode': 'eager' if args.no_graphs else 'hipGraph replay (4 segments, collectives eager)',
       'config': {'workload': 'C3/C4 2-refinement GAN step: frozen RecNet(3,3,32)+3 DC, UNET, CNNDiscriminator, '
                              'VGG19 loss, Adam x2; 256x256, 4x Cartesian, %d slices/GPU' % args.batch,
                  'per_gpu_batch': args.batch, 'global_batch': ws * args.batch,

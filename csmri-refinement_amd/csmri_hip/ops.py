@@ -739,3 +739,10 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
   """In-place Adam on flat fp32 buffers."""
   lib.call('csmri_adam', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
            float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream())
+
+
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0):
+  """Adam with the step counter (int32 device tensor, steps already taken) on the device --
+  the form that can be captured into a hipGraph and replayed."""
+  lib.call('csmri_adam_dev', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
+           float(beta1), float(beta2), float(eps), step_dev.data_ptr(), float(grad_scale), stream())

@@ -360,3 +360,49 @@ extern "C" int csmri_adam(float* p, const float* g, float* m, float* v, long lon
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
+
+// Same update with the step count held in device memory (*step_dev = number of steps already
+// taken; this launch performs step *step_dev + 1 and a trailing 1-thread kernel increments the
+// counter) -- nothing step-dependent is baked into the launch, so the optimizer can live inside
+// a captured hipGraph and be replayed.
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n, float lr,
+                                float b1, float b2, float eps, const int* step_dev, float gscale) {
+  const int step = *step_dev + 1;
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+  const float step_size = lr / bc1;
+  GRID_STRIDE(i4, (n + 3) / 4) {
+    const long long i = i4 * 4;
+    if (i + 4 <= n) {
+      f32x4_t pp = *(f32x4_t*)(p + i), gg = *(const f32x4_t*)(g + i), mm = *(f32x4_t*)(m + i), vv = *(f32x4_t*)(v + i);
+      for (int q = 0; q < 4; ++q) {
+        const float gq = gg[q] * gscale;
+        mm[q] = b1 * mm[q] + (1.f - b1) * gq;
+        vv[q] = b2 * vv[q] + (1.f - b2) * gq * gq;
+        pp[q] -= step_size * (mm[q] / (sqrtf(vv[q]) / bc2_sqrt + eps));
+      }
+      *(f32x4_t*)(p + i) = pp; *(f32x4_t*)(m + i) = mm; *(f32x4_t*)(v + i) = vv;
+    } else {
+      for (long long j = i; j < n; ++j) {
+        const float gq = g[j] * gscale;
+        m[j] = b1 * m[j] + (1.f - b1) * gq;
+        v[j] = b2 * v[j] + (1.f - b2) * gq * gq;
+        p[j] -= step_size * (m[j] / (sqrtf(v[j]) / bc2_sqrt + eps));
+      }
+    }
+  }
+}
+__global__ void incr_kernel(int* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1; }
+extern "C" int csmri_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr,
+                              float beta1, float beta2, float eps, int* step_dev, float grad_scale,
+                              void* stream) {
+  CSMRI_CHECK_ARG(p && g && m && v && n > 0 && step_dev);
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return CSMRI_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, lr, beta1,
+                     beta2, eps, (const int*)step_dev, grad_scale);
+  CSMRI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(64), 0, st, step_dev);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}

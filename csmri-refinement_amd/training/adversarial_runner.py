@@ -23,7 +23,7 @@ import logging
 import torch
 
 import utils
-from metrics import get_metric_fn, get_loss_metric
+from metrics import get_metric_fn, get_loss_metric, MaxMetric
 from models import construct_model
 from models.criteria import get_criterion
 from training.adversarial_training import get_discriminator_input_fn
@@ -122,6 +122,8 @@ class AdversarialRunner(BaseRunner):
     self.discriminator_enabled = True
     self.generator_enabled = True
     self.pool_decisions = None            # optional injected image-pool decisions (tests)
+    self._graph = None
+    self._last_metrics = None
 
   # -- reference surface -------------------------------------------------------
   def get_named_outputs(self, data):
@@ -174,57 +176,176 @@ class AdversarialRunner(BaseRunner):
     optimizer.step()
     return total.detach()
 
+  # ---- the training step, in four segments separated by the two collectives --------
+  # S1: G fwd, D(fake.detach via pool), D(real), D losses, D backward
+  #     -> all-reduce of D's gradient bucket starts (async, RCCL stream)
+  # S2: third D forward (with gradient to G), G losses (GAN, FM, VGG, FeaturePenalty)
+  #     -> wait for D's bucket
+  # S3: D Adam step, then G backward THROUGH the updated D (faithful ordering A)
+  #     -> all-reduce of G's bucket
+  # S4: G Adam step, training metrics, all scalars stacked into one device vector
+  # Eager mode runs the segments back to back; graph mode (enable_graphs) captures each
+  # segment into a hipGraph once and replays them, the collectives staying eager between.
+
+  def _seg1(self, st):
+    batch = st['batch']
+    gen_inp = self.train_model_input_fn(batch)
+    st['gen_inp0'] = gen_inp[0]
+    out_gen = self.gen(*gen_inp)
+    st['out_gen'] = out_gen
+    out_fake_d = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False,
+                                                   detach=True, pool_decisions=self.pool_decisions))
+    out_real = self.disc(nhwc=self.disc_input_fn(batch['target'], gen_inp[0], out_gen,
+                                                 is_real_input=True, detach=True))
+    st['out_disc_real'] = out_real
+    names, vals, disc_losses = [], [], []
+    for name, criterion in self.disc_adv_criteria.items():
+      loss = criterion(out_fake_d, out_real)
+      disc_losses.append(loss)
+      names.append('disc_loss_' + name)
+      vals.append(loss.detach())
+    total_disc = self._weighted_total(disc_losses, self.disc_loss_weights)
+    self.disc_optimizer.zero_grad()
+    total_disc.backward()
+    names.append('disc_loss')
+    vals.append(total_disc.detach())
+    st['names'], st['vals'] = names, vals
+
+  def _seg2(self, st):
+    batch, out_gen = st['batch'], st['out_gen']
+    self.disc.set_wgrad(False)     # D's weight gradients of this pass are discarded (A-5)
+    out_fake = self.disc(nhwc=self.disc_input_fn(out_gen, st['gen_inp0'], out_gen,
+                                                 is_real_input=False, detach=False))
+    self.disc.set_wgrad(True)
+    st['out_disc_fake'] = out_fake
+    gen_losses = []
+    for name, criterion in self.gen_adv_criteria.items():
+      loss = criterion(out_fake, st['out_disc_real'])
+      gen_losses.append(loss)
+      st['names'].append('gen_loss_' + name)
+      st['vals'].append(loss.detach())
+    for name, criterion in self.gen_criteria.items():
+      loss = criterion(out_gen, batch)
+      gen_losses.append(loss)
+      st['names'].append('gen_loss_' + name)
+      st['vals'].append(loss.detach())
+    st['total_gen'] = self._weighted_total(gen_losses, self.gen_loss_weights)
+
+  def _seg3(self, st):
+    self.disc_optimizer.apply()
+    self.gen_optimizer.zero_grad()
+    st['total_gen'].backward()
+    st['names'].append('gen_loss')
+    st['vals'].append(st['total_gen'].detach())
+
+  def _seg4(self, st):
+    self.gen_optimizer.apply()
+    data = (st['batch'], st['out_gen'], st['out_disc_fake'], st['out_disc_real'])
+    metrics = self._compute_train_metrics(data)
+    st['metric_names'] = list(metrics.keys())
+    vec = [v.float().reshape(()) for v in st['vals']] + \
+          [m.sum_values.float().reshape(()) if torch.is_tensor(m.sum_values)
+           else torch.tensor(float(m.sum_values), device=self.device) for m in metrics.values()]
+    st['vec'] = torch.stack(vec)
+
+  def _run_segments_eager(self, st):
+    self._seg1(st)
+    self.disc_optimizer.start_allreduce()
+    self._seg2(st)
+    self.disc_optimizer.wait_allreduce()
+    self._seg3(st)
+    self.gen_optimizer.start_allreduce()
+    self.gen_optimizer.wait_allreduce()
+    self._seg4(st)
+
+  def enable_graphs(self, example_batch, warmup=3):
+    """Capture the four segments as hipGraphs (shared memory pool) for this batch shape.
+    ``example_batch``: device batch dict; its values seed the static input buffers."""
+    assert self.pool_decisions is None and not self.disc.injected_dropout, \
+        'graph mode draws its own randomness'
+    static = {k: v.detach().clone() for k, v in example_batch.items()}
+    self._set_train()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(warmup):
+        self._run_segments_eager({'batch': static})
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    pool = getattr(self.disc_input_fn, 'image_pool', None)
+    bns = [m for net in (self.gen, self.disc) for m in net.modules() if hasattr(m, 'batches_tracked')]
+    before = [m.batches_tracked for m in bns]
+    if pool is not None:
+      pool.prepare(torch.empty((static['inp'].shape[0],) + tuple(pool.buffer.shape[1:]),
+                               dtype=pool.buffer.dtype, device=self.device))
+      pool.external_plan = True
+    st = {'batch': static}
+    graphs = []
+    try:
+      for seg in (self._seg1, self._seg2, self._seg3, self._seg4):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None):
+          seg(st)
+        graphs.append(g)
+    except Exception:
+      if pool is not None:
+        pool.external_plan = False
+      raise
+    self._graph = {'graphs': graphs, 'static': static, 'st': st, 'pool': pool,
+                   'bn_delta': [(m, m.batches_tracked - b) for m, b in zip(bns, before)]}
+    # the capture pass did not execute anything: optimizer host mirrors advanced, undo
+    self.disc_optimizer.step_count -= 1
+    self.gen_optimizer.step_count -= 1
+    for m, d in self._graph['bn_delta']:
+      m.batches_tracked -= d
+    return self
+
+  def disable_graphs(self):
+    g = getattr(self, '_graph', None)
+    if g is not None and g['pool'] is not None:
+      g['pool'].external_plan = False
+    self._graph = None
+
+  def _run_segments_graphed(self, batch):
+    from csmri_hip import ops
+    G = self._graph
+    for k, v in G['static'].items():
+      v.copy_(batch[k], non_blocking=True)
+    if G['pool'] is not None:
+      G['pool'].external_plan = False
+      G['pool'].prepare(G['pool'].buffer[:G['static']['inp'].shape[0]])
+      G['pool'].external_plan = True
+    g1, g2, g3, g4 = G['graphs']
+    g1.replay()
+    self.disc_optimizer.start_allreduce()
+    g2.replay()
+    self.disc_optimizer.wait_allreduce()
+    g3.replay()
+    self.gen_optimizer.start_allreduce()
+    self.gen_optimizer.wait_allreduce()
+    g4.replay()
+    self.disc_optimizer.step_count += 1
+    self.gen_optimizer.step_count += 1
+    for m, d in G['bn_delta']:
+      m.batches_tracked += d
+    ops.bump_weight_epoch()
+    return G['st']
+
   def _train_single_step(self, loader):
     batch = self._request_data(loader)
     if batch is None:
       return 0, None, None
-    loss_metrics = {}
-    gen_inp = self.train_model_input_fn(batch)
-    out_gen = self.gen(*gen_inp)
-
-    # ---- discriminator phase (:331-347) ------------------------------------
-    out_disc_fake_d = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp[0], out_gen,
-                                                         is_real_input=False, detach=True,
-                                                         pool_decisions=self.pool_decisions))
-    out_disc_real = self.disc(nhwc=self.disc_input_fn(batch['target'], gen_inp[0], out_gen,
-                                                      is_real_input=True, detach=True))
-    disc_losses = []
-    for name, criterion in self.disc_adv_criteria.items():
-      loss = criterion(out_disc_fake_d, out_disc_real)
-      disc_losses.append(loss)
-      loss_metrics['disc_loss_' + name] = get_loss_metric(loss.detach())
-    total_disc = self._weighted_total(disc_losses, self.disc_loss_weights)
-    # D backward now (it only fills D's gradient bucket; no state changes), so that
-    # the bucket's all-reduce overlaps the generator-phase forwards below
-    self.disc_optimizer.zero_grad()
-    total_disc.backward()
-    self.disc_optimizer.start_allreduce()
-    loss_metrics['disc_loss'] = get_loss_metric(total_disc.detach())
-
-    # ---- generator phase forward (:349-370) --------------------------------
-    self.disc.set_wgrad(False)
-    out_disc_fake = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp[0], out_gen,
-                                                      is_real_input=False, detach=False))
-    self.disc.set_wgrad(True)
-    gen_losses = []
-    for name, criterion in self.gen_adv_criteria.items():
-      loss = criterion(out_disc_fake, out_disc_real)
-      gen_losses.append(loss)
-      loss_metrics['gen_loss_' + name] = get_loss_metric(loss.detach())
-    for name, criterion in self.gen_criteria.items():
-      loss = criterion(out_gen, batch)
-      gen_losses.append(loss)
-      loss_metrics['gen_loss_' + name] = get_loss_metric(loss.detach())
-
-    # ---- updates (:372-383): D step first, then G backward through the updated D
-    self.disc_optimizer.step()
-    total_gen = self._weighted_total(gen_losses, self.gen_loss_weights)
-    self.gen_optimizer.zero_grad()
-    total_gen.backward()
-    self.gen_optimizer.start_allreduce()
-    self.gen_optimizer.step()
-    loss_metrics['gen_loss'] = get_loss_metric(total_gen.detach())
-    return 1, loss_metrics, (batch, out_gen, out_disc_fake, out_disc_real)
+    if getattr(self, '_graph', None) is not None:
+      st = self._run_segments_graphed(batch)
+      vec = st['vec'].clone()
+    else:
+      st = {'batch': batch}
+      self._run_segments_eager(st)
+      vec = st['vec']
+    n = len(st['names'])
+    loss_metrics = {name: get_loss_metric(vec[i]) for i, name in enumerate(st['names'])}
+    self._last_metrics = {name: MaxMetric(vec[n + j]) for j, name in enumerate(st['metric_names'])}
+    return 1, loss_metrics, (st['batch'], st['out_gen'], st['out_disc_fake'], st['out_disc_real'])
 
   def _val_step(self, loader, compute_metrics=True):
     batch = self._request_data(loader, volatile=True)
@@ -245,6 +366,10 @@ class AdversarialRunner(BaseRunner):
     return loss_metrics, (batch, out_gen, out_disc_fake, out_disc_real)
 
   def _compute_train_metrics(self, data):
+    cached = getattr(self, '_last_metrics', None)
+    if cached is not None:            # computed inside the step (segment 4)
+      self._last_metrics = None
+      return cached
     metrics = {}
     for name, fn in self.train_gen_metric_fns.items():
       metrics['gen_' + name] = fn(data[1], data[0])

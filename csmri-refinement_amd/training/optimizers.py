@@ -34,7 +34,9 @@ class FlatAdam(object):
       self.flat_p[off:off + n].copy_(p.data.reshape(-1))
       p.data = self.flat_p[off:off + n].view_as(p)
       p.grad = self.flat_g[off:off + n].view_as(p)
-    self.step_count = 0
+    self.step_count = 0                       # host mirror of step_dev
+    self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    self._scale = 1.0
     self.bucket = GradBucket(self.flat_g)
     self.param_groups = [{'lr': lr, 'betas': self.betas, 'eps': eps, 'weight_decay': 0,
                           'amsgrad': False, 'params': list(range(len(self.params)))}]
@@ -49,13 +51,20 @@ class FlatAdam(object):
   def start_allreduce(self):
     self.bucket.start()
 
-  def step(self):
-    scale = self.bucket.wait()
+  def wait_allreduce(self):
+    self._scale = self.bucket.wait()
+
+  def apply(self):
+    """The Adam kernel itself (step counter on the device: hipGraph-capturable)."""
+    ops.adam_step_dev(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq,
+                      self.param_groups[0]['lr'], self.betas[0], self.betas[1], self.eps,
+                      self.step_dev, self._scale)
     self.step_count += 1
-    ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq,
-                  self.param_groups[0]['lr'], self.betas[0], self.betas[1], self.eps,
-                  self.step_count, scale)
     ops.bump_weight_epoch()
+
+  def step(self):
+    self.wait_allreduce()
+    self.apply()
 
   # -- torch.optim.Adam compatible state ---------------------------------------
   def state_dict(self):
@@ -75,6 +84,7 @@ class FlatAdam(object):
       self.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
       self.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
       self.step_count = int(st['step'])
+    self.step_dev.fill_(self.step_count)
     if sd.get('param_groups'):
       self.param_groups[0]['lr'] = sd['param_groups'][0].get('lr', self.lr)
 

@@ -1,9 +1,11 @@
 """History pool of generated images (reference utils/image_pool.py:8-60).
 
-Same decision process -- python ``random``: one uniform draw per image once the
-pool is full, then one randint for the slot -- but the pool lives in ONE device
-buffer [pool_size,1,H,W] and the swap is a batched gather/scatter instead of
-per-image unsqueeze/cat/clone."""
+Same decision process -- python ``random``: one uniform draw per image once the pool is
+full, then one randint for the slot; images are processed in batch order, so an image
+stored by item i can be drawn by item j > i -- but the pool lives in ONE device buffer and
+a query is three gathers + one scatter driven by small index tensors.  The host computes
+the indices ("plan") from the decisions; the device part has a fixed shape and can be
+captured into a hipGraph (the runner then only refreshes the index tensors per step)."""
 import random
 
 import torch
@@ -14,38 +16,74 @@ class ImagePool(object):
     self.pool_size = pool_size
     self.p_pool_image = p_pool_image
     self.count = 0
-    self.buffer = None
+    self.buffer = None            # [pool_size + 1, ...]; last slot is a write-only dummy
+    self._idx = None              # device int64 [4, n]: kind, pool_idx, x_idx / wslot, wsrc
+    self._host = None
+    self.external_plan = False    # True while a captured graph owns the device part
 
+  # -- host side ---------------------------------------------------------------
   def decide(self, n):
-    """Host-side decisions for a batch of n images: list of (use_pool, idx)."""
-    out = []
-    filled = self.count
+    """Decisions for a batch of n images: list of (use_pool, slot)."""
+    out, filled = [], self.count
     for _ in range(n):
       if filled < self.pool_size:
         out.append((False, filled))
         filled += 1
+      elif random.uniform(0, 1) < self.p_pool_image:
+        out.append((True, random.randint(0, self.pool_size - 1)))
       else:
-        if random.uniform(0, 1) < self.p_pool_image:
-          out.append((True, random.randint(0, self.pool_size - 1)))
+        out.append((False, -1))
+    return out
+
+  def plan(self, decisions):
+    """Sequential semantics resolved into gather/scatter indices (and self.count)."""
+    n = len(decisions)
+    kind, pidx, xidx = [0] * n, [0] * n, list(range(n))
+    owner = {}                                   # slot -> index of the last writer in this batch
+    filled = self.count
+    for i, (use, slot) in enumerate(decisions):
+      if use:
+        if slot in owner:
+          kind[i], xidx[i] = 2, owner[slot]      # drawn image was stored earlier in this batch
         else:
-          out.append((False, -1))
+          kind[i], pidx[i] = 1, slot
+        owner[slot] = i
+      elif filled < self.pool_size:
+        owner[filled] = i                        # filling phase: store, return the image itself
+        filled += 1
+    self.count = filled
+    wslot = list(owner.keys()) + [self.pool_size] * (n - len(owner))
+    wsrc = list(owner.values()) + [0] * (n - len(owner))
+    return kind, pidx, xidx, wslot, wsrc
+
+  def prepare(self, x, decisions=None):
+    n = x.shape[0]
+    if self.buffer is None:
+      self.buffer = torch.zeros((self.pool_size + 1,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if self._idx is None or self._idx.shape[1] != n:
+      self._idx = torch.zeros(5, n, dtype=torch.int64, device=x.device)
+      self._host = torch.zeros(5, n, dtype=torch.int64).pin_memory() if x.is_cuda else torch.zeros(5, n, dtype=torch.int64)
+    if decisions is None:
+      decisions = self.decide(n)
+    rows = self.plan(decisions)
+    for r, vals in enumerate(rows):
+      self._host[r] = torch.tensor(vals, dtype=torch.int64)
+    self._idx.copy_(self._host, non_blocking=True)
+
+  # -- device side (fixed shape) -------------------------------------------------
+  def apply_plan(self, x):
+    kind, pidx, xidx, wslot, wsrc = self._idx.unbind(0)
+    from_pool = self.buffer.index_select(0, pidx)
+    from_x = x.index_select(0, xidx)
+    k = kind.view(-1, *([1] * (x.dim() - 1)))
+    out = torch.where(k == 1, from_pool, torch.where(k == 2, from_x, x))
+    self.buffer.index_copy_(0, wslot, x.index_select(0, wsrc))
     return out
 
   def query(self, image_batch, decisions=None):
     if self.pool_size == 0:
       return image_batch
     x = image_batch.detach()
-    if self.buffer is None:
-      self.buffer = torch.empty((self.pool_size,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    if decisions is None:
-      decisions = self.decide(x.shape[0])
-    result = x.clone()
-    # sequential semantics (an image stored by item i can be drawn by item j>i)
-    for i, (use, idx) in enumerate(decisions):
-      if self.count < self.pool_size and not use:
-        self.buffer[self.count].copy_(x[i])
-        self.count += 1
-      elif use:
-        result[i].copy_(self.buffer[idx])
-        self.buffer[idx].copy_(x[i])
-    return result
+    if not self.external_plan:
+      self.prepare(x, decisions)
+    return self.apply_plan(x)

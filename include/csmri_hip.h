@@ -281,6 +281,12 @@ int csmri_adam(float* p, const float* g, float* m, float* v, long long n, float 
                float beta1, float beta2, float eps, int step, float grad_scale,
                void* stream);
 
+/* same update, step count in device memory (*step_dev steps already taken; incremented by
+ * the call): graph-capture safe */
+int csmri_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr,
+                   float beta1, float beta2, float eps, int* step_dev, float grad_scale,
+                   void* stream);
+
 /* misc */
 int csmri_fill_f32(float* p, long long n, float v, void* stream);
 int csmri_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream);

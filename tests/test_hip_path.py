@@ -201,13 +201,13 @@ def test_gan_step0_params_and_grads_fp32(env):
   grads = {}
 
   def snap(opt, model, tag):
-    orig = opt.step
+    orig = opt.apply
     names = {id(p): n for n, p in model.named_parameters()}
 
-    def step():
+    def apply():
       grads[tag] = {names[id(p)]: p.grad.detach().cpu().clone() for p in opt.params}
       orig()
-    opt.step = step
+    opt.apply = apply
   snap(runner.gen_optimizer, runner.gen, 'G')
   snap(runner.disc_optimizer, runner.disc, 'D')
   batch = O.synth_batch(2, 128, 128, acc=4, seed=40)
@@ -288,13 +288,13 @@ def test_disc_phase_grads_identical_inputs_fp32(env):
     seen.append(nhwc.detach().float().cpu()[..., :1].permute(0, 3, 1, 2).contiguous())
     return disc_fwd(inp, nhwc)
   runner.disc.forward = fwd
-  step_orig = runner.disc_optimizer.step
+  apply_orig = runner.disc_optimizer.apply
   names = {id(p): n for n, p in runner.disc.named_parameters()}
 
-  def step():
+  def apply():
     grads.update({names[id(p)]: p.grad.detach().cpu().clone() for p in runner.disc_optimizer.params})
-    step_orig()
-  runner.disc_optimizer.step = step
+    apply_orig()
+  runner.disc_optimizer.apply = apply
   runner.train_epoch(Loader([O.synth_batch(2, 128, 128, acc=4, seed=40)]), 1)
   small_disc = dict(O.DISC_CONF, filters=[8, 16, 32, 64, 64, 64])
   PD = {k: v.clone().requires_grad_(True) for k, v in sub(f, 'D0.').items()
@@ -383,3 +383,55 @@ def test_f5_discriminator_fwd_bwd_fp32_vs_reference_golden(env):
     worst = max(worst, err)
     print('F5 grad %-24s rel_l2 %.3e |g| %.3e' % (k, err, float(g.norm())))
   assert worst < 1e-4, worst
+
+
+def test_graph_replay_equals_eager(env):
+  """hipGraph mode replays exactly the eager kernel sequence: with the stochastic parts off
+  (no dropout layers, no image pool) 2 graphed steps == 2 eager steps, bit for bit."""
+  Configuration, set_dtype = env
+  from training import build_runner
+  set_dtype('bf16')
+
+  def make():
+    conf = gan_conf(Configuration, 'bf16')
+    conf.discriminator_model['dropout_after'] = []
+    conf.discriminator_model['use_image_pool'] = False
+    torch.manual_seed(3)
+    return build_runner(conf, 'adversarial', '0', 'train')
+  batch = {k: v.cuda() for k, v in O.synth_batch(2, 128, 128, acc=4, seed=5).items()}
+  host = {k: v.cpu() for k, v in batch.items()}
+  a, b = make(), make()
+  a._set_train()
+  for _ in range(3):
+    a._run_segments_eager({'batch': batch})
+  la = [a.train_epoch(Loader([host]), 1)[0] for _ in range(2)]
+  b.enable_graphs(batch, warmup=3)
+  lb = [b.train_epoch(Loader([host]), 1)[0] for _ in range(2)]
+  for x, y in zip(la, lb):
+    for k in x:
+      assert x[k].value == y[k].value, (k, x[k].value, y[k].value)
+  for (k, p), (_, q) in zip(a.gen.state_dict().items(), b.gen.state_dict().items()):
+    assert torch.equal(p, q), k
+  for (k, p), (_, q) in zip(a.disc.state_dict().items(), b.disc.state_dict().items()):
+    assert torch.equal(p, q), k
+  assert a.gen_optimizer.step_count == b.gen_optimizer.step_count == 5
+  assert int(b.gen_optimizer.step_dev) == 5
+
+
+def test_graph_mode_with_dropout_and_pool_runs(env):
+  Configuration, set_dtype = env
+  from training import build_runner
+  set_dtype('bf16')
+  conf = gan_conf(Configuration, 'bf16')
+  conf.discriminator_model['image_pool_size'] = 6     # fills after 3 steps, then swaps
+  runner = build_runner(conf, 'adversarial', '0', 'train')
+  batch = {k: v.cuda() for k, v in O.synth_batch(2, 128, 128, acc=4, seed=6).items()}
+  runner.enable_graphs(batch)
+  host = {k: v.cpu() for k, v in batch.items()}
+  for _ in range(6):
+    losses, metrics = runner.train_epoch(Loader([host]), 1)
+  vals = {k: v.value for k, v in losses.items()}
+  assert all(v == v and abs(v) < 1e3 for v in vals.values()), vals
+  assert 5.0 < metrics['gen_psnr'].value < 60.0
+  pool = runner.disc_input_fn.image_pool
+  assert pool.count == 6
