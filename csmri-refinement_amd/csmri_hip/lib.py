@@ -73,7 +73,7 @@ _SIGS = {
     'csmri_gconv_suggest_splitk': (i32, [C.POINTER(GConvDesc)]),
     'csmri_pack_weight_bytes': (sz, [i32, i32, i32, i32, i32, i32]),
     'csmri_pack_weight': (i32, [i32, i32, vp, i32, i32, i32, i32, vp, C.POINTER(i32),
-                                C.POINTER(i64), vp]),
+                                C.POINTER(i64), C.POINTER(i32), vp]),
     'csmri_wgrad': (i32, [C.POINTER(WGradDesc), vp]),
     'csmri_wgrad_slab_bytes': (sz, [C.POINTER(WGradDesc)]),
     'csmri_wgrad_suggest_splitk': (i32, [C.POINTER(WGradDesc)]),

@@ -151,18 +151,18 @@ class ConvLayer(object):
     ent = self._packs.get(key)
     epoch = -1 if self.frozen else _EPOCH[0]
     if ent is not None and ent[0] == epoch and ent[1].device == self.weight.device:
-      return ent[1], ent[2], ent[3]
+      return ent[1], ent[2], ent[3], ent[4]
     dt = BF16 if self.dtype == torch.bfloat16 else F32
     nbytes = lib.raw('csmri_pack_weight_bytes')(mode, dt, self.cout, self.cin, self.kh, self.kw)
     buf = ent[1] if ent is not None and ent[1].device == self.weight.device else \
         torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
-    kp, cs = C.c_int(0), C.c_longlong(0)
+    kp, cs, tw = C.c_int(0), C.c_longlong(0), C.c_int(0)
     w = self.weight.detach()
     assert w.is_contiguous() and w.dtype == torch.float32
     lib.call('csmri_pack_weight', mode, dt, w.data_ptr(), self.cout, self.cin, self.kh, self.kw,
-             buf.data_ptr(), C.byref(kp), C.byref(cs), stream())
-    self._packs[key] = (epoch, buf, kp.value, cs.value)
-    return buf, kp.value, cs.value
+             buf.data_ptr(), C.byref(kp), C.byref(cs), C.byref(tw), stream())
+    self._packs[key] = (epoch, buf, kp.value, cs.value, tw.value)
+    return buf, kp.value, cs.value, tw.value
 
   def bias_padded(self):
     if self.bias is None:
@@ -227,7 +227,10 @@ def _gconv_run(d, want_stats, flops=0.0):
     rows = lib.raw('csmri_gconv_stats_rows')(C.byref(d))
     stats = torch.empty(rows, 2, d.Cout, dtype=torch.float32, device=dev)
     d.stats_partial = stats.data_ptr()
-  with _Timed(_tile_label('gconv', d.dtype, d.Cout) + ('_splitk' if splitk > 1 else ''), flops):
+  tiled = (d.dtype == BF16 and d.in_s == 1 and d.dy_step == 1 and d.dx_step == 1 and d.nclass <= 1 and
+           splitk == 1 and d.Cin in (8, 16, 32, 64) and d.Ho * d.Wo >= 4096 and d.out_sy == 1)
+  with _Timed(_tile_label('tconv' if tiled else 'gconv', d.dtype, d.Cout) +
+              ('_splitk' if splitk > 1 else ''), flops):
     lib.call('csmri_gconv', C.byref(d), stream())
   return stats
 
@@ -248,7 +251,7 @@ def conv_forward(layer, x0, x1=None, use_bias=True, act_slope=1.0, want_stats=Fa
   ho, wo = layer.out_hw(h, w)
   odt = out_dtype or layer.dtype
   y = torch.empty(b, ho, wo, layer.cout_p, dtype=odt, device=x0.device)
-  wp, kp, _ = layer._pack(0)
+  wp, kp, _, tw = layer._pack(0)
   pl, pr, pt, pb = layer.pads
   d = lib.GConvDesc()
   d.dtype, d.out_dtype = dt_of(x0), dt_of(y)
@@ -257,7 +260,7 @@ def conv_forward(layer, x0, x1=None, use_bias=True, act_slope=1.0, want_stats=Fa
     d.in1, d.in1_pix_stride, d.c0 = x1.data_ptr(), x1.stride(2), c0
   d.B, d.Hin, d.Win, d.Cin = b, h, w, cin
   d.upsample, d.border = int(layer.upsample), layer.border
-  d.TH, d.TW, d.in_s = layer.kh, layer.kw, layer.stride
+  d.TH, d.TW, d.in_s = layer.kh, tw, layer.stride     # tw >= kw: zero taps pad few-channel filters
   d.dy0, d.dy_step, d.dx0, d.dx_step = -pt, 1, -pl, 1
   d.w, d.Kp, d.nclass, d.w_class_stride = wp.data_ptr(), kp, 1, 0
   d.out, d.out_pix_stride, d.Hout_t, d.Wout_t = y.data_ptr(), y.stride(2), ho, wo
@@ -290,13 +293,14 @@ def conv_dgrad(layer, gy, in_hw, g_src=None, g_slope=1.0):
   d.act_slope = 1.0
   direct = layer.border == BORDER_ZERO and not layer.upsample
   if layer.stride == 1:
-    wp, kp, _ = layer._pack(1)
+    # flipped-tap pack: the input-gradient is a plain correlation over dY
+    wp, kp, _, tw = layer._pack(3)
     d.w, d.Kp, d.nclass, d.w_class_stride = wp.data_ptr(), kp, 1, 0
-    d.TH, d.TW = layer.kh, layer.kw
-    d.dy_step = d.dx_step = -1
+    d.TH, d.TW = layer.kh, tw
+    d.dy_step = d.dx_step = 1
     if direct:
       out = torch.empty(b, h, w, layer.cin_p, dtype=gy.dtype, device=dev)
-      d.dy0, d.dx0 = pt, pl
+      d.dy0, d.dx0 = pt - (layer.kh - 1), pl - (layer.kw - 1)
       d.Ho, d.Wo, d.Hout_t, d.Wout_t = h, w, h, w
       if g_src is not None:
         g_src = as_nhwc(g_src)
@@ -305,14 +309,14 @@ def conv_dgrad(layer, gy, in_hw, g_src=None, g_slope=1.0):
       hv, wv = (2 * h, 2 * w) if layer.upsample else (h, w)
       hp, wpad = hv + pt + pb, wv + pl + pr
       out = torch.empty(b, hp, wpad, layer.cin_p, dtype=gy.dtype, device=dev)
-      d.dy0 = d.dx0 = 0
+      d.dy0, d.dx0 = -(layer.kh - 1), -(layer.kw - 1)
       d.Ho, d.Wo, d.Hout_t, d.Wout_t = hp, wpad, hp, wpad
     d.out_sy = d.out_sx = 1
     d.out_oy = d.out_ox = 0
   elif layer.stride == 2:
     if direct or layer.upsample or layer.kh % 2 or layer.kw % 2:
       raise RuntimeError('csmri_hip: stride-2 dgrad implemented for even kernels with reflection padding')
-    wp, kp, cs = layer._pack(2)
+    wp, kp, cs, _ = layer._pack(2)
     d.w, d.Kp, d.nclass, d.w_class_stride = wp.data_ptr(), kp, 4, cs
     d.TH, d.TW = layer.kh // 2, layer.kw // 2
     d.dy_step = d.dx_step = -1
@@ -518,28 +522,98 @@ class ConvBnAct(torch.autograd.Function):
     return gx0, gx1, None, None, None, None, None, None, None, None
 
 
+def maxpool2_fwd(x):
+  """MaxPool2d(2,2) on NHWC; returns (y, argmax uint8)."""
+  x = as_nhwc(x)
+  b, h, w, c = x.shape
+  y = torch.empty(b, h // 2, w // 2, c, dtype=x.dtype, device=x.device)
+  arg = torch.empty(b, h // 2, w // 2, c, dtype=torch.uint8, device=x.device)
+  lib.call('csmri_maxpool2', dt_of(x), x.data_ptr(), x.stride(2), y.data_ptr(), y.stride(2),
+           arg.data_ptr(), b, h, w, c, stream())
+  return y, arg
+
+
+def maxpool2_bwd(gy, arg, shape):
+  b, h, w, c = shape
+  gy = as_nhwc(gy)
+  gx = torch.empty(b, h, w, c, dtype=gy.dtype, device=gy.device)
+  lib.call('csmri_maxpool2_bwd', dt_of(gy), gy.data_ptr(), gy.stride(2), arg.data_ptr(),
+           gx.data_ptr(), gx.stride(2), b, h, w, c, stream())
+  return gx
+
+
 class MaxPool2(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x):
-    x = as_nhwc(x)
-    b, h, w, c = x.shape
-    y = torch.empty(b, h // 2, w // 2, c, dtype=x.dtype, device=x.device)
-    arg = torch.empty(b, h // 2, w // 2, c, dtype=torch.uint8, device=x.device)
-    lib.call('csmri_maxpool2', dt_of(x), x.data_ptr(), x.stride(2), y.data_ptr(), y.stride(2),
-             arg.data_ptr(), b, h, w, c, stream())
+    y, arg = maxpool2_fwd(x)
     ctx.save_for_backward(arg)
-    ctx.shape = (b, h, w, c)
+    ctx.shape = tuple(x.shape)
     return y
 
   @staticmethod
   def backward(ctx, gy):
     arg, = ctx.saved_tensors
-    b, h, w, c = ctx.shape
-    gy = as_nhwc(gy)
-    gx = torch.empty(b, h, w, c, dtype=gy.dtype, device=gy.device)
-    lib.call('csmri_maxpool2_bwd', dt_of(gy), gy.data_ptr(), gy.stride(2), arg.data_ptr(),
-             gx.data_ptr(), gx.stride(2), b, h, w, c, stream())
-    return gx
+    return maxpool2_bwd(gy, arg, ctx.shape)
+
+
+class FrozenConvStackPair(torch.autograd.Function):
+  """A frozen conv/ReLU/max-pool stack (VGG19 features) applied to a (prediction, target)
+  pair as ONE batched forward: the stack has no batch-coupled op, so concatenating the two
+  halves along the batch is exact, halves the launches and doubles M of the small late
+  layers.  Only the prediction half is differentiated (input gradient only -- the weights
+  are frozen): backward walks the stack on the first half of the saved activations.
+
+  ``plan``: list of ('conv', ConvLayer, slope) / ('pool', None, None); ``taps``: indices into
+  the plan after which a feature map is returned.  Returns 2*len(taps) tensors:
+  prediction features then target features."""
+
+  @staticmethod
+  def forward(ctx, p_in, t_in, plan, taps):
+    b = p_in.shape[0]
+    x = torch.cat((p_in, t_in), 0)
+    saved, shapes, feats = [], [], []
+    for i, (kind, layer, slope) in enumerate(plan):
+      if kind == 'conv':
+        y, _ = conv_forward(layer, x, None, True, slope, False, None)
+        saved.append(y)
+        shapes.append((x.shape[1], x.shape[2]))
+        x = y
+      else:
+        shapes.append((b,) + tuple(x.shape[1:]))
+        x, arg = maxpool2_fwd(x)
+        saved.append(arg)
+      if i in taps:
+        feats.append(x)
+    ctx.plan, ctx.taps, ctx.b, ctx.shapes = plan, taps, b, shapes
+    ctx.save_for_backward(*saved)
+    outs = [f[:b] for f in feats] + [f[b:] for f in feats]
+    ctx.mark_non_differentiable(*outs[len(feats):])
+    return tuple(outs)
+
+  @staticmethod
+  def backward(ctx, *gouts):
+    plan, taps, b = ctx.plan, sorted(ctx.taps), ctx.b
+    saved = ctx.saved_tensors
+    gmap = {t: gouts[j] for j, t in enumerate(taps)}
+    g = None
+    for i in range(len(plan) - 1, -1, -1):
+      if i in gmap and gmap[i] is not None:
+        gi = as_nhwc(gmap[i])
+        g = gi if g is None else g + gi
+      if g is None:
+        continue
+      kind, layer, slope = plan[i]
+      if kind == 'conv':
+        y = saved[i][:b]
+        if g.dtype != layer.dtype:
+          g = g.to(layer.dtype)
+        gp = act_bwd(g, y, slope) if slope != 1.0 else g
+        if i == 0 and not ctx.needs_input_grad[0]:
+          return None, None, None, None
+        g = conv_dgrad(layer, gp, ctx.shapes[i])
+      else:
+        g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i])
+    return g, None, None, None
 
 
 # ----------------------------------------------------------------------------

@@ -72,12 +72,20 @@ extern "C" int csmri_mask_to_u8(const float* mask_nchw, int B, int H, int W, uin
 // -------------------------------------------------------- weight packing ----
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-struct PackGeom { int rows, rows_pad, chan_pad, taps, Kp, nclass; };
+// tw = packed filter width: for few-channel layers (chan_pad 8/16) the width is padded with
+// zero taps to a multiple of 32/chan_pad so that a 32-wide K chunk is a whole number of
+// horizontally adjacent taps (tconv.hip).
+struct PackGeom { int rows, rows_pad, chan_pad, th, tw, taps, Kp, nclass; };
 static PackGeom pack_geom(int mode, int Cout, int Cin, int KH, int KW) {
   PackGeom g;
-  if (mode == 0) { g.rows = Cout; g.chan_pad = round_up(Cin, 8); g.taps = KH * KW; g.nclass = 1; }
-  else if (mode == 1) { g.rows = Cin; g.chan_pad = round_up(Cout, 8); g.taps = KH * KW; g.nclass = 1; }
-  else { g.rows = Cin; g.chan_pad = round_up(Cout, 8); g.taps = (KH / 2) * (KW / 2); g.nclass = 4; }
+  const bool swapped = mode != 0;
+  g.rows = swapped ? Cin : Cout;
+  g.chan_pad = round_up(swapped ? Cout : Cin, 8);
+  g.nclass = mode == 2 ? 4 : 1;
+  g.th = mode == 2 ? KH / 2 : KH;
+  g.tw = mode == 2 ? KW / 2 : KW;
+  if (mode != 2 && (g.chan_pad == 8 || g.chan_pad == 16)) g.tw = round_up(g.tw, 32 / g.chan_pad);
+  g.taps = g.th * g.tw;
   g.rows_pad = round_up(g.rows, 128);
   g.Kp = round_up(g.taps * g.chan_pad, 64);
   return g;
@@ -85,22 +93,24 @@ static PackGeom pack_geom(int mode, int Cout, int Cin, int KH, int KW) {
 
 __global__ void pack_weight_kernel(int mode, int dt, const float* w, int Cout, int Cin, int KH, int KW,
                                    void* out, int rows, int rows_pad, int chan_pad, int taps, int Kp,
-                                   int nclass) {
+                                   int nclass, int tw) {
   const long long per_class = (long long)rows_pad * Kp;
   GRID_STRIDE(i, per_class * nclass) {
     const int cls = (int)(i / per_class);
     const long long rem = i - cls * per_class;
     const int row = (int)(rem / Kp), k = (int)(rem - (long long)row * Kp);
     const int tap = k / chan_pad, ch = k - tap * chan_pad;
+    const int ty = tap / tw, tx = tap - ty * tw;
     float v = 0.f;
     if (row < rows && tap < taps) {
       if (mode == 0) {
-        if (ch < Cin) v = w[(((long long)row * Cin + ch) * KH + tap / KW) * KW + tap % KW];
+        if (ch < Cin && tx < KW) v = w[(((long long)row * Cin + ch) * KH + ty) * KW + tx];
       } else if (mode == 1) {
-        if (ch < Cout) v = w[(((long long)ch * Cin + row) * KH + tap / KW) * KW + tap % KW];
+        if (ch < Cout && tx < KW) v = w[(((long long)ch * Cin + row) * KH + ty) * KW + tx];
+      } else if (mode == 3) {      // flipped taps: dgrad as a plain correlation
+        if (ch < Cout && tx < KW) v = w[(((long long)ch * Cin + row) * KH + (KH - 1 - ty)) * KW + (KW - 1 - tx)];
       } else {
-        const int tw2 = KW / 2, jy = tap / tw2, jx = tap % tw2;
-        const int ky = (cls >> 1) + 2 * jy, kx = (cls & 1) + 2 * jx;
+        const int ky = (cls >> 1) + 2 * ty, kx = (cls & 1) + 2 * tx;
         if (ch < Cout) v = w[(((long long)ch * Cin + row) * KH + ky) * KW + kx];
       }
     }
@@ -114,16 +124,17 @@ extern "C" size_t csmri_pack_weight_bytes(int mode, int dtype, int Cout, int Cin
 }
 extern "C" int csmri_pack_weight(int mode, int dtype, const float* w_ref, int Cout, int Cin, int KH,
                                  int KW, void* out, int* Kp_out, long long* class_stride_out,
-                                 void* stream) {
-  CSMRI_CHECK_ARG(w_ref && out && mode >= 0 && mode <= 2);
+                                 int* TW_out, void* stream) {
+  CSMRI_CHECK_ARG(w_ref && out && mode >= 0 && mode <= 3);
   if (mode == 2) CSMRI_CHECK_ARG(KH % 2 == 0 && KW % 2 == 0);
   PackGeom g = pack_geom(mode, Cout, Cin, KH, KW);
   if (Kp_out) *Kp_out = g.Kp;
   if (class_stride_out) *class_stride_out = (long long)g.rows_pad * g.Kp;
+  if (TW_out) *TW_out = g.tw;
   long long total = (long long)g.nclass * g.rows_pad * g.Kp;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                      mode, dtype, w_ref, Cout, Cin, KH, KW, out, g.rows, g.rows_pad, g.chan_pad,
-                     g.taps, g.Kp, g.nclass);
+                     g.taps, g.Kp, g.nclass, g.tw);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -15,17 +15,7 @@
 // Algorithmic work: 2*M*N*K FLOP; bytes: M*Cin*ES*(taps reuse served by L2/LDS)
 // + N*K*ES weights + M*N*ES output.
 #include "mma_core.h"
-
-struct GParams {
-  const char* in0; const char* in1; int ps0, ps1, c0;
-  int B, Hin, Win, Cin, ups, border;
-  int TH, TW, S, dy0, dys, dx0, dxs;
-  const char* w; int Kp; int nclass; long long wcs;
-  char* out; int ops; int Hout_t, Wout_t, Ho, Wo, osy, osx, ooy, oox, Cout; int out_dt;
-  const float* bias; float slope; const char* gsrc; int gps; float gslope; int gdt;
-  float* stats; int splitk; float* slab;
-  int M, nsteps, steps_per_split, mtiles, ntiles;
-};
+#include "gconv_params.h"
 
 template <int DT, int BM, int BN, int WM, int WN, int KC>
 __global__ __launch_bounds__(256) void gconv_kernel(const GParams p) {
@@ -267,6 +257,7 @@ static GConfig pick_config(const csmri_gconv_desc* d) {
 static int desc_M(const csmri_gconv_desc* d) { return d->B * d->Ho * d->Wo; }
 
 extern "C" int csmri_gconv_stats_rows(const csmri_gconv_desc* d) {
+  if (tconv_eligible(d)) return tconv_stats_rows(d);
   GConfig c = pick_config(d);
   return cdiv(desc_M(d), c.BM) * c.WM;
 }
@@ -278,6 +269,7 @@ extern "C" size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d) {
 }
 
 extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
+  { csmri_gconv_desc t = *d; t.splitk = 1; if (tconv_eligible(&t)) return 1; }
   GConfig c = pick_config(d);
   int nclass = d->nclass > 0 ? d->nclass : 1;
   long long tiles = (long long)cdiv(desc_M(d), c.BM) * cdiv(d->Cout, c.BN) * nclass;
@@ -346,6 +338,7 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
   p.mtiles = cdiv(p.M, c.BM); p.ntiles = cdiv(d->Cout, c.BN);
   (void)es;
   hipStream_t st = (hipStream_t)stream;
+  if (tconv_eligible(d)) return tconv_launch(p, d, st);
   int rc;
 #define GC(DT_, BM_, BN_, WM_, WN_, KC_) rc = launch_gconv<DT_, BM_, BN_, WM_, WN_, KC_>(p, st)
   if (d->dtype == CSMRI_BF16) {

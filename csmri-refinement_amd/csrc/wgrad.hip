@@ -87,12 +87,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
     }
   }
 
+  // pixel coordinates of each block's first pixel, advanced incrementally (PS pixels per step)
+  int sb[NI], soy[NI], sox[NI];
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int mb = s_begin * PS + pg[it] * VE;
+    sb[it] = mb / HoWo;
+    const int r = mb - sb[it] * HoWo;
+    soy[it] = r / p.Wo; sox[it] = r - soy[it] * p.Wo;
+  }
   u32x4_t blk[NI][VE];
   auto load_step = [&](int s) {
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
       const int mb = s * PS + pg[it] * VE;
-      int b = mb / HoWo, r = mb - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
+      int b = sb[it], oy = soy[it], ox = sox[it];
+      sox[it] += PS;
+      while (sox[it] >= p.Wo) { sox[it] -= p.Wo; if (++soy[it] == p.Ho) { soy[it] = 0; ++sb[it]; } }
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
         u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
@@ -189,6 +200,39 @@ __global__ void wgrad_scatter_kernel(const float* slab, int splitk, int Cout, in
     const float s = (s0 + s1) + (s2 + s3);
     const size_t o = ((size_t)co * Cin_real + ci) * KH * KW + tap;
     dw[o] = accumulate ? dw[o] + s : s;
+  }
+}
+
+// Split-K sum + layout change [co][tap][ci] -> [co][ci][tap] through an LDS transpose so that
+// both the slab reads (64 consecutive channels) and the gradient writes (64*taps consecutive
+// floats) are coalesced.  One block per (co, 64-channel chunk); the z (split) loop is spread
+// over 4 thread groups and combined in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_scatter_t_kernel(const float* slab, int splitk, int Cout, int NK,
+                                                              int Cin, int taps, int Cin_real, float* dw,
+                                                              int accumulate) {
+  __shared__ float tile[16][65];
+  const int co = blockIdx.x, ci0 = blockIdx.y * 64;
+  const size_t zs = (size_t)Cout * NK;
+  for (int t0 = 0; t0 < taps; t0 += 16) {
+    const int nt = min(16, taps - t0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = threadIdx.x + 256 * j, t = e >> 6, c = e & 63;
+      if (t < nt && ci0 + c < Cin) {
+        const float* q = slab + (size_t)co * NK + (size_t)(t0 + t) * Cin + ci0 + c;
+        float s = 0.f;
+        for (int z = 0; z < splitk; ++z) s += q[(size_t)z * zs];
+        tile[t][c] = s;
+      }
+    }
+    __syncthreads();
+    const int nc = min(64, Cin_real - ci0);
+    for (int idx = threadIdx.x; idx < nc * nt; idx += 256) {
+      const int cc = idx / nt, t = idx - cc * nt;
+      const size_t o = ((size_t)co * Cin_real + ci0 + cc) * taps + t0 + t;
+      dw[o] = accumulate ? dw[o] + tile[t][cc] : tile[t][cc];
+    }
+    __syncthreads();
   }
 }
 
@@ -313,10 +357,16 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   }
 #undef WG
   if (rc != CSMRI_OK) return rc;
-  const long long total = (long long)d->Cout_real * d->Cin_real * d->KH * d->KW;
-  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(blocks), dim3(256), 0, st, d->slab, p.splitk, d->Cout, p.NK,
-                     d->Cin, d->KH, d->KW, d->Cout_real, d->Cin_real, d->dw, d->accumulate);
+  if (p.splitk <= 8) {        // big layers: bandwidth-bound transposing copy
+    hipLaunchKernelGGL(wgrad_scatter_t_kernel, dim3(d->Cout_real, (d->Cin_real + 63) / 64), dim3(256), 0, st,
+                       d->slab, p.splitk, d->Cout, p.NK, d->Cin, d->KH * d->KW, d->Cin_real, d->dw,
+                       d->accumulate);
+  } else {                    // few outputs, many splits: one thread per output element
+    const long long total = (long long)d->Cout_real * p.NK;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(blocks), dim3(256), 0, st, d->slab, p.splitk, d->Cout, p.NK,
+                       d->Cin, d->KH, d->KW, d->Cout_real, d->Cin_real, d->dw, d->accumulate);
+  }
   CSMRI_LAUNCH_CHECK();
   if (d->db) {
     float* part = d->slab + (size_t)p.splitk * d->Cout * p.NK;

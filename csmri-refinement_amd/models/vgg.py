@@ -52,6 +52,12 @@ class VGG19(nn.Module):
       idx += 2
     self.blocks = nn.ModuleList([nn.ModuleDict(b) for b in blocks])
     self._plan = plan
+    # plan indices after which a requested block's feature map is complete
+    self._taps = []
+    for i, (kind, conv, block) in enumerate(plan):
+      last_of_block = i + 1 == len(plan) or plan[i + 1][2] != block
+      if last_of_block and block in self.output_blocks:
+        self._taps.append(i)
     for p in self.parameters():
       p.requires_grad = requires_grad
     self.register_buffer('mean', torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
@@ -73,6 +79,15 @@ class VGG19(nn.Module):
     if cur in self.output_blocks:
       out.append(x)
     return out
+
+  def features_pair(self, p_in, t_in):
+    """Features of a (prediction, target) pair in one batched pass; only the prediction
+    half carries gradient.  Returns (pred_feats, target_feats)."""
+    plan = [('conv', conv.layer, 0.0) if kind == 'conv' else ('pool', None, None)
+            for kind, conv, _ in self._plan]
+    outs = ops.FrozenConvStackPair.apply(p_in, t_in, plan, tuple(self._taps))
+    n = len(self._taps)
+    return list(outs[:n]), list(outs[n:])
 
   def forward(self, inp):
     """inp: [B,3,H,W] fp32 in (0,1) -> list of [B,C,h,w] fp32 maps (reference API)."""

@@ -40,8 +40,13 @@ class VGGLoss(nn.Module):
     p_in = ops.ComplexAbs.apply(prediction, dt, 3)
     with torch.no_grad():
       t_in = ops.ComplexAbs.apply(target.detach().contiguous(), dt, 3)
-      t_feats = self.vgg.forward_nhwc(t_in)
-    p_feats = self.vgg.forward_nhwc(p_in)
+    if all(not p.requires_grad for p in self.vgg.parameters()):
+      # frozen extractor: one batched pass over [pred; target]
+      p_feats, t_feats = self.vgg.features_pair(p_in, t_in)
+    else:
+      with torch.no_grad():
+        t_feats = self.vgg.forward_nhwc(t_in)
+      p_feats = self.vgg.forward_nhwc(p_in)
     loss = 0
     for wgt, pf, tf in zip(self.weights, p_feats, t_feats):
       loss = loss + wgt * ops.MeanLoss.apply(pf, tf.detach(), self.kind, pf.shape[3])

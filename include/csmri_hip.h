@@ -111,11 +111,15 @@ int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d);
  * contract SURVEY A-12).  mode 0: forward taps; mode 1: stride-1 dgrad
  * (roles of Cout/Cin swapped, taps kept -- the descriptor flips them with
  * dy_step=-1); mode 2: stride-2 dgrad, 4 parity classes of (KH/2 x KW/2) taps.
- * Output rows padded to a multiple of 128, K padded to a multiple of 64, zeros. */
+ * Output rows padded to a multiple of 128, K padded to a multiple of 64, zeros.
+ * mode 3: stride-1 dgrad with FLIPPED taps (K index (ty,tx) holds w[..][KH-1-ty][KW-1-tx]), so
+ * the input-gradient is a plain correlation (dy_step = dx_step = +1, dy0 = pad_top-(KH-1)).
+ * For 8- or 16-channel K sides the packed filter width TW is KW rounded up to a multiple of
+ * 32/channels (zero taps); *TW_out returns it and is what the descriptor's TW must be. */
 size_t csmri_pack_weight_bytes(int mode, int dtype, int Cout, int Cin, int KH, int KW);
 int csmri_pack_weight(int mode, int dtype, const float* w_ref, int Cout, int Cin,
                       int KH, int KW, void* out, int* Kp_out, long long* class_stride_out,
-                      void* stream);
+                      int* TW_out, void* stream);
 
 /* ------------------------------------------------------------------------
  * Weight gradient of a convolution (nn.Conv2d backward w.r.t. weight):

@@ -38,6 +38,7 @@ def test_argument_validation_needs_no_gpu():
   assert lib.raw('csmri_dc')(None, 2, None, None, None, None, 0, None, 1, 64, 64, None) == -1
   assert lib.raw('csmri_adam')(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) == -1
   assert b'bad argument' in lib.raw('csmri_error_string')(-1)
+  # Cin 2 -> 8 channels, KW 3 -> 4 taps (32/8 taps per K chunk): K = 3*4*8 = 96 -> 128
   assert lib.raw('csmri_pack_weight_bytes')(0, lib.BF16, 32, 2, 3, 3) == 128 * 128 * 2
   assert lib.raw('csmri_pack_weight_bytes')(2, lib.F32, 64, 16, 4, 4) == 4 * 128 * 256 * 4
   assert lib.raw('csmri_bn_stats_rows')(524288) == 2048

@@ -172,7 +172,9 @@ def test_gan_step_fp32_vs_reference_golden(env):
   for step, (got, ref, psnr, psnr_ref, acc, acc_ref) in enumerate(out):
     for k in ref:
       print('step %d %-26s hip %.7f ref %.7f' % (step, k, got[k], ref[k]))
-    tol = 2e-6 if step == 0 else 2e-3
+    # step 0: fp32 rounding-order noise (1e-7) x the discriminator's BatchNorm chain on a
+    # batch of 2 (amplifies ~50x) -> 2e-5; later steps: see docstring
+    tol = 2e-5 if step == 0 else 2e-3
     for k in ref:
       assert abs(got[k] - ref[k]) < tol * max(1.0, abs(ref[k])), (step, k, got[k], ref[k])
     assert abs(psnr - psnr_ref) < 1e-3

@@ -1,0 +1,63 @@
+"""Micro-benchmark of single conv launches (HIP events) for kernel tuning.
+usage: python tools/bench_conv.py [name ...]"""
+import os, sys, math
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'csmri-refinement_amd'))
+from csmri_hip import ops
+
+CASES = {
+    # name: (cin, cout, k, stride, border, up, H, W, B)
+    'rec_mid': (32, 32, 3, 1, 'zero', False, 256, 256, 8),
+    'unet32': (32, 32, 4, 1, 'reflection', False, 256, 256, 8),
+    'unet64': (64, 64, 4, 1, 'reflection', False, 128, 128, 8),
+    'unet_cat': (64, 32, 4, 1, 'reflection', False, 256, 256, 8),
+    'vgg1_2': (64, 64, 3, 1, 'zero', False, 256, 256, 8),
+    'vgg2_1': (64, 128, 3, 1, 'zero', False, 128, 128, 8),
+    'vgg2_2': (128, 128, 3, 1, 'zero', False, 128, 128, 8),
+    'vgg3_2': (256, 256, 3, 1, 'zero', False, 64, 64, 8),
+    'vgg4_2': (512, 512, 3, 1, 'zero', False, 32, 32, 8),
+    'vgg5_2': (512, 512, 3, 1, 'zero', False, 16, 16, 8),
+    'disc3': (128, 256, 4, 2, 'reflection', False, 64, 64, 8),
+    'disc5': (512, 1024, 4, 2, 'reflection', False, 16, 16, 8),
+    'disc6': (1024, 1024, 4, 1, 'reflection', False, 8, 8, 8),
+    'rec_first': (2, 32, 3, 1, 'zero', False, 256, 256, 8),
+    'rec_last': (32, 2, 3, 1, 'zero', False, 256, 256, 8),
+}
+
+
+def pads_for(k, s):
+  total = int(math.ceil((k - 1.0) / s)); lo = total // 2; hi = lo if total % 2 == 0 else lo + 1
+  return (lo, hi, lo, hi)
+
+
+def run(name, mode='fwd', iters=20):
+  cin, cout, k, s, border, up, h, w, b = CASES[name]
+  wt = torch.nn.Parameter((torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)).cuda())
+  layer = ops.ConvLayer(wt, None, s, pads_for(k, s), border, torch.bfloat16, upsample=up)
+  x = torch.randn(b, h, w, ops.pad8(cin), device='cuda').bfloat16()
+  y, _ = ops.conv_forward(layer, x, None, False)
+  gy = torch.randn_like(y)
+  fn = {'fwd': lambda: ops.conv_forward(layer, x, None, False),
+        'dgrad': lambda: ops.conv_dgrad(layer, gy, (h, w)),
+        'wgrad': lambda: ops.conv_wgrad(layer, x, None, gy)}[mode]
+  for _ in range(3):
+    fn()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(iters):
+    fn()
+  e1.record(); torch.cuda.synchronize()
+  us = e0.elapsed_time(e1) / iters * 1e3
+  flops = 2.0 * b * y.shape[1] * y.shape[2] * cout * cin * k * k
+  byts = (x.numel() + y.numel()) * 2
+  print('%-10s %-6s %8.1f us  %7.1f TFLOP/s  %6.2f TB/s(in+out)' % (name, mode, us, flops / us / 1e6, byts / us / 1e6))
+
+
+if __name__ == '__main__':
+  names = [a for a in sys.argv[1:] if a in CASES] or list(CASES)
+  modes = [a for a in sys.argv[1:] if a in ('fwd', 'dgrad', 'wgrad')] or ['fwd']
+  for n in names:
+    for m in modes:
+      run(n, m)
