@@ -47,6 +47,11 @@ class GConvDesc(C.Structure):
   ]
 
 
+class PackItem(C.Structure):
+  _fields_ = [('w', vp), ('out', vp), ('mode', i32), ('dtype', i32), ('Cout', i32), ('Cin', i32),
+              ('KH', i32), ('KW', i32)]
+
+
 class WGradDesc(C.Structure):
   _fields_ = [
       ('dtype', i32),
@@ -74,6 +79,7 @@ _SIGS = {
     'csmri_pack_weight_bytes': (sz, [i32, i32, i32, i32, i32, i32]),
     'csmri_pack_weight': (i32, [i32, i32, vp, i32, i32, i32, i32, vp, C.POINTER(i32),
                                 C.POINTER(i64), C.POINTER(i32), vp]),
+    'csmri_pack_weight_multi': (i32, [vp, i32, vp]),
     'csmri_wgrad': (i32, [C.POINTER(WGradDesc), vp]),
     'csmri_wgrad_slab_bytes': (sz, [C.POINTER(WGradDesc)]),
     'csmri_wgrad_suggest_splitk': (i32, [C.POINTER(WGradDesc)]),

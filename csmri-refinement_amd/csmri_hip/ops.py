@@ -152,6 +152,10 @@ class ConvLayer(object):
     epoch = -1 if self.frozen else _EPOCH[0]
     if ent is not None and ent[0] == epoch and ent[1].device == self.weight.device:
       return ent[1], ent[2], ent[3], ent[4]
+    group = getattr(self, 'group', None)
+    if group is not None and not self.frozen and ent is not None and group.repack(mode):
+      ent = self._packs[key]
+      return ent[1], ent[2], ent[3], ent[4]
     dt = BF16 if self.dtype == torch.bfloat16 else F32
     nbytes = lib.raw('csmri_pack_weight_bytes')(mode, dt, self.cout, self.cin, self.kh, self.kw)
     buf = ent[1] if ent is not None and ent[1].device == self.weight.device else \
@@ -180,6 +184,42 @@ class ConvLayer(object):
     hv, wv = (2 * h, 2 * w) if self.upsample else (h, w)
     return ((hv + pt + pb - self.kh) // self.stride + 1,
             (wv + pl + pr - self.kw) // self.stride + 1)
+
+
+class PackGroup(object):
+  """The conv layers of one trainable network.  After an optimizer step every layer's packed
+  weights of a mode are stale; the first layer that notices re-packs ALL of them with one
+  multi-tensor launch (csmri_pack_weight_multi) instead of one launch per layer."""
+
+  def __init__(self, layers):
+    self.layers = [l for l in layers if not l.frozen]
+    for l in self.layers:
+      l.group = self
+    self._tables = {}
+
+  def repack(self, mode):
+    """Re-pack every member that already owns a pack of ``mode`` (buffers exist after the
+    first step).  Returns False if the table cannot be used (caller packs individually)."""
+    members = [l for l in self.layers if mode in l._packs]
+    if not members:
+      return False
+    sig = tuple((id(l), l.weight.data_ptr(), l._packs[mode][1].data_ptr()) for l in members)
+    tab = self._tables.get(mode)
+    if tab is None or tab[0] != sig:
+      arr = (lib.PackItem * len(members))()
+      for it, l in zip(arr, members):
+        it.w, it.out = l.weight.data_ptr(), l._packs[mode][1].data_ptr()
+        it.mode, it.dtype = mode, (BF16 if l.dtype == torch.bfloat16 else F32)
+        it.Cout, it.Cin, it.KH, it.KW = l.cout, l.cin, l.kh, l.kw
+      host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+      tab = (sig, host.to(members[0].weight.device), len(members))
+      self._tables[mode] = tab
+    lib.call('csmri_pack_weight_multi', tab[1].data_ptr(), tab[2], stream())
+    epoch = _EPOCH[0]
+    for l in members:
+      e = l._packs[mode]
+      l._packs[mode] = (epoch,) + tuple(e[1:])
+    return True
 
 
 PROFILE = None        # bench.py sets this to a list to collect per-launch HIP event timings
@@ -803,10 +843,10 @@ def sigmoid_prob(logits):
 def psnr_mse(pred, target):
   """per-image MSE of clamp(|.|,0,1); pred/target interleaved complex [B,H,W,2]."""
   b, h, w, _ = pred.shape
-  mse = torch.empty(b, dtype=torch.float32, device=pred.device)
+  buf = torch.empty(b * 33, dtype=torch.float32, device=pred.device)   # results + 32 partials/image
   lib.call('csmri_psnr_mse', pred.contiguous().data_ptr(), target.contiguous().data_ptr(), b, h * w,
-           mse.data_ptr(), stream())
-  return mse
+           buf.data_ptr(), stream())
+  return buf[:b]
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):

@@ -70,13 +70,13 @@ extern "C" int csmri_mask_to_u8(const float* mask_nchw, int B, int H, int W, uin
 }
 
 // -------------------------------------------------------- weight packing ----
-static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+__host__ __device__ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // tw = packed filter width: for few-channel layers (chan_pad 8/16) the width is padded with
 // zero taps to a multiple of 32/chan_pad so that a 32-wide K chunk is a whole number of
 // horizontally adjacent taps (tconv.hip).
 struct PackGeom { int rows, rows_pad, chan_pad, th, tw, taps, Kp, nclass; };
-static PackGeom pack_geom(int mode, int Cout, int Cin, int KH, int KW) {
+__host__ __device__ static PackGeom pack_geom(int mode, int Cout, int Cin, int KH, int KW) {
   PackGeom g;
   const bool swapped = mode != 0;
   g.rows = swapped ? Cin : Cout;
@@ -116,6 +116,37 @@ __global__ void pack_weight_kernel(int mode, int dt, const float* w, int Cout, i
     }
     store_elem(out, i, dt, v);
   }
+}
+
+// All layers of a network in ONE launch: blockIdx.y selects the item (table in device memory),
+// blockIdx.x grid-strides over that item's packed elements.
+__device__ __forceinline__ float pack_elem(const csmri_pack_item& it, const PackGeom& g, long long i) {
+  const long long per_class = (long long)g.rows_pad * g.Kp;
+  const int cls = (int)(i / per_class);
+  const long long rem = i - cls * per_class;
+  const int row = (int)(rem / g.Kp), k = (int)(rem - (long long)row * g.Kp);
+  const int tap = k / g.chan_pad, ch = k - tap * g.chan_pad;
+  const int ty = tap / g.tw, tx = tap - ty * g.tw;
+  if (!(row < g.rows && tap < g.taps)) return 0.f;
+  const float* w = it.w;
+  const int Cin = it.Cin, Cout = it.Cout, KH = it.KH, KW = it.KW;
+  if (it.mode == 0) return (ch < Cin && tx < KW) ? w[(((long long)row * Cin + ch) * KH + ty) * KW + tx] : 0.f;
+  if (it.mode == 1) return (ch < Cout && tx < KW) ? w[(((long long)ch * Cin + row) * KH + ty) * KW + tx] : 0.f;
+  if (it.mode == 3) return (ch < Cout && tx < KW) ? w[(((long long)ch * Cin + row) * KH + (KH - 1 - ty)) * KW + (KW - 1 - tx)] : 0.f;
+  const int ky = (cls >> 1) + 2 * ty, kx = (cls & 1) + 2 * tx;
+  return ch < Cout ? w[(((long long)ch * Cin + row) * KH + ky) * KW + kx] : 0.f;
+}
+__global__ void pack_weight_multi_kernel(const csmri_pack_item* items) {
+  const csmri_pack_item it = items[blockIdx.y];
+  const PackGeom g = pack_geom(it.mode, it.Cout, it.Cin, it.KH, it.KW);
+  const long long total = (long long)g.nclass * g.rows_pad * g.Kp;
+  GRID_STRIDE(i, total) store_elem(it.out, i, it.dtype, pack_elem(it, g, i));
+}
+extern "C" int csmri_pack_weight_multi(const csmri_pack_item* items_dev, int n, void* stream) {
+  CSMRI_CHECK_ARG(items_dev && n > 0);
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(512, n), dim3(256), 0, (hipStream_t)stream, items_dev);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
 }
 
 extern "C" size_t csmri_pack_weight_bytes(int mode, int dtype, int Cout, int Cin, int KH, int KW) {

@@ -205,12 +205,12 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(int kind, int dt, con
   double tot = block_sum(acc);
   if (threadIdx.x == 0) ((double*)work)[1 + blockIdx.x] = tot;
 }
-__global__ void loss_final_kernel(float* work, int n, double inv_count, float* result) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double t = 0;
-    for (int i = 0; i < n; ++i) t += ((double*)work)[1 + i];
-    result[0] = (float)(t * inv_count);
-  }
+__global__ __launch_bounds__(256) void loss_final_kernel(float* work, int n, double inv_count, float* result) {
+  // fixed-order tree over the per-block partials (deterministic)
+  double t = 0;
+  for (int i = threadIdx.x; i < n; i += 256) t += ((double*)work)[1 + i];
+  t = block_sum(t);
+  if (threadIdx.x == 0) result[0] = (float)(t * inv_count);
 }
 extern "C" int csmri_loss(int kind, int dtype, const void* a, int a_pix_stride, const void* b,
                           int b_pix_stride, long long npix, int C_real, float* result, float* work,
@@ -222,7 +222,7 @@ extern "C" int csmri_loss(int kind, int dtype, const void* a, int a_pix_stride, 
   hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, st, kind, dtype, a, a_pix_stride,
                      b, b_pix_stride, npix, C_real, work);
   CSMRI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, work, blocks,
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, work, blocks,
                      1.0 / ((double)npix * (double)C_real), result);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
@@ -302,23 +302,39 @@ extern "C" int csmri_bce_logits_bwd(const float* logits, long long n, float targ
 // per-image MSE between clamp(|pred|,0,1) and clamp(|target|,0,1); one block per image
 __global__ __launch_bounds__(256) void psnr_mse_kernel(const float2* pred, const float2* tgt, long long HW,
                                                        float* mse) {
+  // grid = (image, PSNR_SPLIT): partial sums per slice of the image, combined below
   const float2* p = pred + (size_t)blockIdx.x * HW;
   const float2* t = tgt + (size_t)blockIdx.x * HW;
+  const long long chunk = (HW + gridDim.y - 1) / gridDim.y;
+  const long long i0 = blockIdx.y * chunk, i1 = min(HW, i0 + chunk);
   double acc = 0;
-  for (long long i = threadIdx.x; i < HW; i += 256) {
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
     float a = fminf(fmaxf(sqrtf(p[i].x * p[i].x + p[i].y * p[i].y), 0.f), 1.f);
     float b = fminf(fmaxf(sqrtf(t[i].x * t[i].x + t[i].y * t[i].y), 0.f), 1.f);
     float d = a - b;
     acc += (double)(d * d);
   }
   double tot = block_sum(acc);
-  if (threadIdx.x == 0) mse[blockIdx.x] = (float)(tot / (double)HW);
+  if (threadIdx.x == 0) mse[blockIdx.x * gridDim.y + blockIdx.y] = (float)tot;
+}
+#define PSNR_SPLIT 32
+__global__ void psnr_final_kernel(const float* part, int B, double inv_hw, float* mse) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double t = 0;
+  for (int j = 0; j < PSNR_SPLIT; ++j) t += part[b * PSNR_SPLIT + j];
+  mse[b] = (float)(t * inv_hw);
 }
 extern "C" int csmri_psnr_mse(const float* pred, const float* target, int B, long long HW, float* mse,
                               void* stream) {
   CSMRI_CHECK_ARG(pred && target && mse && B > 0);
-  hipLaunchKernelGGL(psnr_mse_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float2*)pred,
-                     (const float2*)target, HW, mse);
+  // mse must hold B * (1 + PSNR_SPLIT) floats: [0,B) results, then the partials
+  float* part = mse + B;
+  hipLaunchKernelGGL(psnr_mse_kernel, dim3(B, PSNR_SPLIT), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)pred, (const float2*)target, HW, part);
+  CSMRI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(psnr_final_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, B,
+                     1.0 / (double)HW, mse);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -272,6 +272,169 @@ __global__ void colsum_final_kernel(const float* partial, int rows, int C, int C
   db[c] = accumulate ? db[c] + (float)s : (float)s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 path: the staged tiles keep the natural [pixel][channel] layout (16-byte global loads
+// written straight to LDS, no register transposes, every thread loads both operands) and the
+// K-contiguous MFMA fragments are produced by the LDS itself with ds_read_b64_tr_b16 (hardware
+// transposed read: a 16-lane group reads a 4-pixel x 16-channel block and each lane receives
+// one channel's 4 pixels).  16-byte chunks of a pixel row are XOR-swizzled per row so that the
+// transposed reads of a 32-lane half (8 pixel rows x 2 chunks) hit 16 distinct slots.
+template <int CPR> __device__ __forceinline__ int img_off(int row, int chunk) {
+  int f;
+  if constexpr (CPR >= 16) f = ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
+  else if constexpr (CPR == 8) f = (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
+  else if constexpr (CPR == 4) f = ((row >> 3) & 1) << 1;
+  else f = 0;
+  return row * CPR * 16 + ((chunk ^ f) << 4);
+}
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+struct s16x8_pair { s16x4_t lo, hi; };
+__device__ __forceinline__ bf16x8_t tr_frag(const char* img, int off_lo, int off_hi) {
+  s16x8_pair r;
+  r.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(img + off_lo));
+  r.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(img + off_hi));
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <int BP, int BQ, int WP, int WQ>
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const WParams p) {
+  constexpr int PS = 64;                              // pixels per K step (2 MFMA chunks)
+  constexpr int CP = BP / 8, CQ = BQ / 8;             // 16-byte chunks per pixel row
+  constexpr int NXV = 64 * CP / 256, PXS = 256 / CP;  // X vectors per thread, pixel spacing
+  constexpr int NYV = (64 * CQ + 255) / 256, PYS = 256 / CQ;
+  constexpr int WTP = BP / WP, WTQ = BQ / WQ, FP = WTP / 16, FQ = WTQ / 16;
+  constexpr int IMG_X = 64 * BP * 2, IMG_Y = 64 * BQ * 2, BUF = IMG_X + IMG_Y;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wp = wid / WQ, wq = wid % WQ;
+  const int ptile = blockIdx.x / p.qtiles, qtile = blockIdx.x - ptile * p.qtiles;
+  const int p0 = ptile * BP, q0 = qtile * BQ;
+  const int ks = blockIdx.z;
+  const int s_begin = ks * p.steps_per_split;
+  const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+  const int HoWo = p.Ho * p.Wo;
+  const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
+
+  // X operand: this thread's 16-byte chunk = 8 consecutive (tap, ci) columns, fixed for the launch
+  const int xchunk = tid % CP, xpix0 = tid / CP;
+  const int col = p0 + xchunk * 8;
+  const bool xact = col < p.NK;
+  int ci = 0, dyo = 0, dxo = 0;
+  if (xact) {
+    const int tap = col / p.Cin;
+    ci = col - tap * p.Cin;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    dyo = ky - p.pt; dxo = kx - p.pl;
+  }
+  const char* xsrc = (ci < p.c0) ? p.in0 + (size_t)ci * 2 : p.in1 + (size_t)(ci - p.c0) * 2;
+  const int xps = (ci < p.c0) ? p.ps0 : p.ps1;
+  int sb[NXV], soy[NXV], sox[NXV];
+#pragma unroll
+  for (int j = 0; j < NXV; ++j) {
+    const int m = s_begin * PS + xpix0 + j * PXS;
+    sb[j] = m / HoWo;
+    const int r = m - sb[j] * HoWo;
+    soy[j] = r / p.Wo; sox[j] = r - soy[j] * p.Wo;
+  }
+  // Y operand (dY): chunk = 8 consecutive output channels
+  const int ychunk = tid % CQ, ypix0 = tid / CQ;
+  const bool yact = q0 + ychunk * 8 < p.Cout;
+
+  u32x4_t xr[NXV], yr[NYV];
+  auto load_step = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < NXV; ++j) {
+      const int m = s * PS + xpix0 + j * PXS;
+      u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+      if (xact && m < p.M) {
+        int u = soy[j] * p.S + dyo, w = sox[j] * p.S + dxo;
+        bool ok = true;
+        if (p.border == CSMRI_BORDER_REFLECT) { u = reflect_idx(u, Hv); w = reflect_idx(w, Wv); }
+        else ok = (unsigned)u < (unsigned)Hv && (unsigned)w < (unsigned)Wv;
+        if (p.ups) { u >>= 1; w >>= 1; }
+        if (ok) v = *(const u32x4_t*)(xsrc + (((size_t)sb[j] * p.Hin + u) * p.Win + w) * (size_t)xps * 2);
+      }
+      xr[j] = v;
+      sox[j] += PS;
+      while (sox[j] >= p.Wo) { sox[j] -= p.Wo; if (++soy[j] == p.Ho) { soy[j] = 0; ++sb[j]; } }
+    }
+#pragma unroll
+    for (int j = 0; j < NYV; ++j) {
+      const int pix = ypix0 + j * PYS, m = s * PS + pix;
+      u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+      if (pix < PS && yact && m < p.M)
+        v = *(const u32x4_t*)(p.dy + ((size_t)m * p.dyps + q0 + ychunk * 8) * 2);
+      yr[j] = v;
+    }
+  };
+  auto store_step = [&](int buf) {
+    char* base = smem + buf * BUF;
+#pragma unroll
+    for (int j = 0; j < NXV; ++j) *(u32x4_t*)(base + img_off<CP>(xpix0 + j * PXS, xchunk)) = xr[j];
+#pragma unroll
+    for (int j = 0; j < NYV; ++j) {
+      const int pix = ypix0 + j * PYS;
+      if (pix < PS) *(u32x4_t*)(base + IMG_X + img_off<CQ>(pix, ychunk)) = yr[j];
+    }
+  };
+
+  f32x4_t acc[FP][FQ];
+#pragma unroll
+  for (int i = 0; i < FP; ++i)
+#pragma unroll
+    for (int j = 0; j < FQ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // transposed-read lane geometry: lane = 16*g + 4*q + pp
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  auto mma_step = [&](const char* base) {
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      const int rlo = kc * 32 + 8 * g + tq, rhi = rlo + 4;
+      bf16x8_t pf[FP], qf[FQ];
+#pragma unroll
+      for (int i = 0; i < FP; ++i) {
+        const int ch = (wp * WTP + i * 16) / 8 + (tp >> 1);
+        pf[i] = tr_frag(base, img_off<CP>(rlo, ch) + (tp & 1) * 8, img_off<CP>(rhi, ch) + (tp & 1) * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < FQ; ++j) {
+        const int ch = (wq * WTQ + j * 16) / 8 + (tp >> 1);
+        qf[j] = tr_frag(base + IMG_X, img_off<CQ>(rlo, ch) + (tp & 1) * 8, img_off<CQ>(rhi, ch) + (tp & 1) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < FP; ++i)
+#pragma unroll
+        for (int j = 0; j < FQ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (s_begin < s_end) {
+    load_step(s_begin);
+    store_step(0);
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+      const int cur = (s - s_begin) & 1;
+      const bool more = s + 1 < s_end;
+      if (more) load_step(s + 1);
+      mma_step(smem + cur * BUF);
+      if (more) store_step(cur ^ 1);
+      __syncthreads();
+    }
+  }
+  const int r16 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < FQ; ++j) {
+    const int co = q0 + wq * WTQ + j * 16 + r16;
+    if (co >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < FP; ++i) {
+      const int cc = p0 + wp * WTP + i * 16 + g * 4;
+      if (cc < p.NK) *(f32x4_t*)(p.slab + ((size_t)ks * p.Cout + co) * p.NK + cc) = acc[i][j];
+    }
+  }
+}
+
 struct WConfig { int BP, BQ; };
 static WConfig pick_wconfig(const csmri_wgrad_desc* d) {
   WConfig c;
@@ -315,6 +478,21 @@ static int launch_wgrad(const WParams& p, hipStream_t st) {
   return CSMRI_OK;
 }
 
+template <int BP, int BQ, int WP, int WQ>
+static int launch_wgrad_tr(const WParams& p, hipStream_t st) {
+  constexpr int lds = 2 * 64 * (BP + BQ) * 2;
+  static bool attr_set = false;
+  auto kern = wgrad_tr_kernel<BP, BQ, WP, WQ>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.ptiles * p.qtiles, 1, p.splitk), dim3(256), lds, st, p);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
 extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   CSMRI_CHECK_ARG(d && d->in0 && d->dy && d->dw && d->slab);
   CSMRI_CHECK_ARG(d->dtype == CSMRI_F32 || d->dtype == CSMRI_BF16);
@@ -345,10 +523,10 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   int rc;
 #define WG(DT_, BP_, BQ_, WP_, WQ_) rc = launch_wgrad<DT_, BP_, BQ_, WP_, WQ_>(p, st)
   if (d->dtype == CSMRI_BF16) {
-    if (c.BQ == 128) WG(CSMRI_BF16, 128, 128, 2, 2);
-    else if (c.BQ == 64) WG(CSMRI_BF16, 128, 64, 2, 2);
-    else if (c.BQ == 32) WG(CSMRI_BF16, 256, 32, 4, 1);
-    else WG(CSMRI_BF16, 256, 16, 4, 1);
+    if (c.BQ == 128) rc = launch_wgrad_tr<128, 128, 2, 2>(p, st);
+    else if (c.BQ == 64) rc = launch_wgrad_tr<128, 64, 2, 2>(p, st);
+    else if (c.BQ == 32) rc = launch_wgrad_tr<256, 32, 4, 1>(p, st);
+    else rc = launch_wgrad_tr<256, 16, 4, 1>(p, st);
   } else {
     if (c.BQ == 128) WG(CSMRI_F32, 128, 128, 2, 2);
     else if (c.BQ == 64) WG(CSMRI_F32, 128, 64, 2, 2);

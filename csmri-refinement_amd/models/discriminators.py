@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from csmri_hip import ops
-from models.utils import (ConvParams, BNParams, same_padding, need_bias, default_compute_dtype,
+from models.utils import (ensure_pack_group, ConvParams, BNParams, same_padding, need_bias, default_compute_dtype,
                           COMPUTE_DTYPES)
 from models.weight_inits import initialize_weights
 
@@ -111,6 +111,7 @@ class CNNDiscriminator(nn.Module):
     """inp: [B,num_inputs,H,W] fp32 (reference API) -- or ``nhwc=`` an NHWC tensor
     [B,H,W,pad8(num_inputs)] already in the compute dtype (internal fast path)."""
     x = nhwc if nhwc is not None else ops.ToNHWC.apply(inp, self.dtype, ops.pad8(self.num_inputs))
+    ensure_pack_group(self)
     feats, chans = [], []
     for conv, bn, drop, f in self._layers:
       if bn is None:

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from csmri_hip import ops
-from models.utils import ConvParams, BNParams, same_padding, default_compute_dtype, COMPUTE_DTYPES
+from models.utils import ensure_pack_group, ConvParams, BNParams, same_padding, default_compute_dtype, COMPUTE_DTYPES
 from models.weight_inits import initialize_weights
 
 REQUIRED_PARAMS = ['num_inputs', 'num_outputs', 'num_layers_per_scale', 'encode_filters',
@@ -161,6 +161,7 @@ class UNET(nn.Module):
 
   def forward_nhwc(self, x):
     """x: NHWC [B,H,W,8] compute dtype -> NHWC [B,H,W,8] (num_outputs real channels)."""
+    ensure_pack_group(self)
     skips = []
     for unit in self.encode_units:
       if unit.downsample:

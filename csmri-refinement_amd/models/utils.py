@@ -107,6 +107,18 @@ class BNParams(nn.Module):
     super(BNParams, self)._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 
+def ensure_pack_group(module):
+  """All trainable conv layers of ``module`` re-pack their weights with one launch per mode
+  (ops.PackGroup).  Cheap identity check so that .cuda()/.to() re-creations are picked up."""
+  layers = [m.layer for m in module.modules() if isinstance(m, ConvParams) and m.layer is not None
+            and not m.layer.frozen]
+  key = tuple(id(l) for l in layers)
+  if getattr(module, '_pack_group_key', None) != key:
+    module._pack_group = ops.PackGroup(layers)
+    module._pack_group_key = key
+  return module._pack_group
+
+
 def freeze(module):
   for p in module.parameters():
     p.requires_grad = False

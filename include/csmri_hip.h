@@ -121,6 +121,14 @@ int csmri_pack_weight(int mode, int dtype, const float* w_ref, int Cout, int Cin
                       int KH, int KW, void* out, int* Kp_out, long long* class_stride_out,
                       int* TW_out, void* stream);
 
+/* Multi-tensor form: one launch packs every item of a table that lives in DEVICE memory
+ * (a network's weights are re-packed after each optimizer step). */
+typedef struct csmri_pack_item {
+  const float* w; void* out;
+  int mode, dtype, Cout, Cin, KH, KW;
+} csmri_pack_item;
+int csmri_pack_weight_multi(const csmri_pack_item* items_dev, int n, void* stream);
+
 /* ------------------------------------------------------------------------
  * Weight gradient of a convolution (nn.Conv2d backward w.r.t. weight):
  *   dW[n][c][ky][kx] += sum_{b,oy,ox} dY[b,oy,ox,n] * Xb[b, oy*s+ky-pt, ox*s+kx-pl, c]
@@ -275,7 +283,8 @@ int csmri_bce_logits(const float* logits, long long n, float target, float* prob
 int csmri_bce_logits_bwd(const float* logits, long long n, float target, const float* coeff,
                          float weight, float* glogits, int accumulate, void* stream);
 /* PSNR (metrics/image_metrics.py:7-19 with rec_transforms.py:79-85): per image
- * mse of clamp(|.|,0,1); out[b] = mse_b (host takes 10*log10(1/mse)). */
+ * mse of clamp(|.|,0,1); mse[b] = mse_b for b < B (host takes 10*log10(1/mse)); mse must
+ * hold B*33 floats (the tail is the per-image partial-sum workspace). */
 int csmri_psnr_mse(const float* pred, const float* target, int B, long long HW,
                    float* mse, void* stream);
 
