@@ -136,15 +136,47 @@ __device__ __forceinline__ float pack_elem(const csmri_pack_item& it, const Pack
   const int ky = (cls >> 1) + 2 * ty, kx = (cls & 1) + 2 * tx;
   return ch < Cout ? w[(((long long)ch * Cin + row) * KH + ky) * KW + kx] : 0.f;
 }
-__global__ void pack_weight_multi_kernel(const csmri_pack_item* items) {
+// Re-pack of buffers that were fully written once by csmri_pack_weight (so their zero padding
+// of rows / K tail is in place): a tiled 3-D transpose through LDS.  One tile = one destination
+// row (co, or ci for the swapped modes) x 64 destination channels x all taps; the fp32 source is
+// read in runs of taps (mode 0: 64*taps contiguous floats) and the packed destination written as
+// 64 consecutive elements per tap.  Requires KH*KW <= 16.
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const csmri_pack_item* items) {
+  __shared__ float tile[16][65];
   const csmri_pack_item it = items[blockIdx.y];
   const PackGeom g = pack_geom(it.mode, it.Cout, it.Cin, it.KH, it.KW);
-  const long long total = (long long)g.nclass * g.rows_pad * g.Kp;
-  GRID_STRIDE(i, total) store_elem(it.out, i, it.dtype, pack_elem(it, g, i));
+  const int T = it.KH * it.KW, KW = it.KW, KH = it.KH;
+  const bool swapped = it.mode != 0;
+  const int chan = swapped ? it.Cout : it.Cin;
+  const int nchunk = (g.chan_pad + 63) / 64;
+  const long long per_class = (long long)g.rows_pad * g.Kp;
+  const int ntap = g.th * g.tw;
+  for (int t = blockIdx.x; t < g.rows * nchunk; t += gridDim.x) {
+    const int r = t / nchunk, c0 = (t - r * nchunk) * 64;
+    const int nc = max(0, min(64, chan - c0));
+    for (int e = threadIdx.x; e < nc * T; e += 256) {
+      const int ch = e / T, tap = e - ch * T;
+      tile[tap][ch] = swapped ? it.w[((long long)(c0 + ch) * it.Cin + r) * T + tap]
+                              : it.w[((long long)r * it.Cin + c0 + ch) * T + tap];
+    }
+    __syncthreads();
+    const int ncp = min(64, g.chan_pad - c0);
+    for (int e = threadIdx.x; e < g.nclass * ntap * ncp; e += 256) {
+      const int ch = e % ncp, q = e / ncp;
+      const int tp = q % ntap, cls = q / ntap;
+      const int ty = tp / g.tw, tx = tp - ty * g.tw;
+      int src = -1;
+      if (it.mode == 2) src = ((cls >> 1) + 2 * ty) * KW + (cls & 1) + 2 * tx;
+      else if (tx < KW) src = it.mode == 3 ? (KH - 1 - ty) * KW + (KW - 1 - tx) : ty * KW + tx;
+      const float v = (src >= 0 && ch < nc) ? tile[src][ch] : 0.f;
+      store_elem(it.out, cls * per_class + (long long)r * g.Kp + (long long)tp * g.chan_pad + c0 + ch, it.dtype, v);
+    }
+    __syncthreads();
+  }
 }
 extern "C" int csmri_pack_weight_multi(const csmri_pack_item* items_dev, int n, void* stream) {
   CSMRI_CHECK_ARG(items_dev && n > 0);
-  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(512, n), dim3(256), 0, (hipStream_t)stream, items_dev);
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(2048, n), dim3(256), 0, (hipStream_t)stream, items_dev);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

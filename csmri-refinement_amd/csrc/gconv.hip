@@ -247,6 +247,8 @@ struct GConfig { int BM, BN, WM, KC; };
 static GConfig pick_config(const csmri_gconv_desc* d) {
   GConfig c;
   c.KC = d->dtype == CSMRI_BF16 ? 2 : 1;
+  static const char* kc_env = getenv("CSMRI_GCONV_KC");      // tuning knob (bf16, 128x128 tile only)
+  if (kc_env && d->dtype == CSMRI_BF16 && d->Cout > 64) c.KC = atoi(kc_env) == 1 ? 1 : 2;
   if (d->Cout > 64) { c.BM = 128; c.BN = 128; c.WM = 2; }
   else if (d->Cout > 32) { c.BM = 128; c.BN = 64; c.WM = 2; }
   else if (d->Cout > 16) { c.BM = 256; c.BN = 32; c.WM = 4; }
@@ -342,7 +344,8 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
   int rc;
 #define GC(DT_, BM_, BN_, WM_, WN_, KC_) rc = launch_gconv<DT_, BM_, BN_, WM_, WN_, KC_>(p, st)
   if (d->dtype == CSMRI_BF16) {
-    if (c.BN == 128) GC(CSMRI_BF16, 128, 128, 2, 2, 2);
+    if (c.BN == 128 && c.KC == 1) GC(CSMRI_BF16, 128, 128, 2, 2, 1);
+    else if (c.BN == 128) GC(CSMRI_BF16, 128, 128, 2, 2, 2);
     else if (c.BN == 64) GC(CSMRI_BF16, 128, 64, 2, 2, 2);
     else if (c.BN == 32) GC(CSMRI_BF16, 256, 32, 4, 1, 2);
     else GC(CSMRI_BF16, 256, 16, 4, 1, 2);
