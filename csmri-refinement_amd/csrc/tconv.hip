@@ -18,7 +18,7 @@
 #include "mma_core.h"
 #include "gconv_params.h"
 
-template <int CIN, int FN>
+template <int CIN, int FN, bool STREAM>
 __global__ __launch_bounds__(256) void tconv_kernel(const GParams p) {
   constexpr int RB = CIN * 2;                       // bytes per patch pixel
   constexpr int VPP = RB / 16;                      // 16-byte vectors per pixel
@@ -72,6 +72,18 @@ __global__ __launch_bounds__(256) void tconv_kernel(const GParams p) {
     for (int j = 0; j < LB; ++j)
       if (offs[j] >= 0) *(u32x4_t*)(smem + offs[j]) = vals[j];
   }
+  {
+    // weights: all chunks (WHOLE) or stage 0 = first 2 chunks (STREAM) -> LDS tiles
+    const int nq_all = p.TH * (p.TW / TPC) * KCH;
+    const int nload = STREAM ? min(2, nq_all) : nq_all;
+    const char* wsrc0 = p.w + (size_t)n0 * p.Kp * 2;
+    char* wl0 = smem + p.nsteps;
+    for (int v = tid; v < nload * BN * 4; v += 256) {
+      const int c = v / (BN * 4), row = (v >> 2) % BN, sl = v & 3;
+      *(u32x4_t*)(wl0 + c * (BN * 64) + tile_off(row, sl)) =
+          *(const u32x4_t*)(wsrc0 + ((size_t)row * p.Kp + (size_t)c * 32 + sl * 8) * 2);
+    }
+  }
   __syncthreads();
 
   // ---- K loop out of LDS -----------------------------------------------------------------
@@ -87,19 +99,18 @@ __global__ __launch_bounds__(256) void tconv_kernel(const GParams p) {
   const int nq = p.TH * groups_x * KCH;
   const char* wrow = p.w + ((size_t)(n0 + r16) * p.Kp + g * 8) * 2;
   const size_t wfn = (size_t)16 * p.Kp * 2;
-  // weight fragments come straight from L2: a 4-deep register ring keeps three chunks of
-  // loads in flight (one chunk is only 4*FN MFMAs ~ 60-250 cycles, L2 latency is ~500+)
-  u32x4_t bq[4][FN];
-  auto bload = [&](u32x4_t (&dst)[FN], int q) {
-    if (q < nq) {
-#pragma unroll
-      for (int i = 0; i < FN; ++i) dst[i] = *(const u32x4_t*)(wrow + i * wfn + (size_t)q * 64);
-    }
-  };
+  // Weights go through LDS so that the four waves share one fetch (an ablation showed the
+  // per-wave L2 re-fetch of the weight fragments, not MFMA or the patch load, bounding the
+  // loop).  Layout: per 32-wide K chunk a [BN][64 B] tile with the mma_core swizzle.
+  //   WHOLE : all nq chunks are resident (loaded with the patch, no further barrier)
+  //   STREAM: SC chunks per stage, double buffered, one barrier per stage
+  (void)wrow; (void)wfn;
   int ty = 0, txg = 0, cb = 0;
-  auto compute = [&](const u32x4_t (&bw)[FN]) {
+  auto compute = [&](const char* wt) {      // wt: this chunk's [BN][64 B] weight tile
     const int poff = ty * TPW + txg * TPC;
-    u32x4_t a[4];
+    u32x4_t a[4], bw[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) bw[i] = *(const u32x4_t*)(wt + tile_off(i * 16 + r16, g));
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int P = pbase[f] + poff;
@@ -116,12 +127,46 @@ __global__ __launch_bounds__(256) void tconv_kernel(const GParams p) {
                                                             __builtin_bit_cast(bf16x8_t, a[f]), acc[i][f], 0, 0, 0);
     if (++cb == KCH) { cb = 0; if (++txg == groups_x) { txg = 0; ++ty; } }
   };
-  bload(bq[0], 0); bload(bq[1], 1); bload(bq[2], 2);
-  for (int q = 0; q < nq; q += 4) {
-    bload(bq[3], q + 3); compute(bq[0]);
-    if (q + 1 < nq) { bload(bq[0], q + 4); compute(bq[1]); }
-    if (q + 2 < nq) { bload(bq[1], q + 5); compute(bq[2]); }
-    if (q + 3 < nq) { bload(bq[2], q + 6); compute(bq[3]); }
+  char* wl = smem + p.nsteps;                  // weight region starts after the patch (host: 16-B aligned)
+  constexpr int WT = BN * 64;                  // bytes of one chunk's weight tile
+  const char* wsrc = p.w + (size_t)n0 * p.Kp * 2;
+  if (!STREAM) {
+    // (the loads were issued together with the patch, see wload_whole above the barrier)
+    for (int q = 0; q < nq; ++q) compute(wl + q * WT);
+  } else {
+    constexpr int SC = 2;                      // chunks per stage
+    constexpr int SV = SC * BN * 4;            // 16-byte vectors per stage
+    constexpr int SI = (SV + 255) / 256;
+    const int nst = (nq + SC - 1) / SC;
+    u32x4_t wr[SI];
+    auto sload = [&](int st) {
+#pragma unroll
+      for (int it = 0; it < SI; ++it) {
+        const int v = tid + it * 256;
+        const int c = v / (BN * 4), row = (v >> 2) % BN, sl = v & 3;
+        wr[it] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (v < SV && st * SC + c < nq)
+          wr[it] = *(const u32x4_t*)(wsrc + ((size_t)row * p.Kp + (size_t)(st * SC + c) * 32 + sl * 8) * 2);
+      }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+      for (int it = 0; it < SI; ++it) {
+        const int v = tid + it * 256;
+        const int c = v / (BN * 4), row = (v >> 2) % BN, sl = v & 3;
+        if (v < SV) *(u32x4_t*)(wl + (buf * SC + c) * WT + tile_off(row, sl)) = wr[it];
+      }
+    };
+    // stage 0 was stored before the first barrier (see below); pipeline the rest
+    for (int st = 0; st < nst; ++st) {
+      const bool more = st + 1 < nst;
+      if (more) sload(st + 1);
+#pragma unroll
+      for (int c = 0; c < SC; ++c)
+        if (st * SC + c < nq) compute(wl + ((st & 1) * SC + c) * WT);
+      if (more) sstore((st + 1) & 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue (same contract as gconv) -----------------------------------------------------
@@ -194,11 +239,16 @@ int tconv_stats_rows(const csmri_gconv_desc* d) {
   return d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16) * 4;
 }
 
-template <int CIN, int FN>
-static int launch_tconv(const GParams& p, const csmri_gconv_desc* d, hipStream_t st) {
-  const int lds = (16 + d->TH - 1) * (16 + d->TW - 1) * CIN * 2;
+template <int CIN, int FN, bool STREAM>
+static int launch_tconv(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
+  GParams p = p0;
+  const int patch = ((16 + d->TH - 1) * (16 + d->TW - 1) * CIN * 2 + 15) & ~15;
+  const int tpc = CIN >= 32 ? 1 : 32 / CIN, kch = CIN >= 32 ? CIN / 32 : 1;
+  const int nq = d->TH * (d->TW / tpc) * kch;
+  const int lds = patch + (STREAM ? 2 * 2 : nq) * FN * 16 * 64;
+  p.nsteps = patch;                 // tconv reuses this field: byte offset of the weight tiles
   static int attr = 0;
-  auto kern = tconv_kernel<CIN, FN>;
+  auto kern = tconv_kernel<CIN, FN, STREAM>;
   if (lds > attr) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
@@ -213,7 +263,12 @@ static int launch_tconv(const GParams& p, const csmri_gconv_desc* d, hipStream_t
 
 int tconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st) {
   const int fn = tconv_fn(d);
-#define TC(C_, F_) return launch_tconv<C_, F_>(p, d, st)
+  // whole filter resident in LDS when patch + weights stay under 64 KiB (>= 2 workgroups/CU)
+  const int tpc_ = d->Cin >= 32 ? 1 : 32 / d->Cin, kch_ = d->Cin >= 32 ? d->Cin / 32 : 1;
+  const int nq_ = d->TH * (d->TW / tpc_) * kch_;
+  const int patch_ = (16 + d->TH - 1) * (16 + d->TW - 1) * d->Cin * 2;
+  const bool stream = patch_ + nq_ * fn * 16 * 64 > 64 * 1024;
+#define TC(C_, F_) do { if (stream) return launch_tconv<C_, F_, true>(p, d, st); return launch_tconv<C_, F_, false>(p, d, st); } while (0)
 #define TCC(C_) do { if (fn == 4) TC(C_, 4); else if (fn == 2) TC(C_, 2); else TC(C_, 1); } while (0)
   switch (d->Cin) {
     case 8: TCC(8);
