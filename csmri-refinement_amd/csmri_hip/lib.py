@@ -43,7 +43,7 @@ class GConvDesc(C.Structure):
       ('bias', vp), ('act_slope', f32),
       ('g_src', vp), ('g_pix_stride', i32), ('g_slope', f32), ('g_dtype', i32),
       ('stats_partial', vp),
-      ('splitk', i32), ('slab', vp),
+      ('splitk', i32), ('slab', vp), ('flags', i32),
   ]
 
 
@@ -73,6 +73,8 @@ _SIGS = {
     'csmri_error_string': (C.c_char_p, [i32]),
     'csmri_shutdown': (i32, []),
     'csmri_gconv': (i32, [C.POINTER(GConvDesc), vp]),
+    'csmri_gconv_reduce': (i32, [C.POINTER(GConvDesc), vp]),
+    'csmri_gconv_kernel_name': (i32, [C.POINTER(GConvDesc), C.c_char_p, i32]),
     'csmri_gconv_stats_rows': (i32, [C.POINTER(GConvDesc)]),
     'csmri_gconv_slab_bytes': (sz, [C.POINTER(GConvDesc)]),
     'csmri_gconv_suggest_splitk': (i32, [C.POINTER(GConvDesc)]),

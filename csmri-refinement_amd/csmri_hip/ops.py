@@ -267,11 +267,18 @@ def _gconv_run(d, want_stats, flops=0.0):
     rows = lib.raw('csmri_gconv_stats_rows')(C.byref(d))
     stats = torch.empty(rows, 2, d.Cout, dtype=torch.float32, device=dev)
     d.stats_partial = stats.data_ptr()
-  tiled = (d.dtype == BF16 and d.in_s == 1 and d.dy_step == 1 and d.dx_step == 1 and d.nclass <= 1 and
-           splitk == 1 and d.Cin in (8, 16, 32, 64) and d.Ho * d.Wo >= 4096 and d.out_sy == 1)
-  with _Timed(_tile_label('tconv' if tiled else 'gconv', d.dtype, d.Cout) +
-              ('_splitk' if splitk > 1 else ''), flops):
+  if PROFILE is None:
     lib.call('csmri_gconv', C.byref(d), stream())
+    return stats
+  # profiling: bracket the main kernel alone, keyed by the instance name rocprofv3 reports
+  name = C.create_string_buffer(96)
+  lib.call('csmri_gconv_kernel_name', C.byref(d), name, 96)
+  d.flags = 1                                 # CSMRI_GCONV_DEFER_REDUCE
+  with _Timed(name.value.decode(), flops):
+    lib.call('csmri_gconv', C.byref(d), stream())
+  if splitk > 1:
+    with _Timed('gconv_reduce_kernel', 0.0):
+      lib.call('csmri_gconv_reduce', C.byref(d), stream())
   return stats
 
 
@@ -636,9 +643,13 @@ class FrozenConvStackPair(torch.autograd.Function):
     saved = ctx.saved_tensors
     gmap = {t: gouts[j] for j, t in enumerate(taps)}
     g = None
+    act_done = False       # True when g already carries the activation derivative of plan[i]
     for i in range(len(plan) - 1, -1, -1):
       if i in gmap and gmap[i] is not None:
         gi = as_nhwc(gmap[i])
+        if g is not None and act_done:
+          # a feature tap joins here: its gradient still needs this layer's act derivative
+          gi = act_bwd(gi, saved[i][:b], plan[i][2]) if plan[i][0] == 'conv' and plan[i][2] != 1.0 else gi
         g = gi if g is None else g + gi
       if g is None:
         continue
@@ -647,12 +658,22 @@ class FrozenConvStackPair(torch.autograd.Function):
         y = saved[i][:b]
         if g.dtype != layer.dtype:
           g = g.to(layer.dtype)
-        gp = act_bwd(g, y, slope) if slope != 1.0 else g
+        gp = g if (act_done or slope == 1.0) else act_bwd(g, y, slope)
+        act_done = False
         if i == 0 and not ctx.needs_input_grad[0]:
           return None, None, None, None
-        g = conv_dgrad(layer, gp, ctx.shapes[i])
+        # fuse the producer's activation derivative into this dgrad's epilogue when the
+        # producer is the previous conv of the stack (its output IS this layer's input)
+        prev = plan[i - 1] if i > 0 else None
+        if prev is not None and prev[0] == 'conv' and prev[2] != 1.0 and \
+            layer.border == BORDER_ZERO and not layer.upsample and layer.stride == 1:
+          g = conv_dgrad(layer, gp, ctx.shapes[i], g_src=saved[i - 1][:b], g_slope=prev[2])
+          act_done = True
+        else:
+          g = conv_dgrad(layer, gp, ctx.shapes[i])
       else:
         g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i])
+        act_done = False
     return g, None, None, None
 
 

@@ -18,3 +18,4 @@ struct GParams {
 int tconv_eligible(const csmri_gconv_desc* d);
 int tconv_stats_rows(const csmri_gconv_desc* d);
 int tconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
+void tconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n);

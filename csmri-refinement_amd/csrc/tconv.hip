@@ -279,3 +279,12 @@ int tconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st) {
 #undef TCC
 #undef TC
 }
+
+void tconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n) {
+  const int fn = tconv_fn(d);
+  const int tpc_ = d->Cin >= 32 ? 1 : 32 / d->Cin, kch_ = d->Cin >= 32 ? d->Cin / 32 : 1;
+  const int nq_ = d->TH * (d->TW / tpc_) * kch_;
+  const int patch_ = (16 + d->TH - 1) * (16 + d->TW - 1) * d->Cin * 2;
+  const bool stream = patch_ + nq_ * fn * 16 * 64 > 64 * 1024;
+  snprintf(buf, n, "tconv_kernel<%d, %d, %s>", d->Cin, fn, stream ? "true" : "false");
+}

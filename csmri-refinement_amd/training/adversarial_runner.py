@@ -124,6 +124,8 @@ class AdversarialRunner(BaseRunner):
     self.pool_decisions = None            # optional injected image-pool decisions (tests)
     self._graph = None
     self._last_metrics = None
+    self.overlap_streams = False
+    self._side_stream = None
 
   # -- reference surface -------------------------------------------------------
   def get_named_outputs(self, data):
@@ -213,6 +215,18 @@ class AdversarialRunner(BaseRunner):
 
   def _seg2(self, st):
     batch, out_gen = st['batch'], st['out_gen']
+    st['side_results'] = {}
+    if self.overlap_streams:
+      # the VGG perceptual branch (big GEMMs) is independent of the third D forward (many
+      # small kernels): run it on a side stream; autograd replays the same stream assignment
+      # in the backward, so the two gradient chains into `pred` overlap as well
+      if self._side_stream is None:
+        self._side_stream = torch.cuda.Stream()
+      self._side_stream.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(self._side_stream):
+        for name, criterion in self.gen_criteria.items():
+          if name == 'VGG19':
+            st['side_results'][name] = criterion(out_gen, batch)
     self.disc.set_wgrad(False)     # D's weight gradients of this pass are discarded (A-5)
     out_fake = self.disc(nhwc=self.disc_input_fn(out_gen, st['gen_inp0'], out_gen,
                                                  is_real_input=False, detach=False))
@@ -224,11 +238,14 @@ class AdversarialRunner(BaseRunner):
       gen_losses.append(loss)
       st['names'].append('gen_loss_' + name)
       st['vals'].append(loss.detach())
+    side = st.get('side_results', {})
     for name, criterion in self.gen_criteria.items():
-      loss = criterion(out_gen, batch)
+      loss = side[name] if name in side else criterion(out_gen, batch)
       gen_losses.append(loss)
       st['names'].append('gen_loss_' + name)
       st['vals'].append(loss.detach())
+    if side:
+      torch.cuda.current_stream().wait_stream(self._side_stream)
     st['total_gen'] = self._weighted_total(gen_losses, self.gen_loss_weights)
 
   def _seg3(self, st):

@@ -98,9 +98,15 @@ typedef struct csmri_gconv_desc {
   /* split-K */
   int splitk;                /* >=1; >1 needs slab */
   float* slab;               /* [splitk][M][Cout] fp32 workspace */
+  int flags;                 /* CSMRI_GCONV_DEFER_REDUCE: caller runs csmri_gconv_reduce itself */
 } csmri_gconv_desc;
+#define CSMRI_GCONV_DEFER_REDUCE 1
 
 int csmri_gconv(const csmri_gconv_desc* d, void* stream);
+/* second stage of a split-K launch (slab sum + epilogue); no-op when splitk <= 1 */
+int csmri_gconv_reduce(const csmri_gconv_desc* d, void* stream);
+/* name of the kernel instance csmri_gconv launches for d, as profilers print it (for reports) */
+int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
 /* rows of stats_partial written by csmri_gconv for this problem (0 if splitk>1) */
 int csmri_gconv_stats_rows(const csmri_gconv_desc* d);
 size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d);

@@ -387,9 +387,11 @@ def test_f5_discriminator_fwd_bwd_fp32_vs_reference_golden(env):
   assert worst < 1e-4, worst
 
 
-def test_graph_replay_equals_eager(env):
+@pytest.mark.parametrize('overlap', [False, True], ids=['single_stream', 'vgg_side_stream'])
+def test_graph_replay_equals_eager(env, overlap):
   """hipGraph mode replays exactly the eager kernel sequence: with the stochastic parts off
-  (no dropout layers, no image pool) 2 graphed steps == 2 eager steps, bit for bit."""
+  (no dropout layers, no image pool) 2 graphed steps == 2 eager steps, bit for bit -- also
+  when the VGG branch runs on a side stream (fork/join inside the captured graphs)."""
   Configuration, set_dtype = env
   from training import build_runner
   set_dtype('bf16')
@@ -403,6 +405,7 @@ def test_graph_replay_equals_eager(env):
   batch = {k: v.cuda() for k, v in O.synth_batch(2, 128, 128, acc=4, seed=5).items()}
   host = {k: v.cpu() for k, v in batch.items()}
   a, b = make(), make()
+  a.overlap_streams = b.overlap_streams = overlap
   a._set_train()
   for _ in range(3):
     a._run_segments_eager({'batch': batch})
