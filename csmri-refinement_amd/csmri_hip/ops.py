@@ -222,6 +222,7 @@ class PackGroup(object):
     return True
 
 
+PROFILE_SHAPES = False  # tools: append the problem shape to gconv labels
 PROFILE = None        # bench.py sets this to a list to collect per-launch HIP event timings
 
 
@@ -274,7 +275,11 @@ def _gconv_run(d, want_stats, flops=0.0):
   name = C.create_string_buffer(96)
   lib.call('csmri_gconv_kernel_name', C.byref(d), name, 96)
   d.flags = 1                                 # CSMRI_GCONV_DEFER_REDUCE
-  with _Timed(name.value.decode(), flops):
+  label = name.value.decode()
+  if PROFILE_SHAPES:
+    label += ' B%d %dx%d Cin%d Cout%d t%dx%d s%d ncls%d sk%d' % (
+        d.B, d.Ho, d.Wo, d.Cin, d.Cout, d.TH, d.TW, d.in_s, max(1, d.nclass), splitk)
+  with _Timed(label, flops):
     lib.call('csmri_gconv', C.byref(d), stream())
   if splitk > 1:
     with _Timed('gconv_reduce_kernel', 0.0):

@@ -1,0 +1,223 @@
+// gconv_glds: the implicit-GEMM convolution of gconv.hip with the operand tiles staged by
+// LDS-DMA (global_load_lds_dwordx4) instead of through registers.
+//
+//   D[n][m] = sum_k W[n][k] * X[m][k],  k = (tap, ci),  bf16 operands, fp32 accumulate
+//
+// Tile: 128 positions x BN channels x 64 K per step, 256 threads = 2x2 waves.  One LDS buffer
+// (16 KiB + BN*128 B): a step is {8 or 6 LDS-DMA per thread -> vmcnt(0) -> barrier -> 2x(8 or 6
+// ds_read_b128 + 16 or 8 MFMA) -> barrier}; 3-4 workgroups per CU overlap one another's loads
+// and MFMAs.  An LDS-DMA wave-instruction writes 1 KiB linearly (8 rows x 128 B), so the XOR
+// swizzle that keeps the ds_read_b128 fragment reads conflict-free (16-byte slot ^= (row>>1)&7)
+// is applied on the SOURCE side: the lane that owns slot s of row r fetches K-chunk
+// s ^ ((r>>1)&7) of that row.  Out-of-image taps (zero border), tile rows past M and taps past
+// the filter fetch a 16-byte zero page.
+// Needs Cin % 64 == 0 (a K step never straddles a tap) and Cout % BN == 0; everything else goes
+// to gconv.hip.  Epilogue (bias / leaky / act-derivative / BN partial sums / split-K slab) is the
+// one of gconv.hip.
+#include "mma_core.h"
+#include "gconv_params.h"
+
+__device__ __attribute__((aligned(16))) char g_zero_page[16];
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ int glds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int BN>
+__global__ __launch_bounds__(256, 3) void gconv_glds_kernel(const GParams p) {
+  constexpr int BM = 128, WM = 2, WN = 2;
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
+  constexpr int GA = 4, GB = BN / 32;                  // 8-row groups per wave: positions / weights
+  constexpr int TILE_Q = BM * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int t = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  const int mt = t / p.ntiles, nt = t - mt * p.ntiles;
+  const int cls = blockIdx.z % p.nclass, ks = blockIdx.z / p.nclass;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int s_begin = ks * p.steps_per_split;
+  const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+  const int ooy = p.ooy + (p.nclass == 4 ? (cls >> 1) : 0);
+  const int oox = p.oox + (p.nclass == 4 ? (cls & 1) : 0);
+  const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
+  const int HoWo = p.Ho * p.Wo;
+
+  // this lane's slot in every 8-row group it fills, and the K chunk that belongs there
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7);
+
+  int by[GA], bx[GA], ib[GA];
+#pragma unroll
+  for (int j = 0; j < GA; ++j) {
+    const int m = m0 + (j * 4 + wid) * 8 + lrow;
+    if (m < p.M) {
+      int b = m / HoWo, r = m - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
+      by[j] = oy * p.S + p.dy0; bx[j] = ox * p.S + p.dx0; ib[j] = b * p.Hin * p.Win;
+    } else { by[j] = 0; bx[j] = 0; ib[j] = -1; }
+  }
+  int k0 = s_begin * 64;
+  int tap = k0 / p.Cin, ci = k0 - tap * p.Cin;
+  int ty = tap / p.TW, tx = tap - ty * p.TW;
+  int pix[GA];
+  auto compute_pix = [&]() {
+    const int oy_ = ty * p.dys, ox_ = tx * p.dxs;
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+      int u = by[j] + oy_, v = bx[j] + ox_;
+      bool ok = ib[j] >= 0;
+      if (p.border == CSMRI_BORDER_REFLECT) { u = reflect_idx(u, Hv); v = reflect_idx(v, Wv); }
+      else ok = ok && (unsigned)u < (unsigned)Hv && (unsigned)v < (unsigned)Wv;
+      if (p.ups) { u >>= 1; v >>= 1; }
+      pix[j] = ok ? ib[j] + u * p.Win + v : -1;
+    }
+  };
+  compute_pix();
+  const char* wrow[GB];
+#pragma unroll
+  for (int j = 0; j < GB; ++j)
+    wrow[j] = p.w + ((size_t)cls * (size_t)p.wcs + (size_t)(n0 + (j * 4 + wid) * 8 + lrow) * p.Kp + chunk * 8) * 2;
+
+  auto issue = [&](int s) {
+    const bool second = ci >= p.c0;                     // wave-uniform: c0 % 64 == 0
+    const char* src = second ? p.in1 + (size_t)(ci - p.c0 + chunk * 8) * 2 : p.in0 + (size_t)(ci + chunk * 8) * 2;
+    const size_t ps = (size_t)(second ? p.ps1 : p.ps0) * 2;
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+      const char* g = pix[j] >= 0 ? src + (size_t)pix[j] * ps : g_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(smem + (j * 4 + wid) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < GB; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wrow[j] + (size_t)s * 128),
+                                       (lptr_t)(smem + TILE_Q + (j * 4 + wid) * 1024), 16, 0, 0);
+    ci += 64;
+    if (ci == p.Cin) { ci = 0; if (++tx == p.TW) { tx = 0; ++ty; } compute_pix(); }
+  };
+
+  f32x4_t acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int r16 = lane & 15, g = lane >> 4;
+
+  for (int s = s_begin; s < s_end; ++s) {
+    issue(s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      bf16x8_t pf[FN], qf[FM];
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+        pf[i] = *(const bf16x8_t*)(smem + TILE_Q + glds_off(wn * WTN + i * 16 + r16, kc * 4 + g));
+#pragma unroll
+      for (int j = 0; j < FM; ++j)
+        qf[j] = *(const bf16x8_t*)(smem + glds_off(wm * WTM + j * 16 + r16, kc * 4 + g));
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (same contract as gconv_kernel) --------------------------------------------
+  float s1[FN][4], s2[FN][4];
+  if (p.stats) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[i][r] = 0.f; s2[i][r] = 0.f; }
+  }
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = m0 + wm * WTM + j * 16 + r16;
+    const bool mv = m < p.M;
+    size_t opix = 0, gpix = 0;
+    if (mv) {
+      int b = m / HoWo, r = m - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
+      size_t pp = ((size_t)b * p.Hout_t + (size_t)(oy * p.osy + ooy)) * p.Wout_t + (ox * p.osx + oox);
+      opix = pp * p.ops; gpix = pp * p.gps;
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = n0 + wn * WTN + i * 16 + g * 4;
+      f32x4_t v = acc[i][j];
+      if (p.splitk > 1) {
+        if (mv) *(f32x4_t*)(p.slab + (((size_t)cls * p.splitk + ks) * p.M + m) * p.Cout + n) = v;
+        continue;
+      }
+      if (!mv) continue;
+      if (p.bias) { f32x4_t bb = *(const f32x4_t*)(p.bias + n); v += bb; }
+      if (p.stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
+      }
+      if (p.slope != 1.f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * p.slope : v[r];
+      }
+      if (p.gsrc) {
+        f32x4_t gs = load4(p.gsrc, gpix + n, p.gdt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gs[r] > 0.f ? v[r] : v[r] * p.gslope;
+      }
+      store4(p.out, opix + n, p.out_dt, v);
+    }
+  }
+  if (p.stats && p.splitk == 1) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[i][r], b = s2[i][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        const int n = n0 + wn * WTN + i * 16 + g * 4 + r;
+        if (r16 == 0) {
+          float* row = p.stats + (size_t)(mt * WM + wm) * 2 * p.Cout;
+          row[n] = a; row[p.Cout + n] = b;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+int gconv_glds_bn(const csmri_gconv_desc* d) { return d->Cout % 128 == 0 ? 128 : 64; }
+
+int gconv_glds_eligible(const csmri_gconv_desc* d) {
+  static const char* off = getenv("CSMRI_NO_GLDS");
+  if (off) return 0;
+  if (d->dtype != CSMRI_BF16) return 0;
+  if (d->Cin % 64 || d->Cout % 64) return 0;
+  if (d->in1 && d->c0 % 64) return 0;
+  if (d->in0_pix_stride % 8 || (d->in1 && d->in1_pix_stride % 8)) return 0;
+  return 1;
+}
+
+template <int BN>
+static int launch_glds(const GParams& p, hipStream_t st) {
+  constexpr int lds = (128 + BN) * 128;
+  dim3 grid(p.mtiles * p.ntiles, 1, p.nclass * p.splitk);
+  hipLaunchKernelGGL(gconv_glds_kernel<BN>, grid, dim3(256), lds, st, p);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
+  GParams p = p0;
+  const int bn = gconv_glds_bn(d);
+  p.nsteps = d->TH * d->TW * d->Cin / 64;
+  p.steps_per_split = cdiv(p.nsteps, p.splitk);
+  p.mtiles = cdiv(p.M, 128); p.ntiles = d->Cout / bn;
+  return bn == 128 ? launch_glds<128>(p, st) : launch_glds<64>(p, st);
+}
+
+void gconv_glds_kernel_name(const csmri_gconv_desc* d, char* buf, int n) {
+  snprintf(buf, n, "gconv_glds_kernel<%d>", gconv_glds_bn(d));
+}

@@ -19,3 +19,9 @@ int tconv_eligible(const csmri_gconv_desc* d);
 int tconv_stats_rows(const csmri_gconv_desc* d);
 int tconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 void tconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
+
+// gconv_glds.hip
+int gconv_glds_eligible(const csmri_gconv_desc* d);
+int gconv_glds_bn(const csmri_gconv_desc* d);
+int gconv_glds_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
+void gconv_glds_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
