@@ -435,6 +435,273 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad_glds_kernel: same tiles, images and transposed fragment reads as wgrad_tr_kernel, but the
+// [pixel][channel] images are filled by LDS-DMA (global_load_lds_dwordx4): no staging registers,
+// no ds_write pass (a ds_write_b128 costs 13 LDS cycles per wave-instruction, which made the
+// register-staged kernel store-bound).  An LDS-DMA wave-instruction writes 64 consecutive
+// 16-byte slots, so the chunk swizzle of img_off is applied on the source side: the lane that
+// owns slot s of pixel row r fetches chunk s ^ f(r).  One LDS buffer, two barriers per 64-pixel
+// step; 3-4 workgroups per CU overlap each other's loads and MFMAs.
+__device__ __attribute__((aligned(16))) char w_zero_page[16];
+typedef __attribute__((address_space(1))) const void* wgptr_t;
+typedef __attribute__((address_space(3))) void* wlptr_t;
+
+//
+// wgrad_glds_row_kernel: the same kernel for geometries whose 64-pixel K steps are aligned with
+// output rows (Wo % 64 == 0, or 64 % Wo == 0 with Ho*Wo % 64 == 0 -- every power-of-two feature
+// map).  The step's (b, oy, ox) origin is then wave-uniform (scalar unit) and a lane's pixel is
+// origin + a per-lane constant, which cuts the address arithmetic from ~100 to ~15 vector
+// instructions per 16-byte piece; the general kernel below is vector-ALU bound on exactly that.
+template <int BP, int BQ, int WP, int WQ, bool REFLECT, bool UPS>
+__global__ __launch_bounds__(256, 3) void wgrad_glds_row_kernel(const WParams p) {
+  constexpr int PS = 64;
+  constexpr int CP = BP / 8, CQ = BQ / 8;
+  constexpr int NXI = CP / 4, NYI = (CQ + 3) / 4;
+  constexpr int WTP = BP / WP, WTQ = BQ / WQ, FP = WTP / 16, FQ = WTQ / 16;
+  constexpr int IMG_X = 64 * BP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wid / WQ, wq = wid % WQ;
+  const int ptile = blockIdx.x / p.qtiles, qtile = blockIdx.x - ptile * p.qtiles;
+  const int p0 = ptile * BP, q0 = qtile * BQ;
+  const int ks = blockIdx.z;
+  const int s_begin = ks * p.steps_per_split;
+  const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+  const int Hv = UPS ? 2 * p.Hin : p.Hin, Wv = UPS ? 2 * p.Win : p.Win;
+  const int rows_per_step = p.Wo >= 64 ? 1 : 64 / p.Wo;
+
+  // per instruction: lane constants (tap shift + pixel-in-step shift), source base
+  const char* xsrc[NXI]; int xps[NXI], cu[NXI], cw[NXI];
+#pragma unroll
+  for (int j = 0; j < NXI; ++j) {
+    const int e = (j * 4 + wid) * 64 + lane, row = e / CP, slot = e % CP;
+    const int chunk = ((img_off<CP>(row, slot) >> 4) % CP);
+    const int col = p0 + chunk * 8;
+    const int ry = p.Wo >= 64 ? 0 : row / p.Wo, rx = p.Wo >= 64 ? row : row - ry * p.Wo;
+    xsrc[j] = w_zero_page; xps[j] = 0; cu[j] = 0; cw[j] = 0;      // columns past NK read zeros
+    if (col < p.NK) {
+      const int tap = col / p.Cin, ci = col - tap * p.Cin;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      cu[j] = ry * p.S + ky - p.pt; cw[j] = rx * p.S + kx - p.pl;
+      xsrc[j] = (ci < p.c0) ? p.in0 + (size_t)ci * 2 : p.in1 + (size_t)(ci - p.c0) * 2;
+      xps[j] = ((ci < p.c0) ? p.ps0 : p.ps1) * 2;
+    }
+  }
+  const char* ysrc[NYI]; unsigned ystep[NYI];
+#pragma unroll
+  for (int j = 0; j < NYI; ++j) {
+    const int e = (j * 4 + wid) * 64 + lane, row = e / CQ, slot = e % CQ;
+    const int chunk = ((img_off<CQ>(row, slot) >> 4) % CQ);
+    const bool yv = q0 + chunk * 8 < p.Cout;
+    ysrc[j] = yv ? p.dy + ((size_t)(s_begin * PS + row) * p.dyps + q0 + chunk * 8) * 2 : w_zero_page;
+    ystep[j] = yv ? (unsigned)PS * p.dyps * 2 : 0u;
+  }
+  // wave-uniform origin of the current step
+  int m0 = s_begin * PS;
+  int sb = m0 / (p.Ho * p.Wo);
+  int rem = m0 - sb * p.Ho * p.Wo;
+  int oy0 = rem / p.Wo, ox0 = rem - oy0 * p.Wo;
+  sb = __builtin_amdgcn_readfirstlane(sb); oy0 = __builtin_amdgcn_readfirstlane(oy0);
+  ox0 = __builtin_amdgcn_readfirstlane(ox0);
+
+  auto issue = [&]() {
+    const int su = oy0 * p.S, sw = ox0 * p.S, sbase = sb * p.Hin * p.Win;
+#pragma unroll
+    for (int j = 0; j < NXI; ++j) {
+      int u = su + cu[j], w = sw + cw[j];
+      bool ok = true;
+      if (REFLECT) {                                   // branch-free mirror, |pad| < n
+        u = u < 0 ? -u : u; u = min(u, 2 * (Hv - 1) - u);
+        w = w < 0 ? -w : w; w = min(w, 2 * (Wv - 1) - w);
+      } else ok = ((unsigned)u < (unsigned)Hv) & ((unsigned)w < (unsigned)Wv);
+      if (UPS) { u >>= 1; w >>= 1; }
+      const unsigned pix = (unsigned)sbase + __umul24(u, p.Win) + (unsigned)w;   // < 2^24 (host check)
+      const char* g = xsrc[j] + __umul24(pix, xps[j]);
+      if (!REFLECT) g = ok ? g : w_zero_page;
+      __builtin_amdgcn_global_load_lds((wgptr_t)g, (wlptr_t)(smem + (j * 4 + wid) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NYI; ++j) {
+      if (CQ % 4 == 0 || j * 4 + wid < CQ) {
+        __builtin_amdgcn_global_load_lds((wgptr_t)ysrc[j], (wlptr_t)(smem + IMG_X + (j * 4 + wid) * 1024), 16, 0, 0);
+        ysrc[j] += ystep[j];
+      }
+    }
+    ox0 += PS;
+    if (ox0 >= p.Wo) { ox0 = 0; oy0 += rows_per_step; if (oy0 >= p.Ho) { oy0 = 0; ++sb; } }
+  };
+
+  f32x4_t acc[FP][FQ];
+#pragma unroll
+  for (int i = 0; i < FP; ++i)
+#pragma unroll
+    for (int j = 0; j < FQ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+
+  for (int s = s_begin; s < s_end; ++s) {
+    issue();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      const int rlo = kc * 32 + 8 * g + tq, rhi = rlo + 4;
+      bf16x8_t pf[FP], qf[FQ];
+#pragma unroll
+      for (int i = 0; i < FP; ++i) {
+        const int ch = (wp * WTP + i * 16) / 8 + (tp >> 1);
+        pf[i] = tr_frag(smem, img_off<CP>(rlo, ch) + (tp & 1) * 8, img_off<CP>(rhi, ch) + (tp & 1) * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < FQ; ++j) {
+        const int ch = (wq * WTQ + j * 16) / 8 + (tp >> 1);
+        qf[j] = tr_frag(smem + IMG_X, img_off<CQ>(rlo, ch) + (tp & 1) * 8, img_off<CQ>(rhi, ch) + (tp & 1) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < FP; ++i)
+#pragma unroll
+        for (int j = 0; j < FQ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int r16 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < FQ; ++j) {
+    const int co = q0 + wq * WTQ + j * 16 + r16;
+    if (co >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < FP; ++i) {
+      const int cc = p0 + wp * WTP + i * 16 + g * 4;
+      if (cc < p.NK) *(f32x4_t*)(p.slab + ((size_t)ks * p.Cout + co) * p.NK + cc) = acc[i][j];
+    }
+  }
+}
+
+template <int BP, int BQ, int WP, int WQ>
+__global__ __launch_bounds__(256, 3) void wgrad_glds_kernel(const WParams p) {
+  constexpr int PS = 64;
+  constexpr int CP = BP / 8, CQ = BQ / 8;
+  constexpr int NXI = CP / 4, NYI = (CQ + 3) / 4;    // LDS-DMA instructions per wave per step
+  constexpr int WTP = BP / WP, WTQ = BQ / WQ, FP = WTP / 16, FQ = WTQ / 16;
+  constexpr int IMG_X = 64 * BP * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wp = wid / WQ, wq = wid % WQ;
+  const int ptile = blockIdx.x / p.qtiles, qtile = blockIdx.x - ptile * p.qtiles;
+  const int p0 = ptile * BP, q0 = qtile * BQ;
+  const int ks = blockIdx.z;
+  const int s_begin = ks * p.steps_per_split;
+  const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+  const int HoWo = p.Ho * p.Wo;
+  const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
+
+  // X operand: per instruction, this lane's pixel row (within the step) and (tap, ci) chunk
+  const char* xsrc[NXI]; int xps[NXI], dyo[NXI], dxo[NXI], sb[NXI], soy[NXI], sox[NXI], xm[NXI];
+#pragma unroll
+  for (int j = 0; j < NXI; ++j) {
+    const int e = (j * 4 + wid) * 64 + lane, row = e / CP, slot = e % CP;
+    const int chunk = ((img_off<CP>(row, slot) >> 4) % CP);
+    const int col = p0 + chunk * 8;
+    xsrc[j] = nullptr; xps[j] = 0; dyo[j] = 0; dxo[j] = 0;
+    if (col < p.NK) {
+      const int tap = col / p.Cin, ci = col - tap * p.Cin;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      dyo[j] = ky - p.pt; dxo[j] = kx - p.pl;
+      xsrc[j] = (ci < p.c0) ? p.in0 + (size_t)ci * 2 : p.in1 + (size_t)(ci - p.c0) * 2;
+      xps[j] = ((ci < p.c0) ? p.ps0 : p.ps1) * 2;
+    }
+    const int m = s_begin * PS + row;
+    xm[j] = m;
+    sb[j] = m / HoWo;
+    const int r = m - sb[j] * HoWo;
+    soy[j] = r / p.Wo; sox[j] = r - soy[j] * p.Wo;
+  }
+  // dY operand
+  const char* ysrc[NYI]; int ym[NYI];
+#pragma unroll
+  for (int j = 0; j < NYI; ++j) {
+    const int e = (j * 4 + wid) * 64 + lane, row = e / CQ, slot = e % CQ;
+    const int chunk = ((img_off<CQ>(row, slot) >> 4) % CQ);
+    ym[j] = s_begin * PS + row;
+    ysrc[j] = (q0 + chunk * 8 < p.Cout) ? p.dy + ((size_t)ym[j] * p.dyps + q0 + chunk * 8) * 2 : nullptr;
+  }
+
+  auto issue = [&]() {
+#pragma unroll
+    for (int j = 0; j < NXI; ++j) {
+      const char* g = w_zero_page;
+      if (xsrc[j] && xm[j] < p.M) {
+        int u = soy[j] * p.S + dyo[j], w = sox[j] * p.S + dxo[j];
+        bool ok = true;
+        if (p.border == CSMRI_BORDER_REFLECT) { u = reflect_idx(u, Hv); w = reflect_idx(w, Wv); }
+        else ok = (unsigned)u < (unsigned)Hv && (unsigned)w < (unsigned)Wv;
+        if (p.ups) { u >>= 1; w >>= 1; }
+        if (ok) g = xsrc[j] + (((size_t)sb[j] * p.Hin + u) * p.Win + w) * (size_t)xps[j];
+      }
+      __builtin_amdgcn_global_load_lds((wgptr_t)g, (wlptr_t)(smem + (j * 4 + wid) * 1024), 16, 0, 0);
+      xm[j] += PS; sox[j] += PS;
+      while (sox[j] >= p.Wo) { sox[j] -= p.Wo; if (++soy[j] == p.Ho) { soy[j] = 0; ++sb[j]; } }
+    }
+#pragma unroll
+    for (int j = 0; j < NYI; ++j) {
+      if (CQ % 4 == 0 || j * 4 + wid < CQ) {
+        const char* g = (ysrc[j] && ym[j] < p.M) ? ysrc[j] : w_zero_page;
+        __builtin_amdgcn_global_load_lds((wgptr_t)g, (wlptr_t)(smem + IMG_X + (j * 4 + wid) * 1024), 16, 0, 0);
+        ym[j] += PS;
+        if (ysrc[j]) ysrc[j] += (size_t)PS * p.dyps * 2;
+      }
+    }
+  };
+
+  f32x4_t acc[FP][FQ];
+#pragma unroll
+  for (int i = 0; i < FP; ++i)
+#pragma unroll
+    for (int j = 0; j < FQ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+
+  for (int s = s_begin; s < s_end; ++s) {
+    issue();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      const int rlo = kc * 32 + 8 * g + tq, rhi = rlo + 4;
+      bf16x8_t pf[FP], qf[FQ];
+#pragma unroll
+      for (int i = 0; i < FP; ++i) {
+        const int ch = (wp * WTP + i * 16) / 8 + (tp >> 1);
+        pf[i] = tr_frag(smem, img_off<CP>(rlo, ch) + (tp & 1) * 8, img_off<CP>(rhi, ch) + (tp & 1) * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < FQ; ++j) {
+        const int ch = (wq * WTQ + j * 16) / 8 + (tp >> 1);
+        qf[j] = tr_frag(smem + IMG_X, img_off<CQ>(rlo, ch) + (tp & 1) * 8, img_off<CQ>(rhi, ch) + (tp & 1) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < FP; ++i)
+#pragma unroll
+        for (int j = 0; j < FQ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int r16 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < FQ; ++j) {
+    const int co = q0 + wq * WTQ + j * 16 + r16;
+    if (co >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < FP; ++i) {
+      const int cc = p0 + wp * WTP + i * 16 + g * 4;
+      if (cc < p.NK) *(f32x4_t*)(p.slab + ((size_t)ks * p.Cout + co) * p.NK + cc) = acc[i][j];
+    }
+  }
+}
+
 struct WConfig { int BP, BQ; };
 static WConfig pick_wconfig(const csmri_wgrad_desc* d) {
   WConfig c;
@@ -451,7 +718,9 @@ extern "C" int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d) {
   const long long NK = (long long)d->KH * d->KW * d->Cin;
   const long long tiles = (long long)cdiv(NK, c.BP) * cdiv(d->Cout, c.BQ);
   const int nsteps = cdiv((long long)d->B * d->Ho * d->Wo, wgrad_ps(d->dtype));
-  int sk = (int)((1024 + tiles - 1) / tiles);
+  static const char* target_env = getenv("CSMRI_WGRAD_BLOCKS");   // tuning knob
+  const int target = target_env ? atoi(target_env) : 512;
+  int sk = (int)((target + tiles - 1) / tiles);
   int maxsk = nsteps / 4; if (maxsk < 1) maxsk = 1;
   if (sk > maxsk) sk = maxsk;
   if (sk > 512) sk = 512;
@@ -493,6 +762,26 @@ static int launch_wgrad_tr(const WParams& p, hipStream_t st) {
   return CSMRI_OK;
 }
 
+template <int BP, int BQ, int WP, int WQ>
+static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
+  constexpr int lds = 64 * (BP + BQ) * 2;
+  const bool row_aligned = (p.Wo % 64 == 0 || (64 % p.Wo == 0 && (p.Ho * p.Wo) % 64 == 0)) &&
+                           (long long)p.B * p.Hin * p.Win < (1 << 24) && p.ps0 < (1 << 22) && p.ps1 < (1 << 22) &&
+                           (long long)p.B * p.Hin * p.Win * (p.ps0 > p.ps1 ? p.ps0 : p.ps1) * 2 < (1ll << 32);
+  if (row_aligned) {
+    const dim3 grid(p.ptiles * p.qtiles, 1, p.splitk);
+    const bool refl = p.border == CSMRI_BORDER_REFLECT;
+    if (refl && p.ups) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, true>), grid, dim3(256), lds, st, p);
+    else if (refl) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, false>), grid, dim3(256), lds, st, p);
+    else if (p.ups) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, true>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, false>), grid, dim3(256), lds, st, p);
+  } else
+    hipLaunchKernelGGL((wgrad_glds_kernel<BP, BQ, WP, WQ>), dim3(p.ptiles * p.qtiles, 1, p.splitk), dim3(256), lds,
+                       st, p);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
 extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   CSMRI_CHECK_ARG(d && d->in0 && d->dy && d->dw && d->slab);
   CSMRI_CHECK_ARG(d->dtype == CSMRI_F32 || d->dtype == CSMRI_BF16);
@@ -522,7 +811,13 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   }
   int rc;
 #define WG(DT_, BP_, BQ_, WP_, WQ_) rc = launch_wgrad<DT_, BP_, BQ_, WP_, WQ_>(p, st)
-  if (d->dtype == CSMRI_BF16) {
+  static const char* use_tr = getenv("CSMRI_WGRAD_TR");       // A/B knob: register-staged variant
+  if (d->dtype == CSMRI_BF16 && !use_tr) {
+    if (c.BQ == 128) rc = launch_wgrad_glds<128, 128, 2, 2>(p, st);
+    else if (c.BQ == 64) rc = launch_wgrad_glds<128, 64, 2, 2>(p, st);
+    else if (c.BQ == 32) rc = launch_wgrad_glds<256, 32, 4, 1>(p, st);
+    else rc = launch_wgrad_glds<256, 16, 4, 1>(p, st);
+  } else if (d->dtype == CSMRI_BF16) {
     if (c.BQ == 128) rc = launch_wgrad_tr<128, 128, 2, 2>(p, st);
     else if (c.BQ == 64) rc = launch_wgrad_tr<128, 64, 2, 2>(p, st);
     else if (c.BQ == 32) rc = launch_wgrad_tr<256, 32, 4, 1>(p, st);

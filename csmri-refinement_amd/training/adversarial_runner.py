@@ -298,6 +298,12 @@ class AdversarialRunner(BaseRunner):
       pool.external_plan = True
     st = {'batch': static}
     graphs = []
+    # a cyclic-GC pass in the middle of a capture may destroy graphs/events of an earlier
+    # runner, which the runtime rejects while a stream is capturing: collect now, pause GC
+    import gc
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
     try:
       for seg in (self._seg1, self._seg2, self._seg3, self._seg4):
         g = torch.cuda.CUDAGraph()
@@ -308,6 +314,9 @@ class AdversarialRunner(BaseRunner):
       if pool is not None:
         pool.external_plan = False
       raise
+    finally:
+      if gc_was_enabled:
+        gc.enable()
     self._graph = {'graphs': graphs, 'static': static, 'st': st, 'pool': pool,
                    'bn_delta': [(m, m.batches_tracked - b) for m, b in zip(bns, before)]}
     # the capture pass did not execute anything: optimizer host mirrors advanced, undo
