@@ -498,10 +498,12 @@ def _bn_forward(y, stats, bn, c_real, slope, training, dropmask):
                stream())
     mean = torch.empty(cp, dtype=torch.float32, device=dev)
     invstd = torch.empty(cp, dtype=torch.float32, device=dev)
+    snap = torch.empty(2, cp, dtype=torch.float32, device=dev)
     lib.call('csmri_bn_finalize', stats.data_ptr(), stats.shape[0], cp, c_real, b * h * w, bn.eps,
              bn.momentum, mean.data_ptr(), invstd.data_ptr(), bn.running_mean.data_ptr(),
              bn.running_var.data_ptr(), stream())
   else:
+    snap = None
     mean = torch.zeros(cp, dtype=torch.float32, device=dev)
     invstd = torch.zeros(cp, dtype=torch.float32, device=dev)
     mean[:c_real] = bn.running_mean
@@ -509,8 +511,8 @@ def _bn_forward(y, stats, bn, c_real, slope, training, dropmask):
   z = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
   lib.call('csmri_bn_act', dt_of(y), y.data_ptr(), y.stride(2), z.data_ptr(), z.stride(2), b, h * w, cp,
            c_real, mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-           float(slope), ptr(dropmask), stream())
-  return z, mean, invstd
+           float(slope), ptr(dropmask), ptr(snap), stream())
+  return z, mean, invstd, snap
 
 
 class ConvBnAct(torch.autograd.Function):
@@ -525,18 +527,19 @@ class ConvBnAct(torch.autograd.Function):
     small = x0.shape[0] * layer.out_hw(x0.shape[1], x0.shape[2])[0] * \
         layer.out_hw(x0.shape[1], x0.shape[2])[1] < 32768
     y, stats = conv_forward(layer, x0, x1, False, 1.0, training and not small, None)
-    z, mean, invstd = _bn_forward(y, stats, bn, layer.cout, slope, training, dropmask)
+    z, mean, invstd, snap = _bn_forward(y, stats, bn, layer.cout, slope, training, dropmask)
     ctx.layer, ctx.bn, ctx.slope, ctx.training = layer, bn, slope, training
     ctx.c0 = x0.shape[3]
     ctx.in_hw = (x0.shape[1], x0.shape[2])
-    ctx.save_for_backward(x0, x1, y, z, mean, invstd, dropmask)
+    # z is not kept for the BN backward: the activation sign is recomputed from y and `snap`
+    ctx.save_for_backward(x0, x1, y, snap, mean, invstd, dropmask)
     ctx.w_req = weight.requires_grad and layer.train_weights
     return z
 
   @staticmethod
   def backward(ctx, gz):
     layer, bn = ctx.layer, ctx.bn
-    x0, x1, y, z, mean, invstd, dropmask = ctx.saved_tensors
+    x0, x1, y, snap, mean, invstd, dropmask = ctx.saved_tensors
     if not ctx.training:
       raise RuntimeError('backward through eval-mode BatchNorm is not on the training path')
     gz = as_nhwc(gz)
@@ -547,8 +550,8 @@ class ConvBnAct(torch.autograd.Function):
     rows = lib.raw('csmri_bn_stats_rows')(b * h * w)
     partial = torch.empty(rows + 1, 2, cp, dtype=torch.float32, device=dev)
     lib.call('csmri_bn_bwd_reduce', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
-             z.data_ptr(), z.stride(2), b, h * w, cp, mean.data_ptr(), invstd.data_ptr(),
-             float(ctx.slope), ptr(dropmask), partial.data_ptr(), stream())
+             0, 0, b, h * w, cp, mean.data_ptr(), invstd.data_ptr(),
+             float(ctx.slope), ptr(dropmask), partial.data_ptr(), snap.data_ptr(), stream())
     gy = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
     want_affine = ctx.w_req
     if want_affine:
@@ -557,11 +560,11 @@ class ConvBnAct(torch.autograd.Function):
       if bn.bias.grad is None:
         bn.bias.grad = torch.zeros_like(bn.bias)
     lib.call('csmri_bn_bwd_apply', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
-             z.data_ptr(), z.stride(2), gy.data_ptr(), gy.stride(2), b, h * w, cp, layer.cout,
+             0, 0, gy.data_ptr(), gy.stride(2), b, h * w, cp, layer.cout,
              mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), float(ctx.slope), ptr(dropmask),
              partial.data_ptr(), rows,
              bn.weight.grad.data_ptr() if want_affine else 0,
-             bn.bias.grad.data_ptr() if want_affine else 0, 1, stream())
+             bn.bias.grad.data_ptr() if want_affine else 0, 1, snap.data_ptr(), stream())
     if want_affine:
       conv_wgrad(layer, x0, x1, gy)
     gx0 = gx1 = None

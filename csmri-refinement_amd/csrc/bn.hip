@@ -116,7 +116,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void bn_act_kernel(const void* y, int yps, void* z, int zps, int B, int HW,
                                                      int C, int C_real, const float* mean, const float* invstd,
                                                      const float* gamma, const float* beta, float slope,
-                                                     const float* drop) {
+                                                     const float* drop, float* snap) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
   float sc[4], sh[4];
 #pragma unroll
@@ -124,6 +124,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* y, int yps, voi
     const bool ok = c + q < C_real;
     sc[q] = ok ? invstd[c + q] * gamma[c + q] : 0.f;
     sh[q] = ok ? beta[c + q] - mean[c + q] * sc[q] : 0.f;
+    if (snap && blockIdx.x == 0 && pl == 0) {      // affine parameters as this forward saw them
+      snap[c + q] = ok ? gamma[c + q] : 0.f;
+      snap[C + c + q] = ok ? beta[c + q] : 0.f;
+    }
   }
   const int npix = B * HW;
   for (int p = blockIdx.x * lanes + pl; p < npix; p += gridDim.x * lanes) {
@@ -143,34 +147,40 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* y, int yps, voi
 }
 extern "C" int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride, int B, int HW,
                             int C, int C_real, const float* mean, const float* invstd, const float* gamma,
-                            const float* beta, float slope, const float* dropmask, void* stream) {
+                            const float* beta, float slope, const float* dropmask, float* affine_snap,
+                            void* stream) {
   CSMRI_CHECK_ARG(y && z && mean && invstd && gamma && beta);
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
   const int lanes = 256 / (C / 4);
   int blocks = (B * HW + lanes - 1) / lanes; if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CSMRI_BF16)
-    hipLaunchKernelGGL(bn_act_kernel<CSMRI_BF16>, dim3(blocks), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask);
+    hipLaunchKernelGGL(bn_act_kernel<CSMRI_BF16>, dim3(blocks), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask, affine_snap);
   else
-    hipLaunchKernelGGL(bn_act_kernel<CSMRI_F32>, dim3(blocks), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask);
+    hipLaunchKernelGGL(bn_act_kernel<CSMRI_F32>, dim3(blocks), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask, affine_snap);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
 
 // ---- backward pass 1: partials of dyh = dz*drop*lrelu'(z) and dyh*xhat -------------
-template <int DT>
+// RECOMP: the sign of the activation is recomputed from y with the affine snapshot of the forward
+// (exactly its arithmetic) instead of being read from z -- one tensor pass less
+template <int DT, bool RECOMP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dz, int dzps, const void* y, int yps,
                                                             const void* z, int zps, int npix, int HW, int C,
                                                             const float* mean, const float* invstd, float slope,
-                                                            const float* drop, int rows, float* partial) {
+                                                            const float* drop, int rows, float* partial,
+                                                            const float* snap) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
   const f32x4_t mu = *(const f32x4_t*)(mean + c), is = *(const f32x4_t*)(invstd + c);
+  f32x4_t fsc = is, fbe = is;
+  if (RECOMP) { fsc = is * *(const f32x4_t*)(snap + c); fbe = *(const f32x4_t*)(snap + C + c); }
   const int chunk = (npix + rows - 1) / rows, p0 = blockIdx.x * chunk, p1 = min(npix, p0 + chunk);
   f32x4_t a = (f32x4_t){0, 0, 0, 0}, b = a;
 #pragma unroll 4
   for (int p = p0 + pl; p < p1; p += lanes) {
-    f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c),
-            zz = ld4<DT>(z, (long long)p * zps + c);
+    f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c), zz;
+    if (RECOMP) zz = (yy - mu) * fsc + fbe; else zz = ld4<DT>(z, (long long)p * zps + c);
     f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
     if (drop) dm = *(const f32x4_t*)(drop + (size_t)(p / HW) * C + c);
 #pragma unroll
@@ -185,15 +195,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dz, int 
 extern "C" int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride, const void* y, int y_pix_stride,
                                    const void* z, int z_pix_stride, int B, int HW, int C, const float* mean,
                                    const float* invstd, float slope, const float* dropmask, float* partial,
-                                   void* stream) {
-  CSMRI_CHECK_ARG(dz && y && z && partial);
+                                   const float* affine_snap, void* stream) {
+  CSMRI_CHECK_ARG(dz && y && partial && (z || affine_snap));
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
   const int npix = B * HW, rows = csmri_bn_stats_rows(npix);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CSMRI_BF16)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<CSMRI_BF16>, dim3(rows), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, npix, HW, C, mean, invstd, slope, dropmask, rows, partial);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<CSMRI_F32>, dim3(rows), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, npix, HW, C, mean, invstd, slope, dropmask, rows, partial);
+#define BN_RED(DT_, RC_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT_, RC_>), dim3(rows), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, npix, HW, C, mean, invstd, slope, dropmask, rows, partial, affine_snap)
+  if (dtype == CSMRI_BF16) { if (z) BN_RED(CSMRI_BF16, false); else BN_RED(CSMRI_BF16, true); }
+  else { if (z) BN_RED(CSMRI_F32, false); else BN_RED(CSMRI_F32, true); }
+#undef BN_RED
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
@@ -214,14 +224,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* partial, in
 }
 
 // ---- backward pass 2: dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)) ----
-template <int DT>
+template <int DT, bool RECOMP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dz, int dzps, const void* y, int yps,
                                                            const void* z, int zps, void* dy, int dyps, int npix,
                                                            int HW, int C, int C_real, const float* mean,
                                                            const float* invstd, const float* gamma, float slope,
-                                                           const float* drop, const float* totals, float inv_count) {
+                                                           const float* drop, const float* totals, float inv_count,
+                                                           const float* snap) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
   const f32x4_t mu = *(const f32x4_t*)(mean + c), is = *(const f32x4_t*)(invstd + c);
+  f32x4_t fsc = is, fbe = is;
+  if (RECOMP) { fsc = is * *(const f32x4_t*)(snap + c); fbe = *(const f32x4_t*)(snap + C + c); }
   float gs[4], m1[4], m2[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -230,8 +243,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dz, int d
     m2[q] = totals[C + c + q] * inv_count;
   }
   for (int p = blockIdx.x * lanes + pl; p < npix; p += gridDim.x * lanes) {
-    f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c),
-            zz = ld4<DT>(z, (long long)p * zps + c), o;
+    f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c), zz, o;
+    if (RECOMP) zz = (yy - mu) * fsc + fbe; else zz = ld4<DT>(z, (long long)p * zps + c);
     f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
     if (drop) dm = *(const f32x4_t*)(drop + (size_t)(p / HW) * C + c);
 #pragma unroll
@@ -248,8 +261,9 @@ extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, 
                                   const void* z, int z_pix_stride, void* dy, int dy_pix_stride, int B, int HW,
                                   int C, int C_real, const float* mean, const float* invstd, const float* gamma,
                                   float slope, const float* dropmask, const float* partial, int rows,
-                                  float* dgamma, float* dbeta, int accumulate, void* stream) {
-  CSMRI_CHECK_ARG(dz && y && z && dy && partial && rows > 0);
+                                  float* dgamma, float* dbeta, int accumulate, const float* affine_snap,
+                                  void* stream) {
+  CSMRI_CHECK_ARG(dz && y && (z || affine_snap) && dy && partial && rows > 0);
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (float*)partial, rows, C, C_real, dgamma,
@@ -259,10 +273,10 @@ extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, 
   int blocks = (npix + lanes - 1) / lanes; if (blocks > 4096) blocks = 4096;
   const float* totals = partial + (size_t)rows * 2 * C;
   const float inv = 1.0f / ((float)B * (float)HW);
-  if (dtype == CSMRI_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<CSMRI_BF16>, dim3(blocks), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<CSMRI_F32>, dim3(blocks), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv);
+#define BN_APP(DT_, RC_) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT_, RC_>), dim3(blocks), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv, affine_snap)
+  if (dtype == CSMRI_BF16) { if (z) BN_APP(CSMRI_BF16, false); else BN_APP(CSMRI_BF16, true); }
+  else { if (z) BN_APP(CSMRI_F32, false); else BN_APP(CSMRI_F32, true); }
+#undef BN_APP
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -336,7 +336,7 @@ static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
   p.nsteps = cdiv((long long)d->TH * d->TW * d->Cin, bke);
   CSMRI_CHECK_ARG((long long)p.nsteps * bke <= d->Kp);
   p.steps_per_split = cdiv(p.nsteps, splitk);
-  p.mtiles = cdiv(p.M, c.BM); p.ntiles = cdiv(d->Cout, c.BN);
+  p.mtiles = cdiv(p.M, c.BM); p.ntiles = cdiv(d->Cout, c.BN); p.nt_major = 0;
   return CSMRI_OK;
 }
 

@@ -24,18 +24,20 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int glds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int BN>
-__global__ __launch_bounds__(256, 3) void gconv_glds_kernel(const GParams p) {
+template <int BN, int NST>
+__global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_glds_kernel(const GParams p) {
   constexpr int BM = 128, WM = 2, WN = 2;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
   constexpr int GA = 4, GB = BN / 32;                  // 8-row groups per wave: positions / weights
-  constexpr int TILE_Q = BM * 128;
+  constexpr int TILE_Q = BM * 128, BUF = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int t = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
-  const int mt = t / p.ntiles, nt = t - mt * p.ntiles;
+  // an XCD owns a contiguous run of t: make the operand that is re-read across that run the small one
+  const int mt = p.nt_major ? t % p.mtiles : t / p.ntiles;
+  const int nt = p.nt_major ? t / p.mtiles : t - mt * p.ntiles;
   const int cls = blockIdx.z % p.nclass, ks = blockIdx.z / p.nclass;
   const int m0 = mt * BM, n0 = nt * BN;
   const int s_begin = ks * p.steps_per_split;
@@ -80,19 +82,19 @@ __global__ __launch_bounds__(256, 3) void gconv_glds_kernel(const GParams p) {
   for (int j = 0; j < GB; ++j)
     wrow[j] = p.w + ((size_t)cls * (size_t)p.wcs + (size_t)(n0 + (j * 4 + wid) * 8 + lrow) * p.Kp + chunk * 8) * 2;
 
-  auto issue = [&](int s) {
+  auto issue = [&](int s, char* buf) {
     const bool second = ci >= p.c0;                     // wave-uniform: c0 % 64 == 0
     const char* src = second ? p.in1 + (size_t)(ci - p.c0 + chunk * 8) * 2 : p.in0 + (size_t)(ci + chunk * 8) * 2;
     const size_t ps = (size_t)(second ? p.ps1 : p.ps0) * 2;
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
       const char* g = pix[j] >= 0 ? src + (size_t)pix[j] * ps : g_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(smem + (j * 4 + wid) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(buf + (j * 4 + wid) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < GB; ++j)
       __builtin_amdgcn_global_load_lds((gptr_t)(wrow[j] + (size_t)s * 128),
-                                       (lptr_t)(smem + TILE_Q + (j * 4 + wid) * 1024), 16, 0, 0);
+                                       (lptr_t)(buf + TILE_Q + (j * 4 + wid) * 1024), 16, 0, 0);
     ci += 64;
     if (ci == p.Cin) { ci = 0; if (++tx == p.TW) { tx = 0; ++ty; } compute_pix(); }
   };
@@ -104,26 +106,59 @@ __global__ __launch_bounds__(256, 3) void gconv_glds_kernel(const GParams p) {
     for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int r16 = lane & 15, g = lane >> 4;
 
-  for (int s = s_begin; s < s_end; ++s) {
-    issue(s);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  auto compute = [&](const char* buf) {
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
       bf16x8_t pf[FN], qf[FM];
 #pragma unroll
       for (int i = 0; i < FN; ++i)
-        pf[i] = *(const bf16x8_t*)(smem + TILE_Q + glds_off(wn * WTN + i * 16 + r16, kc * 4 + g));
+        pf[i] = *(const bf16x8_t*)(buf + TILE_Q + glds_off(wn * WTN + i * 16 + r16, kc * 4 + g));
 #pragma unroll
       for (int j = 0; j < FM; ++j)
-        qf[j] = *(const bf16x8_t*)(smem + glds_off(wm * WTM + j * 16 + r16, kc * 4 + g));
+        qf[j] = *(const bf16x8_t*)(buf + glds_off(wm * WTM + j * 16 + r16, kc * 4 + g));
 #pragma unroll
       for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int j = 0; j < FM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+  };
+  if constexpr (NST >= 3) {
+    // ring of NST LDS buffers for grids of at most one workgroup per CU: NST-1 steps of LDS-DMA stay
+    // in flight across the (raw) barrier, retired by counted vmcnt -- latency-bound skinny problems
+    constexpr int L = GA + GB;                     // LDS-DMA instructions per thread per step
+    static_assert(NST == 4, "vmcnt ladder below assumes 2 steps may stay in flight");
+    const int total = s_end - s_begin;
+    int issued = 0;
+    for (; issued < NST - 1 && issued < total; ++issued) issue(s_begin + issued, smem + issued * BUF);
+    for (int i = 0; i < total; ++i) {
+      const int pending = issued - i - 1;
+      if (pending >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+      else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (issued < total) { issue(s_begin + issued, smem + (issued % NST) * BUF); ++issued; }
+      compute(smem + (i % NST) * BUF);
+    }
+  } else if constexpr (NST == 2) {
+    // two LDS buffers: step s+1 streams in while step s is multiplied; one barrier per step
+    if (s_begin < s_end) issue(s_begin, smem);
+    for (int s = s_begin; s < s_end; ++s) {
+      char* cur = smem + ((s - s_begin) & 1) * BUF;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 1 < s_end) issue(s + 1, smem + (((s - s_begin) & 1) ^ 1) * BUF);
+      compute(cur);
+    }
+  } else {
+    for (int s = s_begin; s < s_end; ++s) {
+      issue(s, smem);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(smem);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue (same contract as gconv_kernel) --------------------------------------------
@@ -200,13 +235,28 @@ int gconv_glds_eligible(const csmri_gconv_desc* d) {
   return 1;
 }
 
-template <int BN>
+template <int BN, int NST>
 static int launch_glds(const GParams& p, hipStream_t st) {
-  constexpr int lds = (128 + BN) * 128;
+  constexpr int lds = (128 + BN) * 128 * NST;
   dim3 grid(p.mtiles * p.ntiles, 1, p.nclass * p.splitk);
-  hipLaunchKernelGGL(gconv_glds_kernel<BN>, grid, dim3(256), lds, st, p);
+  static bool attr_set = false;
+  auto kern = gconv_glds_kernel<BN, NST>;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
+}
+
+// LDS stages by grid size: one buffer when >= 3 workgroups per CU overlap each other, two when at
+// most two are resident, a 4-deep ring when the grid is at most one workgroup per CU
+static int glds_stages(long long blocks) {
+  static const char* env = getenv("CSMRI_GLDS_STAGES");     // A/B knob
+  if (env) return atoi(env);
+  return blocks <= 256 ? 4 : (blocks <= 512 ? 2 : 1);
 }
 
 int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
@@ -215,9 +265,17 @@ int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t 
   p.nsteps = d->TH * d->TW * d->Cin / 64;
   p.steps_per_split = cdiv(p.nsteps, p.splitk);
   p.mtiles = cdiv(p.M, 128); p.ntiles = d->Cout / bn;
-  return bn == 128 ? launch_glds<128>(p, st) : launch_glds<64>(p, st);
+  const long long w_elems = (long long)d->Cout * d->TH * d->TW * d->Cin * p.nclass;
+  const long long x_elems = (long long)d->B * d->Hin * d->Win * d->Cin;
+  static const char* ord = getenv("CSMRI_GLDS_ORDER");          // A/B knob: 0 = mt-major, 1 = nt-major
+  p.nt_major = ord ? atoi(ord) : (w_elems > x_elems);
+  const int nst = glds_stages((long long)p.mtiles * p.ntiles * p.nclass * p.splitk);
+  if (bn == 128) return nst == 4 ? launch_glds<128, 4>(p, st) : nst == 2 ? launch_glds<128, 2>(p, st) : launch_glds<128, 1>(p, st);
+  return nst == 4 ? launch_glds<64, 4>(p, st) : nst == 2 ? launch_glds<64, 2>(p, st) : launch_glds<64, 1>(p, st);
 }
 
 void gconv_glds_kernel_name(const csmri_gconv_desc* d, char* buf, int n) {
-  snprintf(buf, n, "gconv_glds_kernel<%d>", gconv_glds_bn(d));
+  const int bn = gconv_glds_bn(d), nclass = d->nclass > 0 ? d->nclass : 1, sk = d->splitk > 0 ? d->splitk : 1;
+  const long long blocks = (long long)cdiv((long long)d->B * d->Ho * d->Wo, 128) * (d->Cout / bn) * nclass * sk;
+  snprintf(buf, n, "gconv_glds_kernel<%d, %d>", bn, glds_stages(blocks));
 }

@@ -12,6 +12,7 @@ struct GParams {
   const float* bias; float slope; const char* gsrc; int gps; float gslope; int gdt;
   float* stats; int splitk; float* slab;
   int M, nsteps, steps_per_split, mtiles, ntiles;
+  int nt_major;   // gconv_glds: tile order that keeps the larger operand shared inside an XCD
 };
 
 // tconv.hip

@@ -264,12 +264,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int dt, const char*
     __syncthreads();
   }
 }
-__global__ void colsum_final_kernel(const float* partial, int rows, int C, int C_real, float* db, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C_real) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int rows, int C, int C_real,
+                                                           float* db, int accumulate) {
+  // 32 channels x 8 row lanes per block; lanes combined in fixed order
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
   double s = 0;
-  for (int r = 0; r < rows; ++r) s += partial[(size_t)r * C + c];
-  db[c] = accumulate ? db[c] + (float)s : (float)s;
+  if (c < C_real)
+    for (int r = rl; r < rows; r += 8) s += partial[(size_t)r * C + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C_real) {
+    for (int l = 1; l < 8; ++l) s += red[l][cl];
+    db[c] = accumulate ? db[c] + (float)s : (float)s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -847,7 +855,7 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows), dim3(256), 0, st, d->dtype, p.dy, p.dyps,
                        (long long)p.M, d->Cout, part);
     CSMRI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout_real + 63) / 64), dim3(64), 0, st, part, rows,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout_real + 31) / 32), dim3(256), 0, st, part, rows,
                        d->Cout, d->Cout_real, d->db, d->accumulate);
     CSMRI_LAUNCH_CHECK();
   }

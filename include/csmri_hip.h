@@ -216,16 +216,20 @@ int csmri_bn_finalize(const float* partial, int rows, int C, int C_real, long lo
                       float eps, float momentum, float* mean, float* invstd,
                       float* running_mean, float* running_var, void* stream);
 /* z = dropmask[b,c] * lrelu( (y-mean)*invstd*gamma + beta ) ; dropmask NULL = 1.
- * eval mode: pass running stats as mean and 1/sqrt(var+eps) as invstd. */
+ * eval mode: pass running stats as mean and 1/sqrt(var+eps) as invstd.
+ * affine_snap (NULL or [2][C] fp32) receives gamma and beta as this forward used them. */
 int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride,
                  int B, int HW, int C, int C_real, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, float slope,
-                 const float* dropmask, void* stream);
-/* backward, pass 1: partial sums of dyh = dz*mask*lrelu'(z) and dyh*xhat */
+                 const float* dropmask, float* affine_snap, void* stream);
+/* backward, pass 1: partial sums of dyh = dz*mask*lrelu'(z) and dyh*xhat.
+ * z may be NULL when affine_snap (from csmri_bn_act) is given: the activation sign is then
+ * recomputed from y with the forward's own arithmetic, saving one tensor read. */
 int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride, const void* y,
                         int y_pix_stride, const void* z, int z_pix_stride, int B, int HW,
                         int C, const float* mean, const float* invstd, float slope,
-                        const float* dropmask, float* partial, void* stream);
+                        const float* dropmask, float* partial, const float* affine_snap,
+                        void* stream);
 /* pass 2: finalize dgamma/dbeta (accumulated into fp32 grads if not NULL) and
  * write dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)) */
 int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, const void* y,
@@ -233,7 +237,8 @@ int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, const void*
                        int dy_pix_stride, int B, int HW, int C, int C_real,
                        const float* mean, const float* invstd, const float* gamma,
                        float slope, const float* dropmask, const float* partial, int rows,
-                       float* dgamma, float* dbeta, int accumulate, void* stream);
+                       float* dgamma, float* dbeta, int accumulate, const float* affine_snap,
+                       void* stream);
 
 /* elementwise activation fwd/bwd with optional bias (used where no BN) */
 int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const void* z, int z_pix_stride,
