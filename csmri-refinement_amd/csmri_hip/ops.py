@@ -174,7 +174,13 @@ class ConvLayer(object):
     epoch = -1 if self.frozen else _EPOCH[0]
     if self._bias_pad is None or self._bias_pad[0] != epoch or \
         self._bias_pad[1].device != self.bias.device:
-      bp = torch.zeros(max(self.cout_p, 128), dtype=torch.float32, device=self.bias.device)
+      group = getattr(self, 'group', None)
+      if group is not None and self._bias_pad is not None and \
+          self._bias_pad[1].device == self.bias.device and group.refresh_biases():
+        return self._bias_pad[1]
+      bp = self._bias_pad[1] if self._bias_pad is not None and \
+          self._bias_pad[1].device == self.bias.device else \
+          torch.zeros(max(self.cout_p, 128), dtype=torch.float32, device=self.bias.device)
       bp[:self.cout].copy_(self.bias.detach())
       self._bias_pad = (epoch, bp)
     return self._bias_pad[1]
@@ -196,6 +202,19 @@ class PackGroup(object):
     for l in self.layers:
       l.group = self
     self._tables = {}
+
+  def refresh_biases(self):
+    """One multi-tensor copy of every member's bias into its zero-padded fp32 buffer."""
+    members = [l for l in self.layers if l.bias is not None and l._bias_pad is not None and
+               l._bias_pad[1].device == l.bias.device]
+    if not members:
+      return False
+    torch._foreach_copy_([l._bias_pad[1][:l.cout] for l in members],
+                         [l.bias.detach() for l in members])
+    epoch = _EPOCH[0]
+    for l in members:
+      l._bias_pad = (epoch, l._bias_pad[1])
+    return True
 
   def repack(self, mode):
     """Re-pack every member that already owns a pack of ``mode`` (buffers exist after the

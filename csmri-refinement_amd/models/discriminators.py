@@ -107,17 +107,38 @@ class CNNDiscriminator(nn.Module):
     self.last_dropout_masks.append(m)
     return m.contiguous()
 
+  def _draw_masks(self, b, device):
+    """All Dropout2d masks of one forward from a single bernoulli draw (3 launches, not 3 per
+    layer); one contiguous [B,C] view per dropout layer, in layer order."""
+    cs = [f for _, bn, drop, f in self._layers if bn is not None and drop]
+    if self.injected_dropout or not cs or any(c % 8 for c in cs):
+      return None
+    p = self.dropout_prob
+    flat = torch.bernoulli(torch.full((b * sum(cs),), 1.0 - p, device=device)) / (1.0 - p)
+    views, off = [], 0
+    for c in cs:
+      views.append(flat[off:off + b * c].view(b, c))
+      off += b * c
+    return views
+
   def forward(self, inp=None, nhwc=None):
     """inp: [B,num_inputs,H,W] fp32 (reference API) -- or ``nhwc=`` an NHWC tensor
     [B,H,W,pad8(num_inputs)] already in the compute dtype (internal fast path)."""
     x = nhwc if nhwc is not None else ops.ToNHWC.apply(inp, self.dtype, ops.pad8(self.num_inputs))
     ensure_pack_group(self)
     feats, chans = [], []
+    drawn = self._draw_masks(x.shape[0], x.device) if self.training else None
     for conv, bn, drop, f in self._layers:
       if bn is None:
         x = ops.ConvAct.apply(x, None, conv.weight, conv.bias, conv.layer, self.slope, None)
       else:
-        mask = self._dropmask(x.shape[0], f, x.device) if (drop and self.training) else None
+        mask = None
+        if drop and self.training:
+          if drawn is not None:
+            mask = drawn.pop(0)
+            self.last_dropout_masks.append(mask)
+          else:
+            mask = self._dropmask(x.shape[0], f, x.device)
         x = ops.ConvBnAct.apply(x, None, conv.weight, bn.weight, bn.bias, conv.layer,
                                 bn.state(self.training), self.slope, self.training, mask)
       feats.append(x)
