@@ -506,22 +506,23 @@ class BNState(object):
     self.eps, self.momentum = eps, momentum
 
 
-def _bn_forward(y, stats, bn, c_real, slope, training, dropmask):
+def _bn_forward(y, stats, bn, c_real, slope, training, dropmask, groups=1):
   b, h, w, cp = y.shape
   dev = y.device
   if training:
     if stats is None:
-      rows = lib.raw('csmri_bn_stats_rows')(b * h * w)
+      rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups)
       stats = torch.empty(rows, 2, cp, dtype=torch.float32, device=dev)
       lib.call('csmri_bn_stats', dt_of(y), y.data_ptr(), y.stride(2), b * h * w, cp, stats.data_ptr(),
-               stream())
-    mean = torch.empty(cp, dtype=torch.float32, device=dev)
-    invstd = torch.empty(cp, dtype=torch.float32, device=dev)
+               groups, stream())
+    mean = torch.empty(groups, cp, dtype=torch.float32, device=dev)
+    invstd = torch.empty(groups, cp, dtype=torch.float32, device=dev)
     snap = torch.empty(2, cp, dtype=torch.float32, device=dev)
     lib.call('csmri_bn_finalize', stats.data_ptr(), stats.shape[0], cp, c_real, b * h * w, bn.eps,
              bn.momentum, mean.data_ptr(), invstd.data_ptr(), bn.running_mean.data_ptr(),
-             bn.running_var.data_ptr(), stream())
+             bn.running_var.data_ptr(), groups, stream())
   else:
+    assert groups == 1
     snap = None
     mean = torch.zeros(cp, dtype=torch.float32, device=dev)
     invstd = torch.zeros(cp, dtype=torch.float32, device=dev)
@@ -530,7 +531,7 @@ def _bn_forward(y, stats, bn, c_real, slope, training, dropmask):
   z = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
   lib.call('csmri_bn_act', dt_of(y), y.data_ptr(), y.stride(2), z.data_ptr(), z.stride(2), b, h * w, cp,
            c_real, mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-           float(slope), ptr(dropmask), ptr(snap), stream())
+           float(slope), ptr(dropmask), ptr(snap), groups, stream())
   return z, mean, invstd, snap
 
 
@@ -539,15 +540,23 @@ class ConvBnAct(torch.autograd.Function):
 
   The conv epilogue emits per-channel partial sums (no extra pass for the batch
   statistics); backward = two-pass BN backward, wgrad, dgrad (+ reflect fold).
-  ``dropmask``: [B,Cp] fp32 in {0, 1/(1-p)} or None."""
+  ``dropmask``: [B,Cp] fp32 in {0, 1/(1-p)} or None.
+  ``groups``: the batch holds that many equal sub-batches normalised independently (as if the
+  module had been called once per sub-batch, in order)."""
 
   @staticmethod
-  def forward(ctx, x0, x1, weight, gamma, beta, layer, bn, slope, training, dropmask):
-    small = x0.shape[0] * layer.out_hw(x0.shape[1], x0.shape[2])[0] * \
-        layer.out_hw(x0.shape[1], x0.shape[2])[1] < 32768
-    y, stats = conv_forward(layer, x0, x1, False, 1.0, training and not small, None)
-    z, mean, invstd, snap = _bn_forward(y, stats, bn, layer.cout, slope, training, dropmask)
-    ctx.layer, ctx.bn, ctx.slope, ctx.training = layer, bn, slope, training
+  def forward(ctx, x0, x1, weight, gamma, beta, layer, bn, slope, training, dropmask, groups=1):
+    ho, wo = layer.out_hw(x0.shape[1], x0.shape[2])
+    m = x0.shape[0] * ho * wo
+    small = m < 32768
+    assert x0.shape[0] % groups == 0
+    # epilogue partial rows cover 64 consecutive positions: a row must not straddle two groups
+    fused_stats = training and not small and (m // groups) % 64 == 0
+    y, stats = conv_forward(layer, x0, x1, False, 1.0, fused_stats, None)
+    if stats is not None and stats.shape[0] % groups:
+      stats = None
+    z, mean, invstd, snap = _bn_forward(y, stats, bn, layer.cout, slope, training, dropmask, groups)
+    ctx.layer, ctx.bn, ctx.slope, ctx.training, ctx.groups = layer, bn, slope, training, groups
     ctx.c0 = x0.shape[3]
     ctx.in_hw = (x0.shape[1], x0.shape[2])
     # z is not kept for the BN backward: the activation sign is recomputed from y and `snap`
@@ -566,11 +575,12 @@ class ConvBnAct(torch.autograd.Function):
       gz = gz.to(layer.dtype)
     b, h, w, cp = y.shape
     dev = y.device
-    rows = lib.raw('csmri_bn_stats_rows')(b * h * w)
-    partial = torch.empty(rows + 1, 2, cp, dtype=torch.float32, device=dev)
+    groups = ctx.groups
+    rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups)
+    partial = torch.empty(rows + groups, 2, cp, dtype=torch.float32, device=dev)
     lib.call('csmri_bn_bwd_reduce', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
              0, 0, b, h * w, cp, mean.data_ptr(), invstd.data_ptr(),
-             float(ctx.slope), ptr(dropmask), partial.data_ptr(), snap.data_ptr(), stream())
+             float(ctx.slope), ptr(dropmask), partial.data_ptr(), snap.data_ptr(), groups, stream())
     gy = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
     want_affine = ctx.w_req
     if want_affine:
@@ -583,7 +593,7 @@ class ConvBnAct(torch.autograd.Function):
              mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), float(ctx.slope), ptr(dropmask),
              partial.data_ptr(), rows,
              bn.weight.grad.data_ptr() if want_affine else 0,
-             bn.bias.grad.data_ptr() if want_affine else 0, 1, snap.data_ptr(), stream())
+             bn.bias.grad.data_ptr() if want_affine else 0, 1, snap.data_ptr(), groups, stream())
     if want_affine:
       conv_wgrad(layer, x0, x1, gy)
     gx0 = gx1 = None
@@ -593,7 +603,7 @@ class ConvBnAct(torch.autograd.Function):
         gx0 = gx
       else:
         gx0, gx1 = gx[..., :ctx.c0], gx[..., ctx.c0:]
-    return gx0, gx1, None, None, None, None, None, None, None, None
+    return gx0, gx1, None, None, None, None, None, None, None, None, None
 
 
 def maxpool2_fwd(x):

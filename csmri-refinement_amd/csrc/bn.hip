@@ -40,7 +40,7 @@ __device__ __forceinline__ void block_sum2(double& a, double& b) {
 
 // write one partial row: reduce the per-thread (a, b) over the pixel lanes of the block
 __device__ __forceinline__ void write_partial_row(f32x4_t a, f32x4_t b, int nv, int lanes, int cv,
-                                                  int pl, int C, float* partial) {
+                                                  int pl, int C, float* row) {
   __shared__ float red[2][256][4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { red[0][threadIdx.x][q] = a[q]; red[1][threadIdx.x][q] = b[q]; }
@@ -49,7 +49,6 @@ __device__ __forceinline__ void write_partial_row(f32x4_t a, f32x4_t b, int nv, 
     for (int l = 1; l < lanes; ++l)
 #pragma unroll
       for (int q = 0; q < 4; ++q) { a[q] += red[0][l * nv + cv][q]; b[q] += red[1][l * nv + cv][q]; }
-    float* row = partial + (size_t)blockIdx.x * 2 * C;
     *(f32x4_t*)(row + cv * 4) = a;
     *(f32x4_t*)(row + C + cv * 4) = b;
   }
@@ -60,53 +59,63 @@ template <int DT>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const void* y, int ps, int npix, int C, int rows,
                                                        float* partial) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv;
+  // npix, rows: per group; blockIdx.y = group (independent statistics per batch group)
+  const int g = blockIdx.y, base = g * npix;
   const int chunk = (npix + rows - 1) / rows, p0 = blockIdx.x * chunk, p1 = min(npix, p0 + chunk);
   f32x4_t a = (f32x4_t){0, 0, 0, 0}, b = a;
 #pragma unroll 4
   for (int p = p0 + pl; p < p1; p += lanes) {
-    f32x4_t v = ld4<DT>(y, (long long)p * ps + cv * 4);
+    f32x4_t v = ld4<DT>(y, (long long)(base + p) * ps + cv * 4);
     a += v; b += v * v;
   }
-  write_partial_row(a, b, nv, lanes, cv, pl, C, partial);
+  write_partial_row(a, b, nv, lanes, cv, pl, C, partial + ((size_t)g * rows + blockIdx.x) * 2 * C);
 }
 extern "C" int csmri_bn_stats(int dtype, const void* y, int pix_stride, int npix, int C, float* partial,
-                              void* stream) {
-  CSMRI_CHECK_ARG(y && partial && npix > 0);
+                              int groups, void* stream) {
+  CSMRI_CHECK_ARG(y && partial && npix > 0 && groups >= 1 && npix % groups == 0);
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
-  const int rows = csmri_bn_stats_rows(npix);
+  const int npg = npix / groups, rows = csmri_bn_stats_rows(npg);
   if (dtype == CSMRI_BF16)
-    hipLaunchKernelGGL(bn_stats_kernel<CSMRI_BF16>, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, pix_stride, npix, C, rows, partial);
+    hipLaunchKernelGGL(bn_stats_kernel<CSMRI_BF16>, dim3(rows, groups), dim3(256), 0, (hipStream_t)stream, y, pix_stride, npg, C, rows, partial);
   else
-    hipLaunchKernelGGL(bn_stats_kernel<CSMRI_F32>, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, pix_stride, npix, C, rows, partial);
+    hipLaunchKernelGGL(bn_stats_kernel<CSMRI_F32>, dim3(rows, groups), dim3(256), 0, (hipStream_t)stream, y, pix_stride, npg, C, rows, partial);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int rows, int C, int C_real,
                                                           double count, float eps, float momentum, float* mean,
-                                                          float* invstd, float* rmean, float* rvar) {
+                                                          float* invstd, float* rmean, float* rvar, int groups) {
   const int c = blockIdx.x;       // one block per channel, fixed-order tree over the rows
-  double s1 = 0, s2 = 0;
-  for (int r = threadIdx.x; r < rows; r += 256) { s1 += partial[(size_t)r * 2 * C + c]; s2 += partial[(size_t)r * 2 * C + C + c]; }
-  block_sum2(s1, s2);
-  if (threadIdx.x != 0) return;
-  const double m = s1 / count;
-  double var = s2 / count - m * m;
-  if (var < 0) var = 0;
-  mean[c] = (float)m;
-  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (rmean && c < C_real) {
-    const double unbiased = count > 1 ? var * count / (count - 1) : var;
-    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+  // rows, count: per group.  Groups are finalized in order, so the running statistics see the
+  // same sequence of momentum updates as `groups` separate forward calls would give.
+  for (int g = 0; g < groups; ++g) {
+    const float* part = partial + (size_t)g * rows * 2 * C;
+    double s1 = 0, s2 = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) { s1 += part[(size_t)r * 2 * C + c]; s2 += part[(size_t)r * 2 * C + C + c]; }
+    __syncthreads();
+    block_sum2(s1, s2);
+    if (threadIdx.x != 0) continue;
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0) var = 0;
+    mean[g * C + c] = (float)m;
+    invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean && c < C_real) {
+      const double unbiased = count > 1 ? var * count / (count - 1) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
   }
 }
 extern "C" int csmri_bn_finalize(const float* partial, int rows, int C, int C_real, long long count, float eps,
                                  float momentum, float* mean, float* invstd, float* running_mean,
-                                 float* running_var, void* stream) {
-  CSMRI_CHECK_ARG(partial && mean && invstd && rows > 0 && count > 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, rows, C, C_real,
-                     (double)count, eps, momentum, mean, invstd, running_mean, running_var);
+                                 float* running_var, int groups, void* stream) {
+  CSMRI_CHECK_ARG(partial && mean && invstd && rows > 0 && count > 0 && groups >= 1 && rows % groups == 0 &&
+                  count % groups == 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, rows / groups, C,
+                     C_real, (double)(count / groups), eps, momentum, mean, invstd, running_mean, running_var,
+                     groups);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
@@ -118,19 +127,23 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* y, int yps, voi
                                                      const float* gamma, const float* beta, float slope,
                                                      const float* drop, float* snap) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
+  // B: images per group; blockIdx.y = group with its own mean/invstd
+  const int grp = blockIdx.y, pbase = grp * B * HW;
+  mean += grp * C; invstd += grp * C;
   float sc[4], sh[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const bool ok = c + q < C_real;
     sc[q] = ok ? invstd[c + q] * gamma[c + q] : 0.f;
     sh[q] = ok ? beta[c + q] - mean[c + q] * sc[q] : 0.f;
-    if (snap && blockIdx.x == 0 && pl == 0) {      // affine parameters as this forward saw them
+    if (snap && blockIdx.x == 0 && grp == 0 && pl == 0) {      // affine parameters as this forward saw them
       snap[c + q] = ok ? gamma[c + q] : 0.f;
       snap[C + c + q] = ok ? beta[c + q] : 0.f;
     }
   }
   const int npix = B * HW;
-  for (int p = blockIdx.x * lanes + pl; p < npix; p += gridDim.x * lanes) {
+  for (int pp = blockIdx.x * lanes + pl; pp < npix; pp += gridDim.x * lanes) {
+    const int p = pbase + pp;
     f32x4_t v = ld4<DT>(y, (long long)p * yps + c), o;
     f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
     if (drop) dm = *(const f32x4_t*)(drop + (size_t)(p / HW) * C + c);
@@ -148,16 +161,17 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* y, int yps, voi
 extern "C" int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride, int B, int HW,
                             int C, int C_real, const float* mean, const float* invstd, const float* gamma,
                             const float* beta, float slope, const float* dropmask, float* affine_snap,
-                            void* stream) {
-  CSMRI_CHECK_ARG(y && z && mean && invstd && gamma && beta);
+                            int groups, void* stream) {
+  CSMRI_CHECK_ARG(y && z && mean && invstd && gamma && beta && groups >= 1 && B % groups == 0);
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
   const int lanes = 256 / (C / 4);
+  B /= groups;                                   // images per group from here on
   int blocks = (B * HW + lanes - 1) / lanes; if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CSMRI_BF16)
-    hipLaunchKernelGGL(bn_act_kernel<CSMRI_BF16>, dim3(blocks), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask, affine_snap);
+    hipLaunchKernelGGL(bn_act_kernel<CSMRI_BF16>, dim3(blocks, groups), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask, affine_snap);
   else
-    hipLaunchKernelGGL(bn_act_kernel<CSMRI_F32>, dim3(blocks), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask, affine_snap);
+    hipLaunchKernelGGL(bn_act_kernel<CSMRI_F32>, dim3(blocks, groups), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask, affine_snap);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
@@ -172,13 +186,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dz, int 
                                                             const float* drop, int rows, float* partial,
                                                             const float* snap) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
-  const f32x4_t mu = *(const f32x4_t*)(mean + c), is = *(const f32x4_t*)(invstd + c);
+  // npix, rows: per group; blockIdx.y = group
+  const int grp = blockIdx.y, pbase = grp * npix;
+  const f32x4_t mu = *(const f32x4_t*)(mean + grp * C + c), is = *(const f32x4_t*)(invstd + grp * C + c);
   f32x4_t fsc = is, fbe = is;
   if (RECOMP) { fsc = is * *(const f32x4_t*)(snap + c); fbe = *(const f32x4_t*)(snap + C + c); }
   const int chunk = (npix + rows - 1) / rows, p0 = blockIdx.x * chunk, p1 = min(npix, p0 + chunk);
   f32x4_t a = (f32x4_t){0, 0, 0, 0}, b = a;
 #pragma unroll 4
-  for (int p = p0 + pl; p < p1; p += lanes) {
+  for (int pp = p0 + pl; pp < p1; pp += lanes) {
+    const int p = pbase + pp;
     f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c), zz;
     if (RECOMP) zz = (yy - mu) * fsc + fbe; else zz = ld4<DT>(z, (long long)p * zps + c);
     f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
@@ -190,17 +207,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dz, int 
       b[q] += d * (yy[q] - mu[q]) * is[q];
     }
   }
-  write_partial_row(a, b, nv, lanes, cv, pl, C, partial);
+  write_partial_row(a, b, nv, lanes, cv, pl, C, partial + ((size_t)grp * rows + blockIdx.x) * 2 * C);
 }
 extern "C" int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride, const void* y, int y_pix_stride,
                                    const void* z, int z_pix_stride, int B, int HW, int C, const float* mean,
                                    const float* invstd, float slope, const float* dropmask, float* partial,
-                                   const float* affine_snap, void* stream) {
-  CSMRI_CHECK_ARG(dz && y && partial && (z || affine_snap));
+                                   const float* affine_snap, int groups, void* stream) {
+  CSMRI_CHECK_ARG(dz && y && partial && (z || affine_snap) && groups >= 1 && B % groups == 0);
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
-  const int npix = B * HW, rows = csmri_bn_stats_rows(npix);
+  const int npix = B / groups * HW, rows = csmri_bn_stats_rows(npix);
   hipStream_t st = (hipStream_t)stream;
-#define BN_RED(DT_, RC_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT_, RC_>), dim3(rows), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, npix, HW, C, mean, invstd, slope, dropmask, rows, partial, affine_snap)
+#define BN_RED(DT_, RC_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT_, RC_>), dim3(rows, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, npix, HW, C, mean, invstd, slope, dropmask, rows, partial, affine_snap)
   if (dtype == CSMRI_BF16) { if (z) BN_RED(CSMRI_BF16, false); else BN_RED(CSMRI_BF16, true); }
   else { if (z) BN_RED(CSMRI_F32, false); else BN_RED(CSMRI_F32, true); }
 #undef BN_RED
@@ -209,17 +226,26 @@ extern "C" int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride,
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* partial, int rows, int C, int C_real,
-                                                              float* dgamma, float* dbeta, int accumulate) {
+                                                              float* dgamma, float* dbeta, int accumulate,
+                                                              int groups) {
   const int c = blockIdx.x;
-  double s1 = 0, s2 = 0;
-  for (int r = threadIdx.x; r < rows; r += 256) { s1 += partial[(size_t)r * 2 * C + c]; s2 += partial[(size_t)r * 2 * C + C + c]; }
-  block_sum2(s1, s2);
-  if (threadIdx.x != 0) return;
-  partial[(size_t)rows * 2 * C + c] = (float)s1;          // totals row (index `rows`)
-  partial[(size_t)rows * 2 * C + C + c] = (float)s2;
-  if (c < C_real) {
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+  // rows: per group; the totals of group g go to row (groups*rows + g)
+  float acc1 = 0.f, acc2 = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const float* part = partial + (size_t)g * rows * 2 * C;
+    double s1 = 0, s2 = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) { s1 += part[(size_t)r * 2 * C + c]; s2 += part[(size_t)r * 2 * C + C + c]; }
+    __syncthreads();
+    block_sum2(s1, s2);
+    if (threadIdx.x != 0) continue;
+    float* tot = partial + ((size_t)groups * rows + g) * 2 * C;
+    tot[c] = (float)s1;
+    tot[C + c] = (float)s2;
+    acc1 += (float)s1; acc2 += (float)s2;
+  }
+  if (threadIdx.x == 0 && c < C_real) {
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + acc1;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + acc2;
   }
 }
 
@@ -232,7 +258,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dz, int d
                                                            const float* drop, const float* totals, float inv_count,
                                                            const float* snap) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
-  const f32x4_t mu = *(const f32x4_t*)(mean + c), is = *(const f32x4_t*)(invstd + c);
+  // npix: per group; blockIdx.y = group
+  const int grp = blockIdx.y, pbase = grp * npix;
+  totals += (size_t)grp * 2 * C;
+  const f32x4_t mu = *(const f32x4_t*)(mean + grp * C + c), is = *(const f32x4_t*)(invstd + grp * C + c);
   f32x4_t fsc = is, fbe = is;
   if (RECOMP) { fsc = is * *(const f32x4_t*)(snap + c); fbe = *(const f32x4_t*)(snap + C + c); }
   float gs[4], m1[4], m2[4];
@@ -242,7 +271,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dz, int d
     m1[q] = totals[c + q] * inv_count;
     m2[q] = totals[C + c + q] * inv_count;
   }
-  for (int p = blockIdx.x * lanes + pl; p < npix; p += gridDim.x * lanes) {
+  for (int pp = blockIdx.x * lanes + pl; pp < npix; pp += gridDim.x * lanes) {
+    const int p = pbase + pp;
     f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c), zz, o;
     if (RECOMP) zz = (yy - mu) * fsc + fbe; else zz = ld4<DT>(z, (long long)p * zps + c);
     f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
@@ -256,24 +286,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dz, int d
     st4<DT>(dy, (long long)p * dyps + c, o);
   }
 }
-// partial must hold (rows + 1) * 2 * C floats (the extra row receives the totals)
+// partial must hold (rows + groups) * 2 * C floats (the extra rows receive the per-group totals)
 extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, const void* y, int y_pix_stride,
                                   const void* z, int z_pix_stride, void* dy, int dy_pix_stride, int B, int HW,
                                   int C, int C_real, const float* mean, const float* invstd, const float* gamma,
                                   float slope, const float* dropmask, const float* partial, int rows,
                                   float* dgamma, float* dbeta, int accumulate, const float* affine_snap,
-                                  void* stream) {
-  CSMRI_CHECK_ARG(dz && y && (z || affine_snap) && dy && partial && rows > 0);
+                                  int groups, void* stream) {
+  CSMRI_CHECK_ARG(dz && y && (z || affine_snap) && dy && partial && rows > 0 && groups >= 1 &&
+                  rows % groups == 0 && B % groups == 0);
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (float*)partial, rows, C, C_real, dgamma,
-                     dbeta, accumulate);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (float*)partial, rows / groups, C, C_real,
+                     dgamma, dbeta, accumulate, groups);
   CSMRI_LAUNCH_CHECK();
+  B /= groups;                                   // images per group from here on
   const int npix = B * HW, lanes = 256 / (C / 4);
   int blocks = (npix + lanes - 1) / lanes; if (blocks > 4096) blocks = 4096;
   const float* totals = partial + (size_t)rows * 2 * C;
   const float inv = 1.0f / ((float)B * (float)HW);
-#define BN_APP(DT_, RC_) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT_, RC_>), dim3(blocks), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv, affine_snap)
+#define BN_APP(DT_, RC_) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT_, RC_>), dim3(blocks, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv, affine_snap)
   if (dtype == CSMRI_BF16) { if (z) BN_APP(CSMRI_BF16, false); else BN_APP(CSMRI_BF16, true); }
   else { if (z) BN_APP(CSMRI_F32, false); else BN_APP(CSMRI_F32, true); }
 #undef BN_APP

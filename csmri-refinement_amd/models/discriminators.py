@@ -95,9 +95,13 @@ class CNNDiscriminator(nn.Module):
       conv.layer.train_weights = enabled
     self.final_conv['0'].layer.train_weights = enabled
 
-  def _dropmask(self, b, c, device):
+  def _dropmask(self, b, c, device, groups=1, layer_idx=0, n_drop=1):
     if self.injected_dropout:
-      m = self.injected_dropout.pop(0).to(device=device, dtype=torch.float32).reshape(b, -1)
+      # injected masks are listed per module call; a grouped call consumes `groups` calls' worth
+      ms = [self.injected_dropout[g * n_drop + layer_idx] for g in range(groups)]
+      m = torch.cat([x.to(device=device, dtype=torch.float32).reshape(b // groups, -1) for x in ms], 0)
+      if layer_idx == n_drop - 1:
+        del self.injected_dropout[:groups * n_drop]
     else:
       p = self.dropout_prob
       m = torch.bernoulli(torch.full((b, c), 1.0 - p, device=device)) / (1.0 - p)
@@ -121,13 +125,18 @@ class CNNDiscriminator(nn.Module):
       off += b * c
     return views
 
-  def forward(self, inp=None, nhwc=None):
+  def forward(self, inp=None, nhwc=None, groups=1):
     """inp: [B,num_inputs,H,W] fp32 (reference API) -- or ``nhwc=`` an NHWC tensor
-    [B,H,W,pad8(num_inputs)] already in the compute dtype (internal fast path)."""
+    [B,H,W,pad8(num_inputs)] already in the compute dtype (internal fast path).
+    ``groups`` > 1: the batch is that many stacked module calls (e.g. [fake; real]); BatchNorm
+    statistics, running-stat updates and dropout draws are per sub-batch, in order, so the
+    outputs equal ``groups`` separate calls -- with half the kernel launches."""
     x = nhwc if nhwc is not None else ops.ToNHWC.apply(inp, self.dtype, ops.pad8(self.num_inputs))
     ensure_pack_group(self)
     feats, chans = [], []
     drawn = self._draw_masks(x.shape[0], x.device) if self.training else None
+    n_drop = sum(1 for _, bn_, d_, _ in self._layers if bn_ is not None and d_)
+    di = 0
     for conv, bn, drop, f in self._layers:
       if bn is None:
         x = ops.ConvAct.apply(x, None, conv.weight, conv.bias, conv.layer, self.slope, None)
@@ -138,9 +147,11 @@ class CNNDiscriminator(nn.Module):
             mask = drawn.pop(0)
             self.last_dropout_masks.append(mask)
           else:
-            mask = self._dropmask(x.shape[0], f, x.device)
+            mask = self._dropmask(x.shape[0], f, x.device, groups, di, n_drop)
+          di += 1
         x = ops.ConvBnAct.apply(x, None, conv.weight, bn.weight, bn.bias, conv.layer,
-                                bn.state(self.training), self.slope, self.training, mask)
+                                bn.state(self.training, groups), self.slope, self.training, mask,
+                                groups)
       feats.append(x)
       chans.append(f)
     fin = self.final_conv['0']

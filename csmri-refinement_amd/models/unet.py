@@ -47,7 +47,7 @@ class _ConvBnAct(object):
 
   def run(self, x0, x1, training):
     return ops.ConvBnAct.apply(x0, x1, self.conv.weight, self.bn.weight, self.bn.bias,
-                               self.conv.layer, self.bn.state(training), self.slope, training, None)
+                               self.conv.layer, self.bn.state(training), self.slope, training, None, 1)
 
 
 class ConvEncodeUnit(nn.Module):

@@ -90,9 +90,9 @@ class BNParams(nn.Module):
     self.kind = 'batchnorm'
     self.batches_tracked = 0
 
-  def state(self, training=False):
+  def state(self, training=False, groups=1):
     if training:
-      self.batches_tracked += 1
+      self.batches_tracked += groups
     return ops.BNState(self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                        self.momentum)
 

@@ -90,6 +90,19 @@ def build_runner(conf, cuda, mode):
                            disc_input_fn=disc_input_fn, val_disc_input_fn=val_disc_input_fn)
 
 
+def _split_disc_output(out, b):
+  """Halves of a discriminator output computed on a stacked [first; second] batch."""
+  first, second = {}, {}
+  for k, v in out.items():
+    if torch.is_tensor(v):
+      first[k], second[k] = v[:b], v[b:]
+    elif isinstance(v, list) and v and torch.is_tensor(v[0]):
+      first[k], second[k] = [t[:b] for t in v], [t[b:] for t in v]
+    else:
+      first[k] = second[k] = v
+  return first, second
+
+
 class AdversarialRunner(BaseRunner):
   def __init__(self, gen_model, disc_model=None, gen_optimizer=None, disc_optimizer=None,
                gen_lr_scheduler=None, disc_lr_scheduler=None, gen_adv_criteria=None,
@@ -126,6 +139,7 @@ class AdversarialRunner(BaseRunner):
     self._last_metrics = None
     self.overlap_streams = False
     self._side_stream = None
+    self.batch_disc_passes = True         # D(fake) and D(real) of the D phase as one grouped pass
 
   # -- reference surface -------------------------------------------------------
   def get_named_outputs(self, data):
@@ -195,10 +209,17 @@ class AdversarialRunner(BaseRunner):
     st['gen_inp0'] = gen_inp[0]
     out_gen = self.gen(*gen_inp)
     st['out_gen'] = out_gen
-    out_fake_d = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False,
-                                                   detach=True, pool_decisions=self.pool_decisions))
-    out_real = self.disc(nhwc=self.disc_input_fn(batch['target'], gen_inp[0], out_gen,
-                                                 is_real_input=True, detach=True))
+    in_fake = self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False, detach=True,
+                                 pool_decisions=self.pool_decisions)
+    in_real = self.disc_input_fn(batch['target'], gen_inp[0], out_gen, is_real_input=True, detach=True)
+    if self.batch_disc_passes:
+      # the two passes of reference :333-341 as ONE pass over [fake; real] with per-half BatchNorm
+      # statistics and dropout draws (identical results, half the launches on D's small maps)
+      out_fake_d, out_real = _split_disc_output(
+          self.disc(nhwc=torch.cat([in_fake, in_real], 0), groups=2), in_fake.shape[0])
+    else:
+      out_fake_d = self.disc(nhwc=in_fake)
+      out_real = self.disc(nhwc=in_real)
     st['out_disc_real'] = out_real
     names, vals, disc_losses = [], [], []
     for name, criterion in self.disc_adv_criteria.items():

@@ -204,24 +204,31 @@ int csmri_mask_to_u8(const float* mask_nchw, int B, int H, int W, uint8_t* dst, 
  * BatchNorm2d (training) + LeakyReLU + Dropout2d mask, NHWC.
  * Replaces nn.BatchNorm2d / nn.LeakyReLU / nn.Dropout2d as sequenced in
  * models/unet.py:48-58,100-118 and models/discriminators.py:129-155.
+ *
+ * `groups` (>= 1): the batch is `groups` equal, consecutive sub-batches that are
+ * normalised independently -- the result equals `groups` separate module calls
+ * (own batch statistics each; running statistics updated once per group, in order),
+ * which lets the two discriminator passes of training/adversarial_runner.py:333-341
+ * (fake, then real) run as one launch sequence.  mean/invstd are [groups][C]; partial
+ * rows are group-major ([groups][rows/groups][2][C]).
  * ---------------------------------------------------------------------- */
 /* per-channel partial sums of a tensor: partial [rows][2][C] (rows returned by
  * csmri_bn_stats_rows) -- used when the conv epilogue did not produce them */
 int csmri_bn_stats_rows(int npix);
 int csmri_bn_stats(int dtype, const void* y, int pix_stride, int npix, int C,
-                   float* partial, void* stream);
+                   float* partial, int groups, void* stream);   /* rows = groups*stats_rows(npix/groups) */
 /* reduce partials -> mean, invstd (saved for backward); update running stats
  * (momentum, unbiased var) when running_mean != NULL.  C_real channels. */
 int csmri_bn_finalize(const float* partial, int rows, int C, int C_real, long long count,
                       float eps, float momentum, float* mean, float* invstd,
-                      float* running_mean, float* running_var, void* stream);
+                      float* running_mean, float* running_var, int groups, void* stream);
 /* z = dropmask[b,c] * lrelu( (y-mean)*invstd*gamma + beta ) ; dropmask NULL = 1.
  * eval mode: pass running stats as mean and 1/sqrt(var+eps) as invstd.
  * affine_snap (NULL or [2][C] fp32) receives gamma and beta as this forward used them. */
 int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride,
                  int B, int HW, int C, int C_real, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, float slope,
-                 const float* dropmask, float* affine_snap, void* stream);
+                 const float* dropmask, float* affine_snap, int groups, void* stream);
 /* backward, pass 1: partial sums of dyh = dz*mask*lrelu'(z) and dyh*xhat.
  * z may be NULL when affine_snap (from csmri_bn_act) is given: the activation sign is then
  * recomputed from y with the forward's own arithmetic, saving one tensor read. */
@@ -229,16 +236,17 @@ int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride, const void
                         int y_pix_stride, const void* z, int z_pix_stride, int B, int HW,
                         int C, const float* mean, const float* invstd, float slope,
                         const float* dropmask, float* partial, const float* affine_snap,
-                        void* stream);
+                        int groups, void* stream);
 /* pass 2: finalize dgamma/dbeta (accumulated into fp32 grads if not NULL) and
- * write dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)) */
+ * write dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)).
+ * partial: the rows of pass 1 plus `groups` extra rows that receive the totals. */
 int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, const void* y,
                        int y_pix_stride, const void* z, int z_pix_stride, void* dy,
                        int dy_pix_stride, int B, int HW, int C, int C_real,
                        const float* mean, const float* invstd, const float* gamma,
                        float slope, const float* dropmask, const float* partial, int rows,
                        float* dgamma, float* dbeta, int accumulate, const float* affine_snap,
-                       void* stream);
+                       int groups, void* stream);
 
 /* elementwise activation fwd/bwd with optional bias (used where no BN) */
 int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const void* z, int z_pix_stride,

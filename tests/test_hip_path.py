@@ -286,9 +286,10 @@ def test_disc_phase_grads_identical_inputs_fp32(env):
   seen, grads = [], {}
   disc_fwd = runner.disc.forward
 
-  def fwd(inp=None, nhwc=None):
-    seen.append(nhwc.detach().float().cpu()[..., :1].permute(0, 3, 1, 2).contiguous())
-    return disc_fwd(inp, nhwc)
+  def fwd(inp=None, nhwc=None, groups=1):
+    x = nhwc.detach().float().cpu()[..., :1].permute(0, 3, 1, 2).contiguous()
+    seen.extend(x.chunk(groups, 0))       # the D phase runs [fake; real] as one grouped pass
+    return disc_fwd(inp, nhwc, groups)
   runner.disc.forward = fwd
   apply_orig = runner.disc_optimizer.apply
   names = {id(p): n for n, p in runner.disc.named_parameters()}
@@ -440,3 +441,51 @@ def test_graph_mode_with_dropout_and_pool_runs(env):
   assert 5.0 < metrics['gen_psnr'].value < 60.0
   pool = runner.disc_input_fn.image_pool
   assert pool.count == 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,size,small', [('fp32', 128, True), ('bf16', 256, False)])
+def test_grouped_disc_pass_equals_two_passes(env, dtype, size, small):
+  """CNNDiscriminator(groups=2) on [a; b] == the module called on a, then on b: outputs,
+  parameter gradients, BatchNorm running statistics and num_batches_tracked (reference
+  training/adversarial_runner.py:333-341 makes the two calls)."""
+  import copy
+  Configuration, set_dtype = env
+  from training import build_runner
+  set_dtype(dtype)
+  runner = build_runner(gan_conf(Configuration, dtype, small=small), 'adversarial', '0', 'train')
+  d1 = runner.disc
+  d2 = copy.deepcopy(d1)
+  d1.train(); d2.train()
+  g = torch.Generator().manual_seed(5)
+  cdt = torch.float32 if dtype == 'fp32' else torch.bfloat16
+  xa = torch.zeros(2, size, size, 8, dtype=cdt).cuda()
+  xb = torch.zeros(2, size, size, 8, dtype=cdt).cuda()
+  xa[..., 0] = torch.rand(2, size, size, generator=g).cuda().to(cdt)
+  xb[..., 0] = torch.rand(2, size, size, generator=g).cuda().to(cdt)
+  chans = [f for _, bn, drop, f in d1._layers if bn is not None and drop]
+  masks = [(torch.rand(2, c, generator=g) < 0.5).float() * 2.0 for _ in range(2) for c in chans]
+  d1.injected_dropout = [m.clone() for m in masks]
+  oa, ob = d1(nhwc=xa), d1(nhwc=xb)
+  (oa['logits'].sum() - 2.0 * ob['logits'].sum()).backward()
+  d2.injected_dropout = [m.clone() for m in masks]
+  o = d2(nhwc=torch.cat([xa, xb], 0), groups=2)
+  (o['logits'][:2].sum() - 2.0 * o['logits'][2:].sum()).backward()
+  tol = 2e-5 if dtype == 'fp32' else 2e-2
+
+  def close(a, b, what):
+    err = float((a.float() - b.float()).norm() / (b.float().norm() + 1e-20))
+    assert err < tol, (what, err)
+  close(o['logits'][:2], oa['logits'], 'logits a')
+  close(o['logits'][2:], ob['logits'], 'logits b')
+  for fa, fb, fo in zip(oa['features'], ob['features'], o['features']):
+    close(fo[:2], fa, 'feature a')
+    close(fo[2:], fb, 'feature b')
+  for (n, p1), (_, p2) in zip(d1.named_parameters(), d2.named_parameters()):
+    close(p2.grad, p1.grad, 'grad ' + n)
+  s1, s2 = d1.state_dict(), d2.state_dict()
+  for k in s1:
+    if 'running' in k:
+      close(s2[k], s1[k], k)
+    if 'num_batches_tracked' in k:
+      assert int(s1[k]) == int(s2[k]) == 2, k
