@@ -441,11 +441,46 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
   d.accumulate = int(accumulate)
   d.splitk = lib.raw('csmri_wgrad_suggest_splitk')(C.byref(d))
   nbytes = lib.raw('csmri_wgrad_slab_bytes')(C.byref(d))
-  slab = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)
-  d.slab = slab.data_ptr()
-  with _Timed(_tile_label('wgrad', d.dtype, d.Cout),
-              2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw):
-    lib.call('csmri_wgrad', C.byref(d), stream())
+
+  def launch():
+    slab = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)
+    d.slab = slab.data_ptr()
+    with _Timed(_tile_label('wgrad', d.dtype, d.Cout),
+                2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw):
+      lib.call('csmri_wgrad', C.byref(d), stream())
+
+  side = _WGRAD['stream']
+  if side is None:
+    launch()
+    return
+  # weight gradients are only consumed by the optimizer: run them on a side stream next to the
+  # data-gradient chain (they are mutually ordered there, so the accumulation stays race-free)
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    launch()
+  for t in (x0, x1, gy):
+    if t is not None:
+      t.record_stream(side)
+  _WGRAD['pending'] = True
+
+
+_WGRAD = {'stream': None, 'pending': False}
+
+
+def enable_wgrad_stream(on):
+  """Route csmri_wgrad launches to a dedicated side stream (join with join_wgrad_stream)."""
+  if on and _WGRAD['stream'] is None:
+    _WGRAD['stream'] = torch.cuda.Stream()
+  elif not on:
+    join_wgrad_stream()
+    _WGRAD['stream'] = None
+
+
+def join_wgrad_stream():
+  """Make the current stream wait for every weight-gradient launch issued so far."""
+  if _WGRAD['pending']:
+    torch.cuda.current_stream().wait_stream(_WGRAD['stream'])
+    _WGRAD['pending'] = False
 
 
 def act_bwd(gz, z, slope):

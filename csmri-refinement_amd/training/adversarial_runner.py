@@ -29,6 +29,7 @@ from models.criteria import get_criterion
 from training.adversarial_training import get_discriminator_input_fn
 from training.base_runner import BaseRunner
 from training.optimizers import get_optimizer
+from csmri_hip import ops
 from training import distributed as dist_utils
 from utils.checkpoints import initialize_pretrained_model
 from utils.config import Configuration
@@ -188,6 +189,7 @@ class AdversarialRunner(BaseRunner):
     total = self._weighted_total(losses, weights)
     optimizer.zero_grad()
     total.backward()
+    ops.join_wgrad_stream()
     optimizer.start_allreduce()
     optimizer.step()
     return total.detach()
@@ -229,7 +231,9 @@ class AdversarialRunner(BaseRunner):
       vals.append(loss.detach())
     total_disc = self._weighted_total(disc_losses, self.disc_loss_weights)
     self.disc_optimizer.zero_grad()
+    ops.enable_wgrad_stream(self.overlap_streams)
     total_disc.backward()
+    ops.join_wgrad_stream()
     names.append('disc_loss')
     vals.append(total_disc.detach())
     st['names'], st['vals'] = names, vals
@@ -272,7 +276,9 @@ class AdversarialRunner(BaseRunner):
   def _seg3(self, st):
     self.disc_optimizer.apply()
     self.gen_optimizer.zero_grad()
+    ops.enable_wgrad_stream(self.overlap_streams)
     st['total_gen'].backward()
+    ops.join_wgrad_stream()
     st['names'].append('gen_loss')
     st['vals'].append(st['total_gen'].detach())
 
