@@ -18,16 +18,25 @@
 #include "mma_core.h"
 #include "gconv_params.h"
 
+__device__ __attribute__((aligned(16))) char t_zero_page[16];
+typedef __attribute__((address_space(1))) const void* tgptr_t;
+typedef __attribute__((address_space(3))) void* tlptr_t;
+
+// LDS image of the input patch: one PLANE per 16-byte channel chunk, pixels 16 bytes apart inside a
+// plane ([chunk][pixel][8 ch]).  A ds_read_b128 fragment read (16 consecutive pixels per 16-lane
+// k-group) is then conflict-free for EVERY tap shift (planes are a multiple of 256 B apart, and a
+// lane group's two k-groups cover complementary pixels of one 16-pixel run), and a tap shift is a
+// plain byte offset -- no per-tap swizzle arithmetic.  Patch and weights are staged by LDS-DMA.
 template <int CIN, int FN, bool STREAM>
 __global__ __launch_bounds__(256) void tconv_kernel(const GParams p) {
-  constexpr int RB = CIN * 2;                       // bytes per patch pixel
-  constexpr int VPP = RB / 16;                      // 16-byte vectors per pixel
+  constexpr int VPP = CIN / 8;                      // planes (16-byte chunks per pixel)
   constexpr int TPC = CIN >= 32 ? 1 : 32 / CIN;     // taps per K chunk
   constexpr int KCH = CIN >= 32 ? CIN / 32 : 1;     // K chunks per tap
   constexpr int BN = FN * 16;
+  constexpr int WT = BN * 64;                       // bytes of one chunk's weight tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
   const int tiles_x = (p.Wo + 15) >> 4, tiles_y = (p.Ho + 15) >> 4;
   int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -37,53 +46,59 @@ __global__ __launch_bounds__(256) void tconv_kernel(const GParams p) {
   const int y0 = tyi * 16, x0 = txi * 16, n0 = blockIdx.y * BN;
   const int TPW = 16 + p.TW - 1, TPH = 16 + p.TH - 1;
   const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
+  const int npix = TPH * TPW, NG = (npix + 63) >> 6, PLANE = NG << 10;
+  char* wl = smem + p.nsteps;                       // weight tiles follow the patch planes
 
-  // ---- patch load: global -> LDS, once -----------------------------------------------
-  // batches of LB independent 16-byte loads per thread are issued before any LDS write so
-  // that a workgroup pays one memory round trip per batch, not one per vector
-  constexpr int LB = 6;
-  const int rowvecs = TPW * VPP, nvec = TPH * rowvecs;
-  for (int base = tid; base < nvec; base += 256 * LB) {
-    u32x4_t vals[LB];
-    int offs[LB];
+  // ---- patch: global -> LDS by LDS-DMA, once ----------------------------------------------
+  {
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)TPW + 1u;     // P / TPW for P < 2^16
+    for (int grp = 0; grp < NG; ++grp) {
+      // instruction (grp, plane) belongs to wave (grp*VPP + plane) & 3
+      if (VPP < 4) { const int first = (grp * VPP) & 3; if (wv < first || wv >= first + VPP) continue; }
+      const int P = (grp << 6) + lane;
+      const int py = (int)__umulhi((unsigned)P, magic), px = P - py * TPW;
+      int u = y0 + p.dy0 + py, w = x0 + p.dx0 + px;
+      if (p.border == CSMRI_BORDER_REFLECT) {
+        u = u < 0 ? -u : u; u = min(u, 2 * (Hv - 1) - u);
+        w = w < 0 ? -w : w; w = min(w, 2 * (Wv - 1) - w);
+      }
+      const bool ok = (P < npix) & ((unsigned)u < (unsigned)Hv) & ((unsigned)w < (unsigned)Wv);
+      if (p.ups) { u >>= 1; w >>= 1; }
+      const size_t pix = ((size_t)b * p.Hin + u) * p.Win + w;
+      const char* s0 = p.in0 + pix * p.ps0 * 2;
+      const char* s1 = p.in1 + pix * p.ps1 * 2;
 #pragma unroll
-    for (int j = 0; j < LB; ++j) {
-      const int v = base + j * 256;
-      vals[j] = (u32x4_t){0u, 0u, 0u, 0u};
-      offs[j] = -1;
-      if (v < nvec) {
-        const int py = v / rowvecs, rem = v - py * rowvecs;
-        const int px = rem / VPP, cv = rem - px * VPP;
-        int u = y0 + p.dy0 + py, w = x0 + p.dx0 + px;
-        if (p.border == CSMRI_BORDER_REFLECT) { u = reflect_idx(u, Hv); w = reflect_idx(w, Wv); }
-        const bool ok = (unsigned)u < (unsigned)Hv && (unsigned)w < (unsigned)Wv;
-        if (p.ups) { u >>= 1; w >>= 1; }
-        const int P = py * TPW + px;
-        offs[j] = P * RB + ((RB == 128 ? (cv ^ (P & 3)) : cv) << 4);
-        if (ok) {
-          const size_t pix = ((size_t)b * p.Hin + u) * p.Win + w;
-          const int c = cv * 8;
-          const char* src = (c < p.c0) ? p.in0 + (pix * p.ps0 + c) * 2 : p.in1 + (pix * p.ps1 + (c - p.c0)) * 2;
-          vals[j] = *(const u32x4_t*)src;
-        }
+      for (int pl = 0; pl < VPP; ++pl) {
+        if (((grp * VPP + pl) & 3) != wv) continue;              // wave-uniform round robin
+        const int c = pl * 8;
+        const char* src = c < p.c0 ? s0 + c * 2 : s1 + (c - p.c0) * 2;
+        src = ok ? src : t_zero_page;
+        __builtin_amdgcn_global_load_lds((tgptr_t)src, (tlptr_t)(smem + pl * PLANE + (grp << 10)), 16, 0, 0);
       }
     }
+  }
+  // ---- weights: [BN][64 B] tiles per 32-wide K chunk (mma_core swizzle applied at the source) --
+  const char* wsrc = p.w + (size_t)n0 * p.Kp * 2;
+  const int wrow_l = lane >> 2, wslot = lane & 3;
+  auto wload = [&](int chunk, char* dst) {            // one chunk: BN/16 instructions, round robin
 #pragma unroll
-    for (int j = 0; j < LB; ++j)
-      if (offs[j] >= 0) *(u32x4_t*)(smem + offs[j]) = vals[j];
-  }
-  {
-    // weights: all chunks (WHOLE) or stage 0 = first 2 chunks (STREAM) -> LDS tiles
-    const int nq_all = p.TH * (p.TW / TPC) * KCH;
-    const int nload = STREAM ? min(2, nq_all) : nq_all;
-    const char* wsrc0 = p.w + (size_t)n0 * p.Kp * 2;
-    char* wl0 = smem + p.nsteps;
-    for (int v = tid; v < nload * BN * 4; v += 256) {
-      const int c = v / (BN * 4), row = (v >> 2) % BN, sl = v & 3;
-      *(u32x4_t*)(wl0 + c * (BN * 64) + tile_off(row, sl)) =
-          *(const u32x4_t*)(wsrc0 + ((size_t)row * p.Kp + (size_t)c * 32 + sl * 8) * 2);
+    for (int i = 0; i < FN; ++i) {
+      if (((chunk * FN + i) & 3) != wv) continue;
+      const int row = i * 16 + wrow_l;
+      const int kc = wslot ^ tile_swz(row);
+      __builtin_amdgcn_global_load_lds((tgptr_t)(wsrc + ((size_t)row * p.Kp + (size_t)chunk * 32 + kc * 8) * 2),
+                                       (tlptr_t)(dst + i * 1024), 16, 0, 0);
     }
+  };
+  const int groups_x = p.TW / TPC;
+  const int nq = p.TH * groups_x * KCH;
+  if (!STREAM) {
+    for (int q = 0; q < nq; ++q) wload(q, wl + q * WT);
+  } else {
+    wload(0, wl);
+    if (nq > 1) wload(1, wl + WT);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // ---- K loop out of LDS -----------------------------------------------------------------
@@ -92,33 +107,21 @@ __global__ __launch_bounds__(256) void tconv_kernel(const GParams p) {
   for (int i = 0; i < FN; ++i)
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  int pbase[4];
+  // lane constants: fragment f = output row 4*wv+f, pixel r16; k-group g -> (plane, pixel shift)
+  const int gplane = CIN >= 32 ? g : (g % VPP), gshift = CIN >= 32 ? 0 : g / VPP;
+  int abase[4], wbase[FN];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) pbase[f] = (4 * wv + f) * TPW + r16;
-  const int groups_x = p.TW / TPC;
-  const int nq = p.TH * groups_x * KCH;
-  const char* wrow = p.w + ((size_t)(n0 + r16) * p.Kp + g * 8) * 2;
-  const size_t wfn = (size_t)16 * p.Kp * 2;
-  // Weights go through LDS so that the four waves share one fetch (an ablation showed the
-  // per-wave L2 re-fetch of the weight fragments, not MFMA or the patch load, bounding the
-  // loop).  Layout: per 32-wide K chunk a [BN][64 B] tile with the mma_core swizzle.
-  //   WHOLE : all nq chunks are resident (loaded with the patch, no further barrier)
-  //   STREAM: SC chunks per stage, double buffered, one barrier per stage
-  (void)wrow; (void)wfn;
+  for (int f = 0; f < 4; ++f) abase[f] = gplane * PLANE + (((4 * wv + f) * TPW + r16 + gshift) << 4);
+#pragma unroll
+  for (int i = 0; i < FN; ++i) wbase[i] = tile_off(i * 16 + r16, g);
   int ty = 0, txg = 0, cb = 0;
-  auto compute = [&](const char* wt) {      // wt: this chunk's [BN][64 B] weight tile
-    const int poff = ty * TPW + txg * TPC;
+  auto compute = [&](const char* wt) {      // wt: this chunk's [BN][64 B] weight tile (wave-uniform)
+    const int soff = ((ty * TPW + txg * TPC) << 4) + (CIN >= 32 ? cb * 4 * PLANE : 0);
     u32x4_t a[4], bw[FN];
 #pragma unroll
-    for (int i = 0; i < FN; ++i) bw[i] = *(const u32x4_t*)(wt + tile_off(i * 16 + r16, g));
+    for (int i = 0; i < FN; ++i) bw[i] = *(const u32x4_t*)(wt + wbase[i]);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int P = pbase[f] + poff;
-      int off;
-      if (RB == 128) off = P * RB + (((cb * 4 + g) ^ (P & 3)) << 4);
-      else off = P * RB + cb * 64 + g * 16;          // CIN<32: spans TPC adjacent pixels
-      a[f] = *(const u32x4_t*)(smem + off);
-    }
+    for (int f = 0; f < 4; ++f) a[f] = *(const u32x4_t*)(smem + abase[f] + soff);
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -127,44 +130,21 @@ __global__ __launch_bounds__(256) void tconv_kernel(const GParams p) {
                                                             __builtin_bit_cast(bf16x8_t, a[f]), acc[i][f], 0, 0, 0);
     if (++cb == KCH) { cb = 0; if (++txg == groups_x) { txg = 0; ++ty; } }
   };
-  char* wl = smem + p.nsteps;                  // weight region starts after the patch (host: 16-B aligned)
-  constexpr int WT = BN * 64;                  // bytes of one chunk's weight tile
-  const char* wsrc = p.w + (size_t)n0 * p.Kp * 2;
   if (!STREAM) {
-    // (the loads were issued together with the patch, see wload_whole above the barrier)
     for (int q = 0; q < nq; ++q) compute(wl + q * WT);
   } else {
-    constexpr int SC = 2;                      // chunks per stage
-    constexpr int SV = SC * BN * 4;            // 16-byte vectors per stage
-    constexpr int SI = (SV + 255) / 256;
-    const int nst = (nq + SC - 1) / SC;
-    u32x4_t wr[SI];
-    auto sload = [&](int st) {
-#pragma unroll
-      for (int it = 0; it < SI; ++it) {
-        const int v = tid + it * 256;
-        const int c = v / (BN * 4), row = (v >> 2) % BN, sl = v & 3;
-        wr[it] = (u32x4_t){0u, 0u, 0u, 0u};
-        if (v < SV && st * SC + c < nq)
-          wr[it] = *(const u32x4_t*)(wsrc + ((size_t)row * p.Kp + (size_t)(st * SC + c) * 32 + sl * 8) * 2);
-      }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-      for (int it = 0; it < SI; ++it) {
-        const int v = tid + it * 256;
-        const int c = v / (BN * 4), row = (v >> 2) % BN, sl = v & 3;
-        if (v < SV) *(u32x4_t*)(wl + (buf * SC + c) * WT + tile_off(row, sl)) = wr[it];
-      }
-    };
-    // stage 0 was stored before the first barrier (see below); pipeline the rest
+    // 2 chunks per stage, two stage buffers: stage st+1 streams in under the MFMAs of stage st
+    const int nst = (nq + 1) >> 1;
     for (int st = 0; st < nst; ++st) {
-      const bool more = st + 1 < nst;
-      if (more) sload(st + 1);
-#pragma unroll
-      for (int c = 0; c < SC; ++c)
-        if (st * SC + c < nq) compute(wl + ((st & 1) * SC + c) * WT);
-      if (more) sstore((st + 1) & 1);
+      char* cur = wl + (st & 1) * 2 * WT;
+      char* nxt = wl + ((st & 1) ^ 1) * 2 * WT;
+      if (st + 1 < nst) {
+        wload(2 * st + 2, nxt);
+        if (2 * st + 3 < nq) wload(2 * st + 3, nxt + WT);
+      }
+      compute(cur);
+      if (2 * st + 1 < nq) compute(cur + WT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
   }
@@ -232,7 +212,7 @@ int tconv_eligible(const csmri_gconv_desc* d) {
   if (d->TW % tpc) return 0;
   if (d->out_sy != 1 || d->out_sx != 1) return 0;
   if ((long long)d->Ho * d->Wo < 64 * 64) return 0;            // small maps: generic / split-K path
-  const size_t lds = (size_t)(16 + d->TH - 1) * (16 + d->TW - 1) * d->Cin * 2;
+  const size_t lds = (size_t)(d->Cin / 8) * (((16 + d->TH - 1) * (16 + d->TW - 1) + 63) / 64) * 1024;
   if (lds > 96 * 1024) return 0;
   return 1;
 }
@@ -244,7 +224,8 @@ int tconv_stats_rows(const csmri_gconv_desc* d) {
 template <int CIN, int FN, bool STREAM>
 static int launch_tconv(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
   GParams p = p0;
-  const int patch = ((16 + d->TH - 1) * (16 + d->TW - 1) * CIN * 2 + 15) & ~15;
+  const int npix_ = (16 + d->TH - 1) * (16 + d->TW - 1);
+  const int patch = (CIN / 8) * ((npix_ + 63) / 64) * 1024;      // planes of 64-pixel groups
   const int tpc = CIN >= 32 ? 1 : 32 / CIN, kch = CIN >= 32 ? CIN / 32 : 1;
   const int nq = d->TH * (d->TW / tpc) * kch;
   const int lds = patch + (STREAM ? 2 * 2 : nq) * FN * 16 * 64;
@@ -268,7 +249,7 @@ int tconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st) {
   // whole filter resident in LDS when patch + weights stay under 64 KiB (>= 2 workgroups/CU)
   const int tpc_ = d->Cin >= 32 ? 1 : 32 / d->Cin, kch_ = d->Cin >= 32 ? d->Cin / 32 : 1;
   const int nq_ = d->TH * (d->TW / tpc_) * kch_;
-  const int patch_ = (16 + d->TH - 1) * (16 + d->TW - 1) * d->Cin * 2;
+  const int patch_ = (d->Cin / 8) * (((16 + d->TH - 1) * (16 + d->TW - 1) + 63) / 64) * 1024;
   const bool stream = patch_ + nq_ * fn * 16 * 64 > 64 * 1024;
 #define TC(C_, F_) do { if (stream) return launch_tconv<C_, F_, true>(p, d, st); return launch_tconv<C_, F_, false>(p, d, st); } while (0)
 #define TCC(C_) do { if (fn == 4) TC(C_, 4); else if (fn == 2) TC(C_, 2); else TC(C_, 1); } while (0)
@@ -286,7 +267,7 @@ void tconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n) {
   const int fn = tconv_fn(d);
   const int tpc_ = d->Cin >= 32 ? 1 : 32 / d->Cin, kch_ = d->Cin >= 32 ? d->Cin / 32 : 1;
   const int nq_ = d->TH * (d->TW / tpc_) * kch_;
-  const int patch_ = (16 + d->TH - 1) * (16 + d->TW - 1) * d->Cin * 2;
+  const int patch_ = (d->Cin / 8) * (((16 + d->TH - 1) * (16 + d->TW - 1) + 63) / 64) * 1024;
   const bool stream = patch_ + nq_ * fn * 16 * 64 > 64 * 1024;
   snprintf(buf, n, "tconv_kernel<%d, %d, %s>", d->Cin, fn, stream ? "true" : "false");
 }
