@@ -28,7 +28,7 @@ typedef __attribute__((address_space(3))) void* tlptr_t;
 // lane group's two k-groups cover complementary pixels of one 16-pixel run), and a tap shift is a
 // plain byte offset -- no per-tap swizzle arithmetic.  Patch and weights are staged by LDS-DMA.
 template <int CIN, int FN, bool STREAM>
-__global__ __launch_bounds__(256) void tconv_kernel(const GParams p) {
+__global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GParams p) {
   constexpr int VPP = CIN / 8;                      // planes (16-byte chunks per pixel)
   constexpr int TPC = CIN >= 32 ? 1 : 32 / CIN;     // taps per K chunk
   constexpr int KCH = CIN >= 32 ? CIN / 32 : 1;     // K chunks per tap

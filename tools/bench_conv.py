@@ -21,6 +21,8 @@ CASES = {
     'disc3': (128, 256, 4, 2, 'reflection', False, 64, 64, 8),
     'disc5': (512, 1024, 4, 2, 'reflection', False, 16, 16, 8),
     'disc6': (1024, 1024, 4, 1, 'reflection', False, 8, 8, 8),
+    'u32x64': (32, 64, 4, 1, 'reflection', False, 256, 256, 8),
+    'u32x64z': (32, 64, 4, 1, 'zero', False, 259, 259, 8),
     'rec_first': (2, 32, 3, 1, 'zero', False, 256, 256, 8),
     'rec_last': (32, 2, 3, 1, 'zero', False, 256, 256, 8),
 }
