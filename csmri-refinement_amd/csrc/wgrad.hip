@@ -462,7 +462,7 @@ typedef __attribute__((address_space(3))) void* wlptr_t;
 // origin + a per-lane constant, which cuts the address arithmetic from ~100 to ~15 vector
 // instructions per 16-byte piece; the general kernel below is vector-ALU bound on exactly that.
 template <int BP, int BQ, int WP, int WQ, bool REFLECT, bool UPS>
-__global__ __launch_bounds__(256, 3) void wgrad_glds_row_kernel(const WParams p) {
+__global__ __launch_bounds__(256, (BP == 128 && BQ == 128) ? 3 : 4) void wgrad_glds_row_kernel(const WParams p) {
   constexpr int PS = 64;
   constexpr int CP = BP / 8, CQ = BQ / 8;
   constexpr int NXI = CP / 4, NYI = (CQ + 3) / 4;
