@@ -122,26 +122,31 @@ extern "C" int csmri_bn_finalize(const float* partial, int rows, int C, int C_re
 
 // ---- z = drop[b,c] * lrelu((y-mean)*invstd*gamma + beta) ---------------------------
 template <int DT>
-__global__ __launch_bounds__(256) void bn_act_kernel(const void* y, int yps, void* z, int zps, int B, int HW,
-                                                     int C, int C_real, const float* mean, const float* invstd,
-                                                     const float* gamma, const float* beta, float slope,
-                                                     const float* drop, float* snap) {
+__global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ y, int yps, void* __restrict__ z,
+                                                     int zps, int B, int HW, int C, int C_real,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float slope,
+                                                     const float* __restrict__ drop, float* __restrict__ snap) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
   // B: images per group; blockIdx.y = group with its own mean/invstd
   const int grp = blockIdx.y, pbase = grp * B * HW;
   mean += grp * C; invstd += grp * C;
-  float sc[4], sh[4];
+  float sc[4], mu[4], be[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const bool ok = c + q < C_real;
     sc[q] = ok ? invstd[c + q] * gamma[c + q] : 0.f;
-    sh[q] = ok ? beta[c + q] - mean[c + q] * sc[q] : 0.f;
+    mu[q] = ok ? mean[c + q] : 0.f;
+    be[q] = ok ? beta[c + q] : 0.f;
     if (snap && blockIdx.x == 0 && grp == 0 && pl == 0) {      // affine parameters as this forward saw them
       snap[c + q] = ok ? gamma[c + q] : 0.f;
       snap[C + c + q] = ok ? beta[c + q] : 0.f;
     }
   }
   const int npix = B * HW;
+#pragma unroll 2
   for (int pp = blockIdx.x * lanes + pl; pp < npix; pp += gridDim.x * lanes) {
     const int p = pbase + pp;
     f32x4_t v = ld4<DT>(y, (long long)p * yps + c), o;
@@ -150,8 +155,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* y, int yps, voi
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       // same operation order as (y-mean)*invstd*gamma+beta up to one rounding
-      float t = (v[q] - (c + q < C_real ? mean[c + q] : 0.f));
-      t = t * sc[q] + (c + q < C_real ? beta[c + q] : 0.f);
+      float t = v[q] - mu[q];
+      t = t * sc[q] + be[q];
       t = t < 0.f ? t * slope : t;
       o[q] = t * dm[q];
     }
@@ -166,7 +171,9 @@ extern "C" int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z,
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
   const int lanes = 256 / (C / 4);
   B /= groups;                                   // images per group from here on
-  int blocks = (B * HW + lanes - 1) / lanes; if (blocks > 4096) blocks = 4096;
+  int blocks = (B * HW + lanes - 1) / lanes;
+  const int cap = 2048 / groups;                 // one resident wave of workgroups: per-channel set-up amortised
+  if (blocks > cap) blocks = cap;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CSMRI_BF16)
     hipLaunchKernelGGL(bn_act_kernel<CSMRI_BF16>, dim3(blocks, groups), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask, affine_snap);
@@ -251,12 +258,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* partial, in
 
 // ---- backward pass 2: dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)) ----
 template <int DT, bool RECOMP>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dz, int dzps, const void* y, int yps,
-                                                           const void* z, int zps, void* dy, int dyps, int npix,
-                                                           int HW, int C, int C_real, const float* mean,
-                                                           const float* invstd, const float* gamma, float slope,
-                                                           const float* drop, const float* totals, float inv_count,
-                                                           const float* snap) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dz, int dzps,
+                                                           const void* __restrict__ y, int yps,
+                                                           const void* __restrict__ z, int zps,
+                                                           void* __restrict__ dy, int dyps, int npix, int HW, int C,
+                                                           int C_real, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, float slope,
+                                                           const float* __restrict__ drop,
+                                                           const float* __restrict__ totals, float inv_count,
+                                                           const float* __restrict__ snap) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
   // npix: per group; blockIdx.y = group
   const int grp = blockIdx.y, pbase = grp * npix;
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dz, int d
     m1[q] = totals[c + q] * inv_count;
     m2[q] = totals[C + c + q] * inv_count;
   }
+#pragma unroll 2
   for (int pp = blockIdx.x * lanes + pl; pp < npix; pp += gridDim.x * lanes) {
     const int p = pbase + pp;
     f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c), zz, o;
@@ -302,7 +314,9 @@ extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, 
   CSMRI_LAUNCH_CHECK();
   B /= groups;                                   // images per group from here on
   const int npix = B * HW, lanes = 256 / (C / 4);
-  int blocks = (npix + lanes - 1) / lanes; if (blocks > 4096) blocks = 4096;
+  int blocks = (npix + lanes - 1) / lanes;
+  const int cap = 2048 / groups;
+  if (blocks > cap) blocks = cap;
   const float* totals = partial + (size_t)rows * 2 * C;
   const float inv = 1.0f / ((float)B * (float)HW);
 #define BN_APP(DT_, RC_) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT_, RC_>), dim3(blocks, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv, affine_snap)
