@@ -92,7 +92,7 @@ _SIGS = {
     'csmri_nchw_to_nhwc': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),
     'csmri_nhwc_to_nchw': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'csmri_mask_to_u8': (i32, [vp, i32, i32, i32, vp, vp]),
-    'csmri_bn_stats_rows': (i32, [i32]),
+    'csmri_bn_stats_rows': (i32, [i32, i32]),
     'csmri_bn_stats': (i32, [i32, vp, i32, i32, i32, vp, i32, vp]),
     'csmri_bn_finalize': (i32, [vp, i32, i32, i32, i64, f32, f32, vp, vp, vp, vp, i32, vp]),
     'csmri_bn_act': (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, f32,

@@ -546,7 +546,7 @@ def _bn_forward(y, stats, bn, c_real, slope, training, dropmask, groups=1):
   dev = y.device
   if training:
     if stats is None:
-      rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups)
+      rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups, cp)
       stats = torch.empty(rows, 2, cp, dtype=torch.float32, device=dev)
       lib.call('csmri_bn_stats', dt_of(y), y.data_ptr(), y.stride(2), b * h * w, cp, stats.data_ptr(),
                groups, stream())
@@ -611,7 +611,7 @@ class ConvBnAct(torch.autograd.Function):
     b, h, w, cp = y.shape
     dev = y.device
     groups = ctx.groups
-    rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups)
+    rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups, cp)
     partial = torch.empty(rows + groups, 2, cp, dtype=torch.float32, device=dev)
     lib.call('csmri_bn_bwd_reduce', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
              0, 0, b, h * w, cp, mean.data_ptr(), invstd.data_ptr(),

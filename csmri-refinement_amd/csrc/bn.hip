@@ -6,8 +6,14 @@
 #include "common.h"
 
 #define BN_MAX_ROWS 2048
-extern "C" int csmri_bn_stats_rows(int npix) {
-  int r = (npix + 127) / 128;
+// workgroups (= partial rows) for a [npix][C] tensor: about 16K elements each, at least one pixel per
+// pixel lane of the 256-thread workgroup, so that wide-channel / few-pixel maps still fill the chip
+extern "C" int csmri_bn_stats_rows(int npix, int C) {
+  int ppb = 16384 / (C > 0 ? C : 1);
+  const int lanes = C >= 4 ? 1024 / C : 256;
+  if (ppb < lanes) ppb = lanes;
+  if (ppb < 1) ppb = 1;
+  int r = (npix + ppb - 1) / ppb;
   return r < 1 ? 1 : (r > BN_MAX_ROWS ? BN_MAX_ROWS : r);
 }
 static bool bn_channels_ok(int C) { return C >= 8 && C <= 1024 && (C & (C - 1)) == 0; }
@@ -74,7 +80,7 @@ extern "C" int csmri_bn_stats(int dtype, const void* y, int pix_stride, int npix
                               int groups, void* stream) {
   CSMRI_CHECK_ARG(y && partial && npix > 0 && groups >= 1 && npix % groups == 0);
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
-  const int npg = npix / groups, rows = csmri_bn_stats_rows(npg);
+  const int npg = npix / groups, rows = csmri_bn_stats_rows(npg, C);
   if (dtype == CSMRI_BF16)
     hipLaunchKernelGGL(bn_stats_kernel<CSMRI_BF16>, dim3(rows, groups), dim3(256), 0, (hipStream_t)stream, y, pix_stride, npg, C, rows, partial);
   else
@@ -146,8 +152,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ y,
     }
   }
   const int npix = B * HW;
-#pragma unroll 2
-  for (int pp = blockIdx.x * lanes + pl; pp < npix; pp += gridDim.x * lanes) {
+  // each workgroup streams one contiguous pixel range (same decomposition as the reductions)
+  const int chunk = (npix + gridDim.x - 1) / gridDim.x, q0 = blockIdx.x * chunk, q1 = min(npix, q0 + chunk);
+#pragma unroll 4
+  for (int pp = q0 + pl; pp < q1; pp += lanes) {
     const int p = pbase + pp;
     f32x4_t v = ld4<DT>(y, (long long)p * yps + c), o;
     f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
@@ -171,9 +179,8 @@ extern "C" int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z,
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
   const int lanes = 256 / (C / 4);
   B /= groups;                                   // images per group from here on
-  int blocks = (B * HW + lanes - 1) / lanes;
-  const int cap = 2048 / groups;                 // one resident wave of workgroups: per-channel set-up amortised
-  if (blocks > cap) blocks = cap;
+  const int blocks = csmri_bn_stats_rows(B * HW, C);
+  (void)lanes;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CSMRI_BF16)
     hipLaunchKernelGGL(bn_act_kernel<CSMRI_BF16>, dim3(blocks, groups), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, B, HW, C, C_real, mean, invstd, gamma, beta, slope, dropmask, affine_snap);
@@ -222,7 +229,7 @@ extern "C" int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride,
                                    const float* affine_snap, int groups, void* stream) {
   CSMRI_CHECK_ARG(dz && y && partial && (z || affine_snap) && groups >= 1 && B % groups == 0);
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
-  const int npix = B / groups * HW, rows = csmri_bn_stats_rows(npix);
+  const int npix = B / groups * HW, rows = csmri_bn_stats_rows(npix, C);
   hipStream_t st = (hipStream_t)stream;
 #define BN_RED(DT_, RC_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT_, RC_>), dim3(rows, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, npix, HW, C, mean, invstd, slope, dropmask, rows, partial, affine_snap)
   if (dtype == CSMRI_BF16) { if (z) BN_RED(CSMRI_BF16, false); else BN_RED(CSMRI_BF16, true); }
@@ -282,8 +289,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
     m1[q] = totals[c + q] * inv_count;
     m2[q] = totals[C + c + q] * inv_count;
   }
-#pragma unroll 2
-  for (int pp = blockIdx.x * lanes + pl; pp < npix; pp += gridDim.x * lanes) {
+  const int chunk = (npix + gridDim.x - 1) / gridDim.x, q0 = blockIdx.x * chunk, q1 = min(npix, q0 + chunk);
+#pragma unroll 4
+  for (int pp = q0 + pl; pp < q1; pp += lanes) {
     const int p = pbase + pp;
     f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c), zz, o;
     if (RECOMP) zz = (yy - mu) * fsc + fbe; else zz = ld4<DT>(z, (long long)p * zps + c);
@@ -314,9 +322,8 @@ extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, 
   CSMRI_LAUNCH_CHECK();
   B /= groups;                                   // images per group from here on
   const int npix = B * HW, lanes = 256 / (C / 4);
-  int blocks = (npix + lanes - 1) / lanes;
-  const int cap = 2048 / groups;
-  if (blocks > cap) blocks = cap;
+  const int blocks = csmri_bn_stats_rows(npix, C);
+  (void)lanes;
   const float* totals = partial + (size_t)rows * 2 * C;
   const float inv = 1.0f / ((float)B * (float)HW);
 #define BN_APP(DT_, RC_) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT_, RC_>), dim3(blocks, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv, affine_snap)

@@ -214,7 +214,7 @@ int csmri_mask_to_u8(const float* mask_nchw, int B, int H, int W, uint8_t* dst, 
  * ---------------------------------------------------------------------- */
 /* per-channel partial sums of a tensor: partial [rows][2][C] (rows returned by
  * csmri_bn_stats_rows) -- used when the conv epilogue did not produce them */
-int csmri_bn_stats_rows(int npix);
+int csmri_bn_stats_rows(int npix, int C);
 int csmri_bn_stats(int dtype, const void* y, int pix_stride, int npix, int C,
                    float* partial, int groups, void* stream);   /* rows = groups*stats_rows(npix/groups) */
 /* reduce partials -> mean, invstd (saved for backward); update running stats

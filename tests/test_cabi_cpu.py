@@ -41,7 +41,8 @@ def test_argument_validation_needs_no_gpu():
   # Cin 2 -> 8 channels, KW 3 -> 4 taps (32/8 taps per K chunk): K = 3*4*8 = 96 -> 128
   assert lib.raw('csmri_pack_weight_bytes')(0, lib.BF16, 32, 2, 3, 3) == 128 * 128 * 2
   assert lib.raw('csmri_pack_weight_bytes')(2, lib.F32, 64, 16, 4, 4) == 4 * 128 * 256 * 4
-  assert lib.raw('csmri_bn_stats_rows')(524288) == 2048
+  assert lib.raw('csmri_bn_stats_rows')(524288, 32) == 1024
+  assert lib.raw('csmri_bn_stats_rows')(1024, 1024) == 64
 
 
 def test_no_cpu_fallback():

@@ -13,7 +13,7 @@ for b, h, w, c in SHAPES:
                    torch.zeros(c, device='cuda'), torch.ones(c, device='cuda'))
   for it in range(12):
     z, mean, invstd, snap = ops._bn_forward(y, None, bn, c, 0.2, True, None, 1)
-    rows = ops.lib.raw('csmri_bn_stats_rows')(b * h * w)
+    rows = ops.lib.raw('csmri_bn_stats_rows')(b * h * w, c)
     partial = torch.empty(rows + 1, 2, c, dtype=torch.float32, device='cuda')
     ops.lib.call('csmri_bn_bwd_reduce', ops.dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2), 0, 0,
                  b, h * w, c, mean.data_ptr(), invstd.data_ptr(), 0.2, 0, partial.data_ptr(), snap.data_ptr(), 1,
