@@ -12,6 +12,10 @@ static inline int grid_for(long long work, int threads = 256) {
 }
 #define GRID_STRIDE(i, n) \
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+// 32-bit element index (host checks n < 2^31): the div/mod chains below cost a fraction of the 64-bit ones
+#define GRID_STRIDE32(i, n) \
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)(n); i += gridDim.x * blockDim.x)
+#define CSMRI_CHECK_I32(n) do { if ((long long)(n) >= (1ll << 31)) return CSMRI_E_UNSUPPORTED; } while (0)
 
 // ---------------------------------------------------------------- layout ----
 __global__ void nchw_to_nhwc_kernel(const float* src, int B, int C, long long HW, void* dst,
@@ -205,18 +209,19 @@ extern "C" int csmri_pack_weight(int mode, int dtype, const float* w_ref, int Co
 __global__ void act_bwd_kernel(int dt, const void* dz, int dzps, const void* z, int zps, void* dy,
                                int dyps, long long npix, int C, float slope) {
   const int nv = C >> 2;
-  GRID_STRIDE(i, npix * nv) {
+  GRID_STRIDE32(i, npix * nv) {
     const int c = (int)(i % nv) * 4;
-    const long long p = i / nv;
-    f32x4_t g = load4(dz, p * dzps + c, dt), zz = load4(z, p * zps + c, dt);
+    const unsigned p = i / nv;
+    f32x4_t g = load4(dz, (long long)p * dzps + c, dt), zz = load4(z, (long long)p * zps + c, dt);
     for (int q = 0; q < 4; ++q) g[q] = zz[q] > 0.f ? g[q] : g[q] * slope;
-    store4(dy, p * dyps + c, dt, g);
+    store4(dy, (long long)p * dyps + c, dt, g);
   }
 }
 extern "C" int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const void* z,
                              int z_pix_stride, void* dy, int dy_pix_stride, long long npix, int C,
                              float slope, void* stream) {
   CSMRI_CHECK_ARG(dz && z && dy && C % 4 == 0);
+  CSMRI_CHECK_I32(npix * C);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream,
                      dtype, dz, dz_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, C, slope);
   CSMRI_LAUNCH_CHECK();
@@ -227,11 +232,11 @@ extern "C" int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const
 __global__ void maxpool2_kernel(int dt, const void* x, int xps, void* y, int yps, uint8_t* arg, int B,
                                 int H, int W, int C) {
   const int nv = C >> 2, Ho = H >> 1, Wo = W >> 1;
-  GRID_STRIDE(i, (long long)B * Ho * Wo * nv) {
+  GRID_STRIDE32(i, (long long)B * Ho * Wo * nv) {
     const int c = (int)(i % nv) * 4;
-    const long long p = i / nv;
+    const unsigned p = i / nv;
     const int ox = (int)(p % Wo);
-    const long long t = p / Wo;
+    const unsigned t = p / Wo;
     const int oy = (int)(t % Ho), b = (int)(t / Ho);
     const long long base = ((long long)b * H + 2 * oy) * W + 2 * ox;
     f32x4_t best = load4(x, base * xps + c, dt);
@@ -241,22 +246,22 @@ __global__ void maxpool2_kernel(int dt, const void* x, int xps, void* y, int yps
       for (int q = 0; q < 4; ++q)
         if (v[q] > best[q] || v[q] != v[q]) { best[q] = v[q]; idx[q] = k; }
     }
-    store4(y, p * yps + c, dt, best);
-    if (arg) *(uint32_t*)(arg + p * C + c) = idx[0] | (idx[1] << 8) | (idx[2] << 16) | (idx[3] << 24);
+    store4(y, (long long)p * yps + c, dt, best);
+    if (arg) *(uint32_t*)(arg + (long long)p * C + c) = idx[0] | (idx[1] << 8) | (idx[2] << 16) | (idx[3] << 24);
   }
 }
 __global__ void maxpool2_bwd_kernel(int dt, const void* dy, int dyps, const uint8_t* arg, void* dx,
                                     int dxps, int B, int H, int W, int C) {
   const int nv = C >> 2, Ho = H >> 1, Wo = W >> 1;
-  GRID_STRIDE(i, (long long)B * Ho * Wo * nv) {
+  GRID_STRIDE32(i, (long long)B * Ho * Wo * nv) {
     const int c = (int)(i % nv) * 4;
-    const long long p = i / nv;
+    const unsigned p = i / nv;
     const int ox = (int)(p % Wo);
-    const long long t = p / Wo;
+    const unsigned t = p / Wo;
     const int oy = (int)(t % Ho), b = (int)(t / Ho);
     const long long base = ((long long)b * H + 2 * oy) * W + 2 * ox;
-    f32x4_t g = load4(dy, p * dyps + c, dt);
-    const uint32_t a = *(const uint32_t*)(arg + p * C + c);
+    f32x4_t g = load4(dy, (long long)p * dyps + c, dt);
+    const uint32_t a = *(const uint32_t*)(arg + (long long)p * C + c);
     for (int k = 0; k < 4; ++k) {
       f32x4_t o;
       for (int q = 0; q < 4; ++q) o[q] = ((a >> (8 * q)) & 0xff) == (unsigned)k ? g[q] : 0.f;
@@ -268,6 +273,7 @@ extern "C" int csmri_maxpool2(int dtype, const void* x, int x_pix_stride, void* 
                               uint8_t* argmax, int B, int H, int W, int C, void* stream) {
   CSMRI_CHECK_ARG(x && y && H % 2 == 0 && W % 2 == 0 && C % 4 == 0);
   long long n = (long long)B * (H / 2) * (W / 2) * (C / 4);
+  CSMRI_CHECK_I32((long long)B * H * W * C);
   hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dtype, x,
                      x_pix_stride, y, y_pix_stride, argmax, B, H, W, C);
   CSMRI_LAUNCH_CHECK();
@@ -277,6 +283,7 @@ extern "C" int csmri_maxpool2_bwd(int dtype, const void* dy, int dy_pix_stride, 
                                   void* dx, int dx_pix_stride, int B, int H, int W, int C, void* stream) {
   CSMRI_CHECK_ARG(dy && dx && argmax && H % 2 == 0 && W % 2 == 0 && C % 4 == 0);
   long long n = (long long)B * (H / 2) * (W / 2) * (C / 4);
+  CSMRI_CHECK_I32((long long)B * H * W * C);
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dtype,
                      dy, dy_pix_stride, argmax, dx, dx_pix_stride, B, H, W, C);
   CSMRI_LAUNCH_CHECK();
@@ -298,11 +305,11 @@ __global__ void fold_pad_grad_kernel(int dt, const void* gp, void* out, int ops,
   const int nv = C >> 2;
   const int Hu = ups ? 2 * H : H, Wu = ups ? 2 * W : W;
   const int Hp = Hu + pt + pb, Wp = Wu + pl + pr;
-  GRID_STRIDE(i, (long long)B * H * W * nv) {
+  GRID_STRIDE32(i, (long long)B * H * W * nv) {
     const int c = (int)(i % nv) * 4;
-    const long long p = i / nv;
+    const unsigned p = i / nv;
     const int x = (int)(p % W);
-    const long long t = p / W;
+    const unsigned t = p / W;
     const int y = (int)(t % H), b = (int)(t / H);
     f32x4_t acc = (f32x4_t){0, 0, 0, 0};
     const int ny = ups ? 2 : 1;
@@ -316,10 +323,10 @@ __global__ void fold_pad_grad_kernel(int dt, const void* gp, void* out, int ops,
             acc += load4(gp, (((long long)b * Hp + ys[a]) * Wp + xs[e]) * C + c, dt);
       }
     if (gsrc) {
-      f32x4_t s = load4(gsrc, p * gps + c, dt);
+      f32x4_t s = load4(gsrc, (long long)p * gps + c, dt);
       for (int q = 0; q < 4; ++q) acc[q] = s[q] > 0.f ? acc[q] : acc[q] * gslope;
     }
-    store4(out, p * ops + c, dt, acc);
+    store4(out, (long long)p * ops + c, dt, acc);
   }
 }
 extern "C" int csmri_fold_pad_grad(int dtype, const void* gpad, void* out, int out_pix_stride, int B,
@@ -327,6 +334,7 @@ extern "C" int csmri_fold_pad_grad(int dtype, const void* gpad, void* out, int o
                                    const void* g_src, int g_pix_stride, float g_slope, void* stream) {
   CSMRI_CHECK_ARG(gpad && out && C % 4 == 0);
   long long n = (long long)B * H * W * (C / 4);
+  CSMRI_CHECK_I32((long long)B * (2 * H + pt + pb) * (2 * W + pl + pr) * C);
   hipLaunchKernelGGL(fold_pad_grad_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dtype,
                      gpad, out, out_pix_stride, B, H, W, C, pt, pb, pl, pr, upsample, g_src,
                      g_pix_stride, g_slope);
@@ -355,16 +363,17 @@ extern "C" int csmri_cast(const void* src, int src_dtype, void* dst, int dst_dty
 
 __global__ void copy_channels_kernel(const void* s, int sdt, int sps, int cs, void* d, int ddt, int dps,
                                      int cd, long long npix) {
-  GRID_STRIDE(i, npix * cd) {
+  GRID_STRIDE32(i, npix * cd) {
     const int c = (int)(i % cd);
-    const long long p = i / cd;
-    store_elem(d, p * dps + c, ddt, c < cs ? load_elem(s, p * sps + c, sdt) : 0.f);
+    const unsigned p = i / cd;
+    store_elem(d, (long long)p * dps + c, ddt, c < cs ? load_elem(s, (long long)p * sps + c, sdt) : 0.f);
   }
 }
 extern "C" int csmri_copy_channels(const void* src, int src_dtype, int src_pix_stride, int C_src, void* dst,
                                    int dst_dtype, int dst_pix_stride, int C_dst, long long npix,
                                    void* stream) {
   CSMRI_CHECK_ARG(src && dst && C_src > 0 && C_dst > 0 && npix > 0);
+  CSMRI_CHECK_I32(npix * (C_dst > C_src ? C_dst : C_src));
   hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(npix * C_dst)), dim3(256), 0, (hipStream_t)stream,
                      src, src_dtype, src_pix_stride, C_src, dst, dst_dtype, dst_pix_stride, C_dst, npix);
   CSMRI_LAUNCH_CHECK();

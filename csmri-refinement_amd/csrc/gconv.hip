@@ -215,16 +215,17 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GParams p) {
 // split-K second stage: sum slabs, then the same epilogue (bias/act/actgrad)
 __global__ void gconv_reduce_kernel(const GParams p) {
   const int HoWo = p.Ho * p.Wo;
-  const int nv = p.Cout / 4;
-  const long long total = (long long)p.M * nv * p.nclass;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int cls = (int)(i / ((long long)p.M * nv));
-    const long long rem = i - (long long)cls * p.M * nv;
-    const int m = (int)(rem / nv), n = (int)(rem - (long long)m * nv) * 4;
-    const float* slab = p.slab + (size_t)cls * p.splitk * p.M * p.Cout;
+  const unsigned nv = p.Cout / 4;
+  const unsigned per_class = (unsigned)p.M * nv;            // host: M * Cout * nclass < 2^31
+  const unsigned total = per_class * p.nclass;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int cls = (int)(i / per_class);
+    const unsigned rem = i - cls * per_class;
+    const int m = (int)(rem / nv), n = (int)(rem - (unsigned)m * nv) * 4;
+    const float* slab = p.slab + (size_t)cls * p.splitk * p.M * p.Cout + (size_t)m * p.Cout + n;
+    const size_t zstride = (size_t)p.M * p.Cout;
     f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < p.splitk; ++z) v += *(const f32x4_t*)(slab + ((size_t)z * p.M + m) * p.Cout + n);
+    for (int z = 0; z < p.splitk; ++z) v += *(const f32x4_t*)(slab + z * zstride);
     int b = m / HoWo, r = m - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
     const int ooy = p.ooy + (p.nclass == 4 ? (cls >> 1) : 0), oox = p.oox + (p.nclass == 4 ? (cls & 1) : 0);
     size_t pp = ((size_t)b * p.Hout_t + (size_t)(oy * p.osy + ooy)) * p.Wout_t + (ox * p.osx + oox);
@@ -342,6 +343,7 @@ static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
 
 static int launch_reduce(const GParams& p, hipStream_t st) {
   long long total = (long long)p.M * (p.Cout / 4) * p.nclass;
+  if (total * 4 >= (1ll << 31)) return CSMRI_E_UNSUPPORTED;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(gconv_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
   CSMRI_LAUNCH_CHECK();
