@@ -125,3 +125,4 @@ def freeze(module):
   for m in module.modules():
     if isinstance(m, ConvParams) and m.layer is not None:
       m.layer.frozen = True
+      m._layer_args = m._layer_args[:5] + (True,)      # survives the re-creation in _apply (.cuda())
