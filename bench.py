@@ -200,7 +200,12 @@ def main():
   runner.overlap_streams = not args.no_overlap
   if not args.no_graphs:
     # capture the step once (3 eager steps inside); the timed region replays hipGraphs
-    runner.enable_graphs(batches[0])
+    try:
+      runner.enable_graphs(batches[0])
+    except Exception as e:            # keep the measurement alive: eager launches, same kernels
+      sys.stderr.write('bench: hipGraph capture failed (%r); running eager\n' % (e,))
+      runner.disable_graphs()
+      args.no_graphs = True
   loader = DeviceLoader(batches, args.warmup)
   if args.warmup > 0:
     runner.train_epoch(loader, 1)

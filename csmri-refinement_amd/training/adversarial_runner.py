@@ -334,7 +334,9 @@ class AdversarialRunner(BaseRunner):
     try:
       for seg in (self._seg1, self._seg2, self._seg3, self._seg4):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None):
+        # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
+        with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None,
+                              capture_error_mode='thread_local'):
           seg(st)
         graphs.append(g)
     except Exception:

@@ -29,11 +29,13 @@ def init_from_env(backend=None):
   if ws <= 1 or dist.is_initialized():
     return ws
   if backend is None:
-    backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    # CSMRI_DIST_BACKEND=gloo: several ranks on ONE GPU (functional tests of the multi-rank path)
+    backend = os.environ.get('CSMRI_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
   os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
   os.environ.setdefault('MASTER_PORT', '29500')
   if backend == 'nccl':
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local if torch.cuda.device_count() > local else 0)
   dist.init_process_group(backend=backend, init_method='env://')
   return ws
 
