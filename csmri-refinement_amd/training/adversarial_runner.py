@@ -140,6 +140,7 @@ class AdversarialRunner(BaseRunner):
     self._last_metrics = None
     self.overlap_streams = False
     self._side_stream = None
+    self.vgg_early = None                 # None: decided at the first step (True on a single GPU)
     self.batch_disc_passes = True         # D(fake) and D(real) of the D phase as one grouped pass
 
   # -- reference surface -------------------------------------------------------
@@ -207,10 +208,18 @@ class AdversarialRunner(BaseRunner):
 
   def _seg1(self, st):
     batch = st['batch']
+    if self.vgg_early is None:
+      from training import distributed as dist_utils
+      import os
+      env = os.environ.get('CSMRI_VGG_EARLY')          # A/B knob
+      self.vgg_early = (env == '1') if env in ('0', '1') else dist_utils.world_size() == 1
     gen_inp = self.train_model_input_fn(batch)
     st['gen_inp0'] = gen_inp[0]
     out_gen = self.gen(*gen_inp)
     st['out_gen'] = out_gen
+    st['side_results'] = {}
+    if self.overlap_streams and self.vgg_early:
+      self._fork_vgg(st, out_gen, batch)
     in_fake = self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False, detach=True,
                                  pool_decisions=self.pool_decisions)
     in_real = self.disc_input_fn(batch['target'], gen_inp[0], out_gen, is_real_input=True, detach=True)
@@ -237,21 +246,29 @@ class AdversarialRunner(BaseRunner):
     names.append('disc_loss')
     vals.append(total_disc.detach())
     st['names'], st['vals'] = names, vals
+    if st['side_results']:                       # a segment (graph) ends with every stream joined
+      torch.cuda.current_stream().wait_stream(self._side_stream)
+
+  def _fork_vgg(self, st, out_gen, batch):
+    """The VGG perceptual branch (big GEMMs) only needs the generator output: run it on a side
+    stream next to chains of small kernels -- the discriminator passes and backward of segment 1
+    on a single GPU (vgg_early), or the third D forward of segment 2 when segment 2 has to hide
+    the D-bucket all-reduce.  Autograd replays the stream assignment in the backward, so the two
+    gradient chains into `pred` overlap as well."""
+    if self._side_stream is None:
+      self._side_stream = torch.cuda.Stream()
+    self._side_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(self._side_stream):
+      for name, criterion in self.gen_criteria.items():
+        if name == 'VGG19':
+          st['side_results'][name] = criterion(out_gen, batch)
 
   def _seg2(self, st):
     batch, out_gen = st['batch'], st['out_gen']
-    st['side_results'] = {}
-    if self.overlap_streams:
-      # the VGG perceptual branch (big GEMMs) is independent of the third D forward (many
-      # small kernels): run it on a side stream; autograd replays the same stream assignment
-      # in the backward, so the two gradient chains into `pred` overlap as well
-      if self._side_stream is None:
-        self._side_stream = torch.cuda.Stream()
-      self._side_stream.wait_stream(torch.cuda.current_stream())
-      with torch.cuda.stream(self._side_stream):
-        for name, criterion in self.gen_criteria.items():
-          if name == 'VGG19':
-            st['side_results'][name] = criterion(out_gen, batch)
+    forked_here = False
+    if self.overlap_streams and not st['side_results']:
+      self._fork_vgg(st, out_gen, batch)
+      forked_here = True
     self.disc.set_wgrad(False)     # D's weight gradients of this pass are discarded (A-5)
     out_fake = self.disc(nhwc=self.disc_input_fn(out_gen, st['gen_inp0'], out_gen,
                                                  is_real_input=False, detach=False))
@@ -269,7 +286,7 @@ class AdversarialRunner(BaseRunner):
       gen_losses.append(loss)
       st['names'].append('gen_loss_' + name)
       st['vals'].append(loss.detach())
-    if side:
+    if side and forked_here:
       torch.cuda.current_stream().wait_stream(self._side_stream)
     st['total_gen'] = self._weighted_total(gen_losses, self.gen_loss_weights)
 
