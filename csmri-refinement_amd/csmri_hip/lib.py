@@ -106,6 +106,7 @@ _SIGS = {
     'csmri_maxpool2_bwd': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     'csmri_complex_abs': (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
     'csmri_complex_abs_bwd': (i32, [vp, i64, vp, i32, i32, i32, i32, vp, i32, vp]),
+    'csmri_minmax_floats': (sz, [i32]),
     'csmri_minmax_real': (i32, [vp, i32, i64, vp, vp]),
     'csmri_refine_combine': (i32, [vp, vp, i32, i32, vp, vp, i32, i64, vp, vp, vp]),
     'csmri_refine_combine_bwd': (i32, [vp, vp, i32, i32, vp, vp, i32, i64, vp, i32, i32, vp,

@@ -848,7 +848,7 @@ class RefineCombine(torch.autograd.Function):
   def forward(ctx, pre, u, scale):
     b, h, w, _ = pre.shape
     u = as_nhwc(u)
-    mm = torch.empty(b, 2, dtype=torch.float32, device=pre.device)
+    mm = torch.empty(lib.raw('csmri_minmax_floats')(b), dtype=torch.float32, device=pre.device)
     lib.call('csmri_minmax_real', pre.data_ptr(), b, h * w, mm.data_ptr(), stream())
     pred = torch.empty_like(pre)
     scaled = torch.empty(b, h, w, dtype=torch.float32, device=pre.device)

@@ -83,27 +83,46 @@ extern "C" int csmri_complex_abs_bwd(const float* x, long long npix, const void*
 }
 
 // ---------------------------------------------------- refinement wrapper ----
-// one workgroup per sample: min of the real channel, then max of (x - min)
-__global__ __launch_bounds__(256) void minmax_real_kernel(const float2* x, long long HW, float* mm) {
-  __shared__ float sh[256];
-  const float2* xb = x + (size_t)blockIdx.x * HW;
-  float mn = INFINITY;
-  for (long long i = threadIdx.x; i < HW; i += 256) mn = fminf(mn, xb[i].x);
-  sh[threadIdx.x] = mn;
+// min of the real channel and max of (x - min) per sample.  max_i fl(x_i - mn) == fl(max_i x_i - mn)
+// (rounding is monotone), so one pass computes min and max; two stages keep it deterministic and
+// spread a sample over MM_SPLIT workgroups.
+#define MM_SPLIT 32
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float2* x, long long HW, float* part) {
+  __shared__ float smn[256], smx[256];
+  const float2* xb = x + (size_t)blockIdx.y * HW;
+  const long long chunk = (HW + MM_SPLIT - 1) / MM_SPLIT, i0 = blockIdx.x * chunk, i1 = min(HW, i0 + chunk);
+  float mn = INFINITY, mx = -INFINITY;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) { const float v = xb[i].x; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+  smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] = fminf(sh[threadIdx.x], sh[threadIdx.x + s]); __syncthreads(); }
-  mn = sh[0];
-  __syncthreads();
-  float mx = -INFINITY;
-  for (long long i = threadIdx.x; i < HW; i += 256) mx = fmaxf(mx, xb[i].x - mn);
-  sh[threadIdx.x] = mx;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s]); __syncthreads(); }
-  if (threadIdx.x == 0) { mm[2 * blockIdx.x] = mn; mm[2 * blockIdx.x + 1] = sh[0]; }
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      smn[threadIdx.x] = fminf(smn[threadIdx.x], smn[threadIdx.x + s]);
+      smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[(blockIdx.y * MM_SPLIT + blockIdx.x) * 2] = smn[0];
+    part[(blockIdx.y * MM_SPLIT + blockIdx.x) * 2 + 1] = smx[0];
+  }
 }
+__global__ void minmax_final_kernel(const float* part, int B, float* mm) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int k = 0; k < MM_SPLIT; ++k) { mn = fminf(mn, part[(b * MM_SPLIT + k) * 2]); mx = fmaxf(mx, part[(b * MM_SPLIT + k) * 2 + 1]); }
+  mm[2 * b] = mn; mm[2 * b + 1] = mx - mn;
+}
+// minmax: [B][2] results followed by B*MM_SPLIT*2 floats of scratch (csmri_minmax_floats(B) in all)
+extern "C" size_t csmri_minmax_floats(int B) { return (size_t)B * 2 * (1 + MM_SPLIT); }
 extern "C" int csmri_minmax_real(const float* x, int B, long long HW, float* minmax, void* stream) {
   CSMRI_CHECK_ARG(x && minmax && B > 0);
-  hipLaunchKernelGGL(minmax_real_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float2*)x, HW, minmax);
+  float* part = minmax + (size_t)B * 2;
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(MM_SPLIT, B), dim3(256), 0, (hipStream_t)stream, (const float2*)x,
+                     HW, part);
+  CSMRI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(minmax_final_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, B, minmax);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
@@ -155,13 +174,15 @@ __global__ __launch_bounds__(256) void refine_combine_bwd_kernel(
   double tot = block_sum(acc);
   if (threadIdx.x == 0) partial[1 + blockIdx.x] = (float)tot;
 }
-__global__ void sum_partials_kernel(float* partial, int n) {
-  // single thread: deterministic order
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double t = 0;
-    for (int i = 0; i < n; ++i) t += partial[1 + i];
-    partial[0] = (float)t;
-  }
+__global__ __launch_bounds__(256) void sum_partials_kernel(float* partial, int n) {
+  // one workgroup, fixed-order strided sums + tree: deterministic
+  __shared__ double sh[256];
+  double t = 0;
+  for (int i = threadIdx.x; i < n; i += 256) t += partial[1 + i];
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) partial[0] = (float)sh[0];
 }
 extern "C" int csmri_refine_combine_bwd(const float* gpred, const void* u, int u_dtype, int u_pix_stride,
                                         const float* scale_param, const float* minmax, int B,
@@ -174,7 +195,7 @@ extern "C" int csmri_refine_combine_bwd(const float* gpred, const void* u, int u
                      u_dtype, u_pix_stride, scale_param, minmax, B, HW, du, du_dtype, du_pix_stride,
                      dscale_partial);
   CSMRI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, dscale_partial, blocks);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, dscale_partial, blocks);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -271,7 +271,9 @@ int csmri_complex_abs_bwd(const float* x, long long npix, const void* g, int g_d
                           int g_pix_stride, int nch, int mode, float* dx, int accumulate,
                           void* stream);
 /* per-sample min and max-of-shifted of channel 0 of x [B,HW,2]:
- * minmax[b] = (min, max(x-min))   (models/refinement_wrapper.py:51-73) */
+ * minmax[b] = (min, max(x-min))   (models/refinement_wrapper.py:51-73).
+ * minmax holds csmri_minmax_floats(B) floats: the [B][2] result, then two-stage scratch. */
+size_t csmri_minmax_floats(int B);
 int csmri_minmax_real(const float* x, int B, long long HW, float* minmax, void* stream);
 /* pred = cat( unscale(scale(pre_real) + s*u), pre_imag ); scaled = s*u
  * (models/refinement_wrapper.py:169-194).  u: [B,HW] values with pix stride. */
