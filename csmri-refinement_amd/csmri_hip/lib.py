@@ -44,6 +44,8 @@ class GConvDesc(C.Structure):
       ('g_src', vp), ('g_pix_stride', i32), ('g_slope', f32), ('g_dtype', i32),
       ('stats_partial', vp),
       ('splitk', i32), ('slab', vp), ('flags', i32),
+      ('out_halo', vp), ('halo_pix_stride', i32), ('win_y0', i32), ('win_x0', i32), ('win_h', i32),
+      ('win_w', i32),
   ]
 
 
@@ -87,6 +89,7 @@ _SIGS = {
     'csmri_wgrad_suggest_splitk': (i32, [C.POINTER(WGradDesc)]),
     'csmri_fold_pad_grad': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                   i32, vp, i32, f32, vp]),
+    'csmri_fold_halo': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, f32, vp]),
     'csmri_dc': (i32, [vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
     'csmri_dc_work_bytes': (sz, [i32, i32, i32]),
     'csmri_nchw_to_nhwc': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),

@@ -241,6 +241,7 @@ class PackGroup(object):
     return True
 
 
+FOLD_WINDOW = True      # reflection dgrads: centre written in place + border-only halo fold
 PROFILE_SHAPES = False  # tools: append the problem shape to gconv labels
 PROFILE = None        # bench.py sets this to a list to collect per-launch HIP event timings
 
@@ -400,12 +401,27 @@ def conv_dgrad(layer, gy, in_hw, g_src=None, g_slope=1.0):
     d.out_oy = d.out_ox = 0
   else:
     raise RuntimeError('unsupported stride')
+  flops = 2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw
+  gs = as_nhwc(g_src) if g_src is not None else None
+  if not direct and not layer.upsample and h >= pt + pb + 2 and w >= pl + pr + 2 and FOLD_WINDOW:
+    # reflection padding, no upsampling: the kernel writes the un-padded centre straight into dx
+    # and only the halo positions into `out`; a border-only kernel mirrors the halo back
+    dx = torch.empty(b, h, w, layer.cin_p, dtype=gy.dtype, device=dev)
+    d.out, d.out_pix_stride = dx.data_ptr(), dx.stride(2)
+    d.out_halo, d.halo_pix_stride = out.data_ptr(), out.stride(2)
+    d.win_y0, d.win_x0, d.win_h, d.win_w = pt, pl, h, w
+    if gs is not None:
+      d.g_src, d.g_pix_stride, d.g_slope, d.g_dtype = gs.data_ptr(), gs.stride(2), g_slope, dt_of(gs)
+    _gconv_run(d, False, flops)
+    lib.call('csmri_fold_halo', dt_of(out), out.data_ptr(), dx.data_ptr(), dx.stride(2), b, h, w,
+             layer.cin_p, pt, pb, pl, pr, ptr(gs), gs.stride(2) if gs is not None else 0,
+             float(g_slope), stream())
+    return dx
   d.out, d.out_pix_stride = out.data_ptr(), out.stride(2)
-  _gconv_run(d, False, 2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw)
+  _gconv_run(d, False, flops)
   if direct:
     return out
   dx = torch.empty(b, h, w, layer.cin_p, dtype=gy.dtype, device=dev)
-  gs = as_nhwc(g_src) if g_src is not None else None
   lib.call('csmri_fold_pad_grad', dt_of(out), out.data_ptr(), dx.data_ptr(), dx.stride(2), b, h, w,
            layer.cin_p, pt, pb, pl, pr, int(layer.upsample), ptr(gs),
            gs.stride(2) if gs is not None else 0, float(g_slope), stream())

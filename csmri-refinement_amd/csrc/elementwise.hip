@@ -329,6 +329,56 @@ __global__ void fold_pad_grad_kernel(int dt, const void* gp, void* out, int ops,
     store4(out, (long long)p * ops + c, dt, acc);
   }
 }
+// border-only fold: dx (dense, un-padded) already holds the centre contribution; add what the
+// reflection padding mirrors back from the halo positions of the padded gradient
+__global__ void fold_halo_kernel(int dt, const void* gp, void* dx, int dxps, int B, int H, int W, int C,
+                                 int pt, int pb, int pl, int pr, const void* gsrc, int gps, float gslope) {
+  const int nv = C >> 2;
+  const int Hp = H + pt + pb, Wp = W + pl + pr;
+  const int nyb = pt + pb, nxb = pl + pr;
+  const unsigned per_img = (unsigned)(nyb * W + (H - nyb) * nxb);
+  GRID_STRIDE32(i, (unsigned)B * per_img * nv) {
+    const int c = (int)(i % nv) * 4;
+    const unsigned q = i / nv;
+    const int b = (int)(q / per_img);
+    const int j = (int)(q - (unsigned)b * per_img);
+    int y, x;
+    if (j < nyb * W) {                     // border rows, every column
+      const int yi = j / W;
+      x = j - yi * W;
+      y = yi < pt ? 1 + yi : H - 1 - pb + (yi - pt);
+    } else {                               // remaining rows, border columns only
+      const int k = j - nyb * W, yy = k / nxb, xi = k - yy * nxb;
+      y = yy == 0 ? 0 : (yy <= H - 2 - pb - pt ? pt + yy : H - 1);
+      x = xi < pl ? 1 + xi : W - 1 - pr + (xi - pl);
+    }
+    int ys[3], xs[3];
+    const int ky = fold_sources(y, H, pt, pb, ys), kx = fold_sources(x, W, pl, pr, xs);
+    f32x4_t acc = (f32x4_t){0, 0, 0, 0};
+    for (int a = 0; a < ky; ++a)
+      for (int e = 0; e < kx; ++e)
+        if (a | e) acc += load4(gp, (((long long)b * Hp + ys[a]) * Wp + xs[e]) * C + c, dt);
+    const long long p = ((long long)b * H + y) * W + x;
+    if (gsrc) {
+      f32x4_t s = load4(gsrc, p * gps + c, dt);
+      for (int r = 0; r < 4; ++r) acc[r] = s[r] > 0.f ? acc[r] : acc[r] * gslope;
+    }
+    f32x4_t cur = load4(dx, p * dxps + c, dt);
+    store4(dx, p * dxps + c, dt, cur + acc);
+  }
+}
+extern "C" int csmri_fold_halo(int dtype, const void* gpad_halo, void* dx, int dx_pix_stride, int B, int H,
+                               int W, int C, int pt, int pb, int pl, int pr, const void* g_src,
+                               int g_pix_stride, float g_slope, void* stream) {
+  CSMRI_CHECK_ARG(gpad_halo && dx && C % 4 == 0 && H >= pt + pb + 2 && W >= pl + pr + 2);
+  CSMRI_CHECK_I32((long long)B * (H + pt + pb) * (W + pl + pr) * C);
+  const long long n = (long long)B * ((pt + pb) * W + (H - pt - pb) * (pl + pr)) * (C / 4);
+  if (n <= 0) return CSMRI_OK;
+  hipLaunchKernelGGL(fold_halo_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dtype, gpad_halo, dx,
+                     dx_pix_stride, B, H, W, C, pt, pb, pl, pr, g_src, g_pix_stride, g_slope);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
 extern "C" int csmri_fold_pad_grad(int dtype, const void* gpad, void* out, int out_pix_stride, int B,
                                    int H, int W, int C, int pt, int pb, int pl, int pr, int upsample,
                                    const void* g_src, int g_pix_stride, float g_slope, void* stream) {

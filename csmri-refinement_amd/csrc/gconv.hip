@@ -161,11 +161,10 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GParams p) {
   for (int j = 0; j < FM; ++j) {
     const int m = m0 + wm * WTM + j * 16 + r16;
     const bool mv = m < p.M;
-    size_t opix = 0, gpix = 0;
+    OutPos op; op.base = p.out; op.opix = 0; op.gpix = 0; op.g_ok = true;
     if (mv) {
       int b = m / HoWo, r = m - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
-      size_t pp = ((size_t)b * p.Hout_t + (size_t)(oy * p.osy + ooy)) * p.Wout_t + (ox * p.osx + oox);
-      opix = pp * p.ops; gpix = pp * p.gps;
+      op = gconv_out_pos(p, b, oy * p.osy + ooy, ox * p.osx + oox);
     }
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
@@ -186,12 +185,12 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * p.slope : v[r];
       }
-      if (p.gsrc) {
-        f32x4_t gs = load4(p.gsrc, gpix + n, p.gdt);
+      if (p.gsrc && op.g_ok) {
+        f32x4_t gs = load4(p.gsrc, op.gpix + n, p.gdt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gs[r] > 0.f ? v[r] : v[r] * p.gslope;
       }
-      store4(p.out, opix + n, p.out_dt, v);
+      store4(op.base, op.opix + n, p.out_dt, v);
     }
   }
   if (p.stats && p.splitk == 1) {
@@ -228,15 +227,15 @@ __global__ void gconv_reduce_kernel(const GParams p) {
     for (int z = 0; z < p.splitk; ++z) v += *(const f32x4_t*)(slab + z * zstride);
     int b = m / HoWo, r = m - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
     const int ooy = p.ooy + (p.nclass == 4 ? (cls >> 1) : 0), oox = p.oox + (p.nclass == 4 ? (cls & 1) : 0);
-    size_t pp = ((size_t)b * p.Hout_t + (size_t)(oy * p.osy + ooy)) * p.Wout_t + (ox * p.osx + oox);
+    const OutPos op = gconv_out_pos(p, b, oy * p.osy + ooy, ox * p.osx + oox);
     if (p.bias) v += *(const f32x4_t*)(p.bias + n);
     if (p.slope != 1.f)
       for (int q = 0; q < 4; ++q) v[q] = v[q] < 0.f ? v[q] * p.slope : v[q];
-    if (p.gsrc) {
-      f32x4_t gs = load4(p.gsrc, pp * p.gps + n, p.gdt);
+    if (p.gsrc && op.g_ok) {
+      f32x4_t gs = load4(p.gsrc, op.gpix + n, p.gdt);
       for (int q = 0; q < 4; ++q) v[q] = gs[q] > 0.f ? v[q] : v[q] * p.gslope;
     }
-    store4(p.out, pp * p.ops + n, p.out_dt, v);
+    store4(op.base, op.opix + n, p.out_dt, v);
   }
 }
 
@@ -332,6 +331,12 @@ static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
   p.bias = d->bias; p.slope = d->act_slope; p.gsrc = (const char*)d->g_src; p.gps = d->g_pix_stride;
   p.gslope = d->g_slope; p.gdt = d->g_dtype;
   p.stats = d->stats_partial; p.splitk = splitk; p.slab = d->slab;
+  p.out2 = (char*)d->out_halo; p.o2ps = d->halo_pix_stride;
+  p.win_y0 = d->win_y0; p.win_x0 = d->win_x0; p.win_h = d->win_h; p.win_w = d->win_w;
+  if (d->out_halo) {
+    CSMRI_CHECK_ARG(d->win_h > 0 && d->win_w > 0 && d->halo_pix_stride % 4 == 0 && !d->stats_partial);
+    if ((uintptr_t)d->out_halo & 15) return CSMRI_E_ALIGN;
+  }
   p.M = desc_M(d);
   const int bke = (d->dtype == CSMRI_BF16 ? 32 : 16) * c.KC;
   p.nsteps = cdiv((long long)d->TH * d->TW * d->Cin, bke);

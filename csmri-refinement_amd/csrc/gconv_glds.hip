@@ -173,11 +173,10 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
   for (int j = 0; j < FM; ++j) {
     const int m = m0 + wm * WTM + j * 16 + r16;
     const bool mv = m < p.M;
-    size_t opix = 0, gpix = 0;
+    OutPos op; op.base = p.out; op.opix = 0; op.gpix = 0; op.g_ok = true;
     if (mv) {
       int b = m / HoWo, r = m - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
-      size_t pp = ((size_t)b * p.Hout_t + (size_t)(oy * p.osy + ooy)) * p.Wout_t + (ox * p.osx + oox);
-      opix = pp * p.ops; gpix = pp * p.gps;
+      op = gconv_out_pos(p, b, oy * p.osy + ooy, ox * p.osx + oox);
     }
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
@@ -197,12 +196,12 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * p.slope : v[r];
       }
-      if (p.gsrc) {
-        f32x4_t gs = load4(p.gsrc, gpix + n, p.gdt);
+      if (p.gsrc && op.g_ok) {
+        f32x4_t gs = load4(p.gsrc, op.gpix + n, p.gdt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gs[r] > 0.f ? v[r] : v[r] * p.gslope;
       }
-      store4(p.out, opix + n, p.out_dt, v);
+      store4(op.base, op.opix + n, p.out_dt, v);
     }
   }
   if (p.stats && p.splitk == 1) {

@@ -13,7 +13,28 @@ struct GParams {
   float* stats; int splitk; float* slab;
   int M, nsteps, steps_per_split, mtiles, ntiles;
   int nt_major;   // gconv_glds: tile order that keeps the larger operand shared inside an XCD
+  char* out2; int o2ps, win_y0, win_x0, win_h, win_w;   // output window (csmri_gconv_desc.out_halo)
 };
+
+// where output position (b, ty, tx) of the tensor goes: window -> dense `out`, else halo buffer
+struct OutPos { char* base; size_t opix, gpix; bool g_ok; };
+__device__ __forceinline__ OutPos gconv_out_pos(const GParams& p, int b, int ty, int tx) {
+  OutPos o;
+  if (p.out2) {
+    const int cy = ty - p.win_y0, cx = tx - p.win_x0;
+    if ((unsigned)cy < (unsigned)p.win_h && (unsigned)cx < (unsigned)p.win_w) {
+      const size_t pp = ((size_t)b * p.win_h + cy) * p.win_w + cx;
+      o.base = p.out; o.opix = pp * p.ops; o.gpix = pp * p.gps; o.g_ok = true;
+    } else {
+      const size_t pp = ((size_t)b * p.Hout_t + ty) * p.Wout_t + tx;
+      o.base = p.out2; o.opix = pp * p.o2ps; o.gpix = 0; o.g_ok = false;
+    }
+  } else {
+    const size_t pp = ((size_t)b * p.Hout_t + ty) * p.Wout_t + tx;
+    o.base = p.out; o.opix = pp * p.ops; o.gpix = pp * p.gps; o.g_ok = true;
+  }
+  return o;
+}
 
 // tconv.hip
 int tconv_eligible(const csmri_gconv_desc* d);

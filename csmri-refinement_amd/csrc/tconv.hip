@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
   for (int f = 0; f < 4; ++f) {
     const int oy = y0 + 4 * wv + f, ox = x0 + r16;
     const bool mv = oy < p.Ho && ox < p.Wo;
-    const size_t pp = ((size_t)b * p.Hout_t + (oy * p.osy + p.ooy)) * p.Wout_t + (ox * p.osx + p.oox);
+    const OutPos op = gconv_out_pos(p, b, oy * p.osy + p.ooy, ox * p.osx + p.oox);
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
       const int n = n0 + i * 16 + g * 4;
@@ -176,12 +176,12 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * p.slope : v[r];
       }
-      if (p.gsrc) {
-        f32x4_t gs = load4(p.gsrc, pp * p.gps + n, p.gdt);
+      if (p.gsrc && op.g_ok) {
+        f32x4_t gs = load4(p.gsrc, op.gpix + n, p.gdt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gs[r] > 0.f ? v[r] : v[r] * p.gslope;
       }
-      store4(p.out, pp * p.ops + n, p.out_dt, v);
+      store4(op.base, op.opix + n, p.out_dt, v);
     }
   }
   if (p.stats) {

@@ -99,6 +99,12 @@ typedef struct csmri_gconv_desc {
   int splitk;                /* >=1; >1 needs slab */
   float* slab;               /* [splitk][M][Cout] fp32 workspace */
   int flags;                 /* CSMRI_GCONV_DEFER_REDUCE: caller runs csmri_gconv_reduce itself */
+  /* optional output window (reflection-padded dgrad without a full fold pass): positions whose
+   * tensor coordinate (ty, tx) lies inside [win_y0, win_y0+win_h) x [win_x0, win_x0+win_w) are
+   * written to `out`, now a dense [B, win_h, win_w] tensor indexed by (ty-win_y0, tx-win_x0)
+   * (g_src is indexed the same way); all other positions go, without actgrad, to `out_halo`
+   * ([B, Hout_t, Wout_t] extents, only those positions are touched).  NULL: no window. */
+  void* out_halo; int halo_pix_stride; int win_y0, win_x0, win_h, win_w;
 } csmri_gconv_desc;
 #define CSMRI_GCONV_DEFER_REDUCE 1
 
@@ -166,6 +172,13 @@ int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d);
  * nn.Upsample(nearest), models/utils.py:58-72, unet.py:98) and optionally apply
  * the activation derivative of the producer.  gpad: [B, (up?2H:H)+pt+pb,
  * (up?2W:W)+pl+pr, C] dense; out: [B,H,W,C] with out_pix_stride. */
+/* border-only companion of the csmri_gconv output window: adds to dx [B,H,W,C] (in place) the
+ * gradient that reflection padding (pads pt,pb,pl,pr) mirrors back from the halo positions of
+ * gpad_halo [B,H+pt+pb,W+pl+pr,C]; multiplied by lrelu'(g_src) when g_src != NULL.  Touches
+ * O(perimeter) pixels.  Needs H >= pt+pb+2 and W >= pl+pr+2. */
+int csmri_fold_halo(int dtype, const void* gpad_halo, void* dx, int dx_pix_stride, int B, int H, int W,
+                    int C, int pt, int pb, int pl, int pr, const void* g_src, int g_pix_stride,
+                    float g_slope, void* stream);
 int csmri_fold_pad_grad(int dtype, const void* gpad, void* out, int out_pix_stride,
                         int B, int H, int W, int C, int pt, int pb, int pl, int pr,
                         int upsample, const void* g_src, int g_pix_stride, float g_slope,
