@@ -148,6 +148,7 @@ __device__ __forceinline__ float pack_elem(const csmri_pack_item& it, const Pack
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const csmri_pack_item* items) {
   __shared__ float tile[16][65];
   const csmri_pack_item it = items[blockIdx.y];
+  const float* __restrict__ it_w = it.w;
   const PackGeom g = pack_geom(it.mode, it.Cout, it.Cin, it.KH, it.KW);
   const int T = it.KH * it.KW, KW = it.KW, KH = it.KH;
   const bool swapped = it.mode != 0;
@@ -158,22 +159,40 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const csmri_pack
   for (int t = blockIdx.x; t < g.rows * nchunk; t += gridDim.x) {
     const int r = t / nchunk, c0 = (t - r * nchunk) * 64;
     const int nc = max(0, min(64, chan - c0));
-    for (int e = threadIdx.x; e < nc * T; e += 256) {
-      const int ch = e / T, tap = e - ch * T;
-      tile[tap][ch] = swapped ? it.w[((long long)(c0 + ch) * it.Cin + r) * T + tap]
-                              : it.w[((long long)r * it.Cin + c0 + ch) * T + tap];
+    // at most 64*16 elements per tile = 4 per thread: fixed-trip loops keep all four global loads
+    // (and later all four stores) of a thread in flight together
+    float vals[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = threadIdx.x + u * 256;
+      vals[u] = 0.f;
+      if (e < nc * T) {
+        const int ch = e / T, tap = e - ch * T;
+        vals[u] = swapped ? it_w[((long long)(c0 + ch) * it.Cin + r) * T + tap]
+                           : it_w[((long long)r * it.Cin + c0 + ch) * T + tap];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = threadIdx.x + u * 256;
+      if (e < nc * T) { const int ch = e / T, tap = e - ch * T; tile[tap][ch] = vals[u]; }
     }
     __syncthreads();
     const int ncp = min(64, g.chan_pad - c0);
-    for (int e = threadIdx.x; e < g.nclass * ntap * ncp; e += 256) {
-      const int ch = e % ncp, q = e / ncp;
-      const int tp = q % ntap, cls = q / ntap;
-      const int ty = tp / g.tw, tx = tp - ty * g.tw;
-      int src = -1;
-      if (it.mode == 2) src = ((cls >> 1) + 2 * ty) * KW + (cls & 1) + 2 * tx;
-      else if (tx < KW) src = it.mode == 3 ? (KH - 1 - ty) * KW + (KW - 1 - tx) : ty * KW + tx;
-      const float v = (src >= 0 && ch < nc) ? tile[src][ch] : 0.f;
-      store_elem(it.out, cls * per_class + (long long)r * g.Kp + (long long)tp * g.chan_pad + c0 + ch, it.dtype, v);
+    const int nout = g.nclass * ntap * ncp;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = threadIdx.x + u * 256;
+      if (e < nout) {
+        const int ch = e % ncp, q = e / ncp;
+        const int tp = q % ntap, cls = q / ntap;
+        const int ty = tp / g.tw, tx = tp - ty * g.tw;
+        int src = -1;
+        if (it.mode == 2) src = ((cls >> 1) + 2 * ty) * KW + (cls & 1) + 2 * tx;
+        else if (tx < KW) src = it.mode == 3 ? (KH - 1 - ty) * KW + (KW - 1 - tx) : ty * KW + tx;
+        const float v = (src >= 0 && ch < nc) ? tile[src][ch] : 0.f;
+        store_elem(it.out, cls * per_class + (long long)r * g.Kp + (long long)tp * g.chan_pad + c0 + ch, it.dtype, v);
+      }
     }
     __syncthreads();
   }
