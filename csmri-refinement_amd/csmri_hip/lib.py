@@ -54,6 +54,11 @@ class PackItem(C.Structure):
               ('KH', i32), ('KW', i32)]
 
 
+class LossItem(C.Structure):
+  _fields_ = [('a', vp), ('b', vp), ('a_pix_stride', i32), ('b_pix_stride', i32), ('npix', i64),
+              ('C', i32), ('C_real', i32), ('weight', f32), ('ga', vp), ('ga_pix_stride', i32)]
+
+
 class WGradDesc(C.Structure):
   _fields_ = [
       ('dtype', i32),
@@ -116,6 +121,9 @@ _SIGS = {
                                        vp]),
     'csmri_loss': (i32, [i32, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp]),
     'csmri_loss_work_bytes': (sz, []),
+    'csmri_loss_multi_work_bytes': (sz, [i32]),
+    'csmri_loss_multi': (i32, [i32, i32, C.POINTER(LossItem), i32, vp, vp, vp]),
+    'csmri_loss_multi_bwd': (i32, [i32, i32, C.POINTER(LossItem), i32, vp, vp]),
     'csmri_loss_bwd': (i32, [i32, i32, vp, i32, vp, i32, i64, i32, i32, vp, f32, vp, i32, i32,
                              vp]),
     'csmri_bce_logits': (i32, [vp, i64, f32, vp, vp, vp]),

@@ -919,6 +919,55 @@ class MeanLoss(torch.autograd.Function):
     return ga, None, None, None
 
 
+class MultiMeanLoss(torch.autograd.Function):
+  """sum_i weights[i] * mean|a_i - b_i| (kind 0) or mean (a_i - b_i)^2 (kind 1) over the real
+  channels of n NHWC tensor pairs, one launch pair forward and one launch backward.
+  Call: MultiMeanLoss.apply(kind, weights, chans, a_0..a_{n-1}, b_0..b_{n-1}); the b_i are
+  targets (no gradient)."""
+
+  @staticmethod
+  def _items(kind, weights, chans, a_list, b_list, grads=None):
+    n = len(a_list)
+    arr = (lib.LossItem * n)()
+    for i in range(n):
+      a, b = a_list[i], b_list[i]
+      bb, h, w, cp = a.shape
+      it = arr[i]
+      it.a, it.a_pix_stride = a.data_ptr(), a.stride(2)
+      it.b, it.b_pix_stride = ptr(b), (b.stride(2) if b is not None else 0)
+      it.npix, it.C, it.C_real, it.weight = bb * h * w, cp, chans[i], float(weights[i])
+      if grads is not None:
+        it.ga, it.ga_pix_stride = grads[i].data_ptr(), grads[i].stride(2)
+    return arr
+
+  @staticmethod
+  def forward(ctx, kind, weights, chans, *tensors):
+    n = len(tensors) // 2
+    a_list = [as_nhwc(t) for t in tensors[:n]]
+    b_list = [as_nhwc(t) if t is not None else None for t in tensors[n:]]
+    dev = a_list[0].device
+    res = torch.empty(1 + n, dtype=torch.float32, device=dev)
+    work = torch.empty(lib.raw('csmri_loss_multi_work_bytes')(n) // 8, dtype=torch.float64, device=dev)
+    arr = MultiMeanLoss._items(kind, weights, chans, a_list, b_list)
+    lib.call('csmri_loss_multi', kind, dt_of(a_list[0]), arr, n, res.data_ptr(), work.data_ptr(), stream())
+    ctx.save_for_backward(*(a_list + [b for b in b_list if b is not None]))
+    ctx.has_b = [b is not None for b in b_list]
+    ctx.kind, ctx.weights, ctx.chans, ctx.n = kind, list(weights), list(chans), n
+    return res[0]
+
+  @staticmethod
+  def backward(ctx, g):
+    saved = list(ctx.saved_tensors)
+    n = ctx.n
+    a_list, rest = saved[:n], saved[n:]
+    b_list = [rest.pop(0) if hb else None for hb in ctx.has_b]
+    coeff = g.reshape(1).float().contiguous()
+    grads = [torch.empty(a.shape, dtype=a.dtype, device=a.device) for a in a_list]
+    arr = MultiMeanLoss._items(ctx.kind, ctx.weights, ctx.chans, a_list, b_list, grads)
+    lib.call('csmri_loss_multi_bwd', ctx.kind, dt_of(a_list[0]), arr, n, coeff.data_ptr(), stream())
+    return (None, None, None) + tuple(grads) + (None,) * n
+
+
 class BCELogits(torch.autograd.Function):
   """mean BCE(sigmoid(logits), target) with torch's log clamp (adversarial_loss.py)."""
 

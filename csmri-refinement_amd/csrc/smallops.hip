@@ -280,6 +280,100 @@ extern "C" int csmri_loss_bwd(int kind, int dtype, const void* a, int a_pix_stri
   return CSMRI_OK;
 }
 
+// ---- several mean losses in one launch (feature matching: one L1 per discriminator layer) ----
+#define LOSS_MULTI_BLOCKS 64
+struct LossItems { csmri_loss_item it[CSMRI_LOSS_MAX_ITEMS]; };
+extern "C" size_t csmri_loss_multi_work_bytes(int n) { return (size_t)n * LOSS_MULTI_BLOCKS * sizeof(double); }
+
+__global__ __launch_bounds__(256) void loss_multi_partial_kernel(int kind, int dt, const LossItems L, double* work) {
+  const csmri_loss_item& t = L.it[blockIdx.y];
+  const int nv = (t.C_real + 3) >> 2;
+  const unsigned total = (unsigned)(t.npix * nv);            // host: < 2^31
+  double acc = 0.0;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += LOSS_MULTI_BLOCKS * 256) {
+    const unsigned p = i / nv;
+    const int c = (int)(i - p * nv) * 4;
+    if (c + 4 <= t.C_real) {
+      f32x4_t x = load4(t.a, (long long)p * t.a_pix_stride + c, dt);
+      f32x4_t y = t.b ? load4(t.b, (long long)p * t.b_pix_stride + c, dt) : (f32x4_t){0, 0, 0, 0};
+      for (int q = 0; q < 4; ++q) { float d = x[q] - y[q]; acc += kind == 0 ? fabsf(d) : d * d; }
+    } else {
+      for (int q = 0; c + q < t.C_real; ++q) {
+        float d = load_elem(t.a, (long long)p * t.a_pix_stride + c + q, dt) -
+                  (t.b ? load_elem(t.b, (long long)p * t.b_pix_stride + c + q, dt) : 0.f);
+        acc += kind == 0 ? fabsf(d) : d * d;
+      }
+    }
+  }
+  double tot = block_sum(acc);
+  if (threadIdx.x == 0) work[blockIdx.y * LOSS_MULTI_BLOCKS + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(64) void loss_multi_final_kernel(const LossItems L, int n, const double* work, float* result) {
+  // lane i < n sums item i's partials in fixed order; lane 0 combines the weighted means in order
+  __shared__ double means[CSMRI_LOSS_MAX_ITEMS];
+  const int i = threadIdx.x;
+  if (i < n) {
+    double t = 0;
+    for (int k = 0; k < LOSS_MULTI_BLOCKS; ++k) t += work[i * LOSS_MULTI_BLOCKS + k];
+    means[i] = t / ((double)L.it[i].npix * (double)L.it[i].C_real);
+    result[1 + i] = (float)means[i];
+  }
+  __syncthreads();
+  if (i == 0) {
+    double tot = 0;
+    for (int k = 0; k < n; ++k) tot += (double)L.it[k].weight * means[k];
+    result[0] = (float)tot;
+  }
+}
+static int loss_items_ok(const csmri_loss_item* items, int n) {
+  if (!items || n < 1 || n > CSMRI_LOSS_MAX_ITEMS) return 0;
+  for (int i = 0; i < n; ++i)
+    if (!items[i].a || items[i].npix <= 0 || items[i].C_real <= 0 ||
+        items[i].npix * ((items[i].C > items[i].C_real ? items[i].C : items[i].C_real) + 3) >= (1ll << 31)) return 0;
+  return 1;
+}
+extern "C" int csmri_loss_multi(int kind, int dtype, const csmri_loss_item* items, int n, float* result,
+                                float* work, void* stream) {
+  CSMRI_CHECK_ARG(result && work && (kind == 0 || kind == 1) && loss_items_ok(items, n));
+  LossItems L;
+  for (int i = 0; i < n; ++i) L.it[i] = items[i];
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_multi_partial_kernel, dim3(LOSS_MULTI_BLOCKS, n), dim3(256), 0, st, kind, dtype, L,
+                     (double*)work);
+  CSMRI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_multi_final_kernel, dim3(1), dim3(64), 0, st, L, n, (const double*)work, result);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+__global__ void loss_multi_bwd_kernel(int kind, int dt, const LossItems L, const float* coeff) {
+  const csmri_loss_item& t = L.it[blockIdx.y];
+  const int nv = t.C >> 2;
+  const float k = (coeff ? coeff[0] : 1.f) * (t.weight / ((float)t.npix * (float)t.C_real));
+  const unsigned total = (unsigned)(t.npix * nv);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned p = i / nv;
+    const int c = (int)(i - p * nv) * 4;
+    f32x4_t x = load4(t.a, (long long)p * t.a_pix_stride + c, dt);
+    f32x4_t y = t.b ? load4(t.b, (long long)p * t.b_pix_stride + c, dt) : (f32x4_t){0, 0, 0, 0};
+    f32x4_t g;
+    for (int q = 0; q < 4; ++q) {
+      const float d = x[q] - y[q];
+      float v = kind == 0 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+      g[q] = (c + q < t.C_real) ? v * k : 0.f;
+    }
+    store4(t.ga, (long long)p * t.ga_pix_stride + c, dt, g);
+  }
+}
+extern "C" int csmri_loss_multi_bwd(int kind, int dtype, const csmri_loss_item* items, int n, const float* coeff,
+                                    void* stream) {
+  CSMRI_CHECK_ARG((kind == 0 || kind == 1) && loss_items_ok(items, n));
+  LossItems L;
+  for (int i = 0; i < n; ++i) { CSMRI_CHECK_ARG(items[i].ga && items[i].C % 4 == 0); L.it[i] = items[i]; }
+  hipLaunchKernelGGL(loss_multi_bwd_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, kind, dtype, L, coeff);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
 // BCE(sigmoid(l), t) with torch's log clamp at -100; one block (n is tiny: B*5*5)
 __global__ __launch_bounds__(256) void bce_logits_kernel(const float* l, long long n, float t, float* prob,
                                                          float* result) {

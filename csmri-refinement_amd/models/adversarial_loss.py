@@ -7,7 +7,11 @@ list of L1(f_fake, f_real.detach()).  LSGAN/WGAN are not used by the hot-path
 configs and raise."""
 import torch.nn as nn
 
+import os
+
 from csmri_hip import ops
+
+_FM_MULTI = os.environ.get('CSMRI_FM_MULTI', '1') != '0'     # A/B knob
 
 
 def get_adversarial_loss(conf, loss_name, cuda, loss_type):
@@ -49,7 +53,12 @@ class FeatureMatchingLoss(nn.Module):
   def forward(self, out_disc_fake, out_disc_real):
     ff, fr = out_disc_fake['features'], out_disc_real['features']
     chans = out_disc_fake['feature_channels']
+    n = len(ff)
+    if n <= 16 and len({f.dtype for f in ff}) == 1 and _FM_MULTI:
+      # every layer's distance in one launch pair (and one backward launch)
+      return ops.MultiMeanLoss.apply(self.kind, [self.sign / n] * n, list(chans), *ff,
+                                     *[b.detach() for b in fr])
     loss = 0
     for a, b, c in zip(ff, fr, chans):
       loss = loss + ops.MeanLoss.apply(a, b.detach(), self.kind, c)
-    return self.sign * loss / len(ff)
+    return self.sign * loss / n

@@ -310,6 +310,24 @@ size_t csmri_loss_work_bytes(void);
 int csmri_loss_bwd(int kind, int dtype, const void* a, int a_pix_stride, const void* b,
                    int b_pix_stride, long long npix, int C, int C_real, const float* coeff,
                    float weight, void* ga, int ga_pix_stride, int accumulate, void* stream);
+/* several mean losses in ONE launch pair: result[0] = sum_i weight_i * mean_i, result[1+i] = mean_i
+ * (FeatureMatchingLoss, models/adversarial_loss.py:133-160: one L1 per discriminator layer).
+ * items is a HOST array (copied into the kernel arguments), n <= CSMRI_LOSS_MAX_ITEMS;
+ * result: 1+n floats; work: csmri_loss_multi_work_bytes(n).  The backward writes
+ * ga_i = coeff[0] * weight_i / count_i * d(|a-b| or (a-b)^2)/da into items[i].ga (C padded channels). */
+#define CSMRI_LOSS_MAX_ITEMS 16
+typedef struct csmri_loss_item {
+  const void* a; const void* b;          /* b may be NULL (= 0) */
+  int a_pix_stride, b_pix_stride;
+  long long npix; int C, C_real;
+  float weight;
+  void* ga; int ga_pix_stride;           /* backward only */
+} csmri_loss_item;
+size_t csmri_loss_multi_work_bytes(int n);
+int csmri_loss_multi(int kind, int dtype, const csmri_loss_item* items, int n, float* result,
+                     float* work, void* stream);
+int csmri_loss_multi_bwd(int kind, int dtype, const csmri_loss_item* items, int n, const float* coeff,
+                         void* stream);
 /* BCE on sigmoid(logits) with constant target t (models/adversarial_loss.py:71-98,
  * F.binary_cross_entropy clamps log at -100): result[0] = mean. */
 int csmri_bce_logits(const float* logits, long long n, float target, float* prob,
