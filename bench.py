@@ -234,7 +234,8 @@ def main():
       'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-      'launch_mode': 'eager' if args.no_graphs else 'hipGraph replay (4 segments, collectives eager)',
+      'launch_mode': 'eager' if args.no_graphs else ('hipGraph replay (one graph per step)' if ws == 1 else
+                                                      'hipGraph replay (4 segments, collectives eager)'),
       'config': {'workload': 'C3/C4 2-refinement GAN step: frozen RecNet(3,3,32)+3 DC, UNET, CNNDiscriminator, '
                              'VGG19 loss, Adam x2; 256x256, 4x Cartesian, %d slices/GPU' % args.batch,
                  'per_gpu_batch': args.batch, 'global_batch': ws * args.batch,

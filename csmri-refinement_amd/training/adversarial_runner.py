@@ -348,8 +348,17 @@ class AdversarialRunner(BaseRunner):
     gc.collect()
     gc_was_enabled = gc.isenabled()
     gc.disable()
+    from training import distributed as dist_utils
+    if dist_utils.world_size() == 1:
+      # no collectives between the segments on a single GPU: one graph, three launch gaps fewer
+      def whole(st_):
+        for seg in (self._seg1, self._seg2, self._seg3, self._seg4):
+          seg(st_)
+      segments = (whole,)
+    else:
+      segments = (self._seg1, self._seg2, self._seg3, self._seg4)
     try:
-      for seg in (self._seg1, self._seg2, self._seg3, self._seg4):
+      for seg in segments:
         g = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
         with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None,
@@ -387,15 +396,18 @@ class AdversarialRunner(BaseRunner):
       G['pool'].external_plan = False
       G['pool'].prepare(G['pool'].buffer[:G['static']['inp'].shape[0]])
       G['pool'].external_plan = True
-    g1, g2, g3, g4 = G['graphs']
-    g1.replay()
-    self.disc_optimizer.start_allreduce()
-    g2.replay()
-    self.disc_optimizer.wait_allreduce()
-    g3.replay()
-    self.gen_optimizer.start_allreduce()
-    self.gen_optimizer.wait_allreduce()
-    g4.replay()
+    if len(G['graphs']) == 1:
+      G['graphs'][0].replay()
+    else:
+      g1, g2, g3, g4 = G['graphs']
+      g1.replay()
+      self.disc_optimizer.start_allreduce()
+      g2.replay()
+      self.disc_optimizer.wait_allreduce()
+      g3.replay()
+      self.gen_optimizer.start_allreduce()
+      self.gen_optimizer.wait_allreduce()
+      g4.replay()
     self.disc_optimizer.step_count += 1
     self.gen_optimizer.step_count += 1
     for m, d in G['bn_delta']:
