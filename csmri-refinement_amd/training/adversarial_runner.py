@@ -19,6 +19,7 @@ and the two VGG forwards run, and loss scalars stay on the device (one readback 
 logging interval instead of one blocking .data[0] per loss)."""
 from collections import OrderedDict
 import logging
+import os
 
 import torch
 
@@ -140,6 +141,8 @@ class AdversarialRunner(BaseRunner):
     self._last_metrics = None
     self.overlap_streams = False
     self._side_stream = None
+    self.third_pass_early = os.environ.get('CSMRI_THIRD_EARLY', '1') != '0'   # with vgg_early (single GPU)
+    self._side_stream3 = None
     self.vgg_early = None                 # None: decided at the first step (True on a single GPU)
     self.batch_disc_passes = True         # D(fake) and D(real) of the D phase as one grouped pass
 
@@ -232,6 +235,16 @@ class AdversarialRunner(BaseRunner):
       out_fake_d = self.disc(nhwc=in_fake)
       out_real = self.disc(nhwc=in_real)
     st['out_disc_real'] = out_real
+    st['out_disc_fake_early'] = None
+    if self.overlap_streams and self.vgg_early and self.third_pass_early:
+      # single GPU: the third D forward (reference :354-357; same D weights, it only has to
+      # follow the two passes above for the BatchNorm running statistics) runs on its own stream
+      # next to the D loss and backward below -- two chains of small kernels share the chip
+      if self._side_stream3 is None:
+        self._side_stream3 = torch.cuda.Stream()
+      self._side_stream3.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(self._side_stream3):
+        st['out_disc_fake_early'] = self._third_disc_pass(st)
     names, vals, disc_losses = [], [], []
     for name, criterion in self.disc_adv_criteria.items():
       loss = criterion(out_fake_d, out_real)
@@ -248,6 +261,15 @@ class AdversarialRunner(BaseRunner):
     st['names'], st['vals'] = names, vals
     if st['side_results']:                       # a segment (graph) ends with every stream joined
       torch.cuda.current_stream().wait_stream(self._side_stream)
+    if st['out_disc_fake_early'] is not None:
+      torch.cuda.current_stream().wait_stream(self._side_stream3)
+
+  def _third_disc_pass(self, st):
+    self.disc.set_wgrad(False)     # D's weight gradients of this pass are discarded (A-5)
+    out_fake = self.disc(nhwc=self.disc_input_fn(st['out_gen'], st['gen_inp0'], st['out_gen'],
+                                                 is_real_input=False, detach=False))
+    self.disc.set_wgrad(True)
+    return out_fake
 
   def _fork_vgg(self, st, out_gen, batch):
     """The VGG perceptual branch (big GEMMs) only needs the generator output: run it on a side
@@ -269,10 +291,9 @@ class AdversarialRunner(BaseRunner):
     if self.overlap_streams and not st['side_results']:
       self._fork_vgg(st, out_gen, batch)
       forked_here = True
-    self.disc.set_wgrad(False)     # D's weight gradients of this pass are discarded (A-5)
-    out_fake = self.disc(nhwc=self.disc_input_fn(out_gen, st['gen_inp0'], out_gen,
-                                                 is_real_input=False, detach=False))
-    self.disc.set_wgrad(True)
+    out_fake = st.get('out_disc_fake_early')
+    if out_fake is None:
+      out_fake = self._third_disc_pass(st)
     st['out_disc_fake'] = out_fake
     gen_losses = []
     for name, criterion in self.gen_adv_criteria.items():
