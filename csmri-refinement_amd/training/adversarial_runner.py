@@ -312,7 +312,15 @@ class AdversarialRunner(BaseRunner):
     st['total_gen'] = self._weighted_total(gen_losses, self.gen_loss_weights)
 
   def _seg3(self, st):
-    self.disc_optimizer.apply()
+    if st.get('out_disc_fake_early') is not None:
+      # the third D pass lives on its own stream: run D's Adam there too.  Only that pass's
+      # backward (data gradients through the UPDATED D, ordering A) needs the new weights; the
+      # VGG backward and the rest of the generator backward start without waiting for it.
+      self._side_stream3.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(self._side_stream3):
+        self.disc_optimizer.apply()
+    else:
+      self.disc_optimizer.apply()
     self.gen_optimizer.zero_grad()
     ops.enable_wgrad_stream(self.overlap_streams)
     st['total_gen'].backward()
