@@ -48,6 +48,7 @@ def _worker(rank, world, port, q, graphs):
   class Loader(list):
     batch_size = 2
   torch.manual_seed(100 + rank)                        # per-rank dropout / pool draws
+  runner.overlap_streams = bool(graphs)                # side streams (VGG branch, weight gradients) too
   if graphs:
     runner.enable_graphs(mine)
   runner.train_epoch(Loader([mine, mine]), 1)
