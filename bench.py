@@ -128,6 +128,7 @@ def roofline(runner, loader, steps=2):
   import torch
   from csmri_hip import ops
   runner.disable_graphs()       # per-launch events need eager launches
+  runner.overlap_streams = False  # ... on ONE stream: concurrent side-stream kernels would inflate the brackets
   ops.PROFILE = []
   runner.train_epoch(DeviceLoader(loader.batches, steps), 1)
   torch.cuda.synchronize()
