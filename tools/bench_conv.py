@@ -23,6 +23,8 @@ CASES = {
     'disc6': (1024, 1024, 4, 1, 'reflection', False, 8, 8, 8),
     'u32x64': (32, 64, 4, 1, 'reflection', False, 256, 256, 8),
     'u32x64z': (32, 64, 4, 1, 'zero', False, 259, 259, 8),
+    'vgg5_2b16': (512, 512, 3, 1, 'zero', False, 16, 16, 16),
+    'vgg4_2b16': (512, 512, 3, 1, 'zero', False, 32, 32, 16),
     'rec_first': (2, 32, 3, 1, 'zero', False, 256, 256, 8),
     'rec_last': (32, 2, 3, 1, 'zero', False, 256, 256, 8),
 }
