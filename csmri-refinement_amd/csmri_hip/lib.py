@@ -129,6 +129,8 @@ _SIGS = {
     'csmri_bce_logits': (i32, [vp, i64, f32, vp, vp, vp]),
     'csmri_bce_logits_bwd': (i32, [vp, i64, f32, vp, f32, vp, i32, vp]),
     'csmri_psnr_mse': (i32, [vp, vp, i32, i64, vp, vp]),
+    'csmri_ssim_work_bytes': (sz, [i32, i32, i32]),
+    'csmri_ssim': (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     'csmri_adam': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
     'csmri_adam_dev': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp]),
     'csmri_fill_f32': (i32, [vp, i64, f32, vp]),

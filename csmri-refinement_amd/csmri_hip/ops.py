@@ -1007,6 +1007,18 @@ def psnr_mse(pred, target):
   return buf[:b]
 
 
+def ssim(pred, target):
+  """per-image SSIM of clamp(|.|,0,1) (11x11 gaussian window); pred/target interleaved complex
+  [B,H,W,2] fp32.  Returns a [B] fp32 tensor."""
+  _need_gpu(pred)
+  b, h, w, _ = pred.shape
+  out = torch.empty(b, dtype=torch.float32, device=pred.device)
+  work = torch.empty(lib.raw('csmri_ssim_work_bytes')(b, h, w) // 8, dtype=torch.float64, device=pred.device)
+  lib.call('csmri_ssim', pred.contiguous().float().data_ptr(), target.contiguous().float().data_ptr(), b, h, w,
+           out.data_ptr(), work.data_ptr(), stream())
+  return out
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
   """In-place Adam on flat fp32 buffers."""
   lib.call('csmri_adam', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),

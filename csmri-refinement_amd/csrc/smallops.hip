@@ -454,6 +454,95 @@ extern "C" int csmri_psnr_mse(const float* pred, const float* target, int B, lon
   return CSMRI_OK;
 }
 
+// ---------------------------------------------------------------------- SSIM ----
+// SSIM of clamp(|pred|,0,1) vs clamp(|target|,0,1) per image (metrics/pytorch_ssim/__init__.py:22-42
+// through metrics/image_metrics.py:22-42): 11x11 gaussian window (sigma 1.5), zero padding,
+// C1 = 0.01^2, C2 = 0.03^2, mean of the SSIM map.  One workgroup per 16x16 tile: the magnitudes of
+// the tile plus a 5-pixel halo go to LDS once, the five windowed moments are computed separably
+// (row pass into LDS, column pass in registers), the tile's map values are summed in fixed order.
+#define SSIM_R 5
+#define SSIM_T 16
+#define SSIM_P (SSIM_T + 2 * SSIM_R)
+struct SsimWin { float g[2 * SSIM_R + 1]; };
+__global__ __launch_bounds__(256) void ssim_tile_kernel(const float2* pred, const float2* tgt, int H, int W,
+                                                        int tiles_x, int tiles_y, const SsimWin win, double* part) {
+  __shared__ float a[SSIM_P][SSIM_P + 1], b[SSIM_P][SSIM_P + 1];
+  __shared__ float hrow[5][SSIM_P][SSIM_T + 1];
+  const int img = blockIdx.y, tile = blockIdx.x;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int y0 = ty * SSIM_T - SSIM_R, x0 = tx * SSIM_T - SSIM_R;
+  const float2* pi = pred + (size_t)img * H * W;
+  const float2* ti = tgt + (size_t)img * H * W;
+  for (int e = threadIdx.x; e < SSIM_P * SSIM_P; e += 256) {
+    const int r = e / SSIM_P, c = e - r * SSIM_P, y = y0 + r, x = x0 + c;
+    float va = 0.f, vb = 0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+      const float2 p = pi[(size_t)y * W + x], t = ti[(size_t)y * W + x];
+      va = fminf(fmaxf(sqrtf(p.x * p.x + p.y * p.y), 0.f), 1.f);
+      vb = fminf(fmaxf(sqrtf(t.x * t.x + t.y * t.y), 0.f), 1.f);
+    }
+    a[r][c] = va; b[r][c] = vb;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < SSIM_P * SSIM_T; e += 256) {      // row pass
+    const int r = e / SSIM_T, c = e - r * SSIM_T;
+    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k <= 2 * SSIM_R; ++k) {
+      const float g = win.g[k], va = a[r][c + k], vb = b[r][c + k];
+      m1 += g * va; m2 += g * vb; e11 += g * (va * va); e22 += g * (vb * vb); e12 += g * (va * vb);
+    }
+    hrow[0][r][c] = m1; hrow[1][r][c] = m2; hrow[2][r][c] = e11; hrow[3][r][c] = e22; hrow[4][r][c] = e12;
+  }
+  __syncthreads();
+  const int r = threadIdx.x / SSIM_T, c = threadIdx.x - r * SSIM_T;     // column pass: one pixel per thread
+  float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+  for (int k = 0; k <= 2 * SSIM_R; ++k) {
+    const float g = win.g[k];
+    m1 += g * hrow[0][r + k][c]; m2 += g * hrow[1][r + k][c]; e11 += g * hrow[2][r + k][c];
+    e22 += g * hrow[3][r + k][c]; e12 += g * hrow[4][r + k][c];
+  }
+  double v = 0.0;
+  if (ty * SSIM_T + r < H && tx * SSIM_T + c < W) {
+    const float mu1_sq = m1 * m1, mu2_sq = m2 * m2, mu12 = m1 * m2;
+    const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+    const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+    v = (double)(((2.f * mu12 + c1) * (2.f * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2)));
+  }
+  const double tot = block_sum(v);
+  if (threadIdx.x == 0) part[(size_t)img * tiles_x * tiles_y + tile] = tot;
+}
+__global__ __launch_bounds__(256) void ssim_final_kernel(const double* part, int ntiles, double inv_hw, float* out) {
+  double t = 0;
+  for (int i = threadIdx.x; i < ntiles; i += 256) t += part[(size_t)blockIdx.x * ntiles + i];
+  t = block_sum(t);
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)(t * inv_hw);
+}
+extern "C" size_t csmri_ssim_work_bytes(int B, int H, int W) {
+  return (size_t)B * ((H + SSIM_T - 1) / SSIM_T) * ((W + SSIM_T - 1) / SSIM_T) * sizeof(double);
+}
+extern "C" int csmri_ssim(const float* pred, const float* target, int B, int H, int W, float* ssim, void* work,
+                          void* stream) {
+  CSMRI_CHECK_ARG(pred && target && ssim && work && B > 0 && H > 0 && W > 0);
+  SsimWin win;
+  float sum = 0.f;                       // the reference builds the window in float32 (torch.Tensor)
+  for (int k = 0; k <= 2 * SSIM_R; ++k) {
+    win.g[k] = (float)exp(-(double)((k - SSIM_R) * (k - SSIM_R)) / (2.0 * 1.5 * 1.5));
+    sum += win.g[k];
+  }
+  for (int k = 0; k <= 2 * SSIM_R; ++k) win.g[k] /= sum;
+  const int tx = (W + SSIM_T - 1) / SSIM_T, ty = (H + SSIM_T - 1) / SSIM_T;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ssim_tile_kernel, dim3(tx * ty, B), dim3(256), 0, st, (const float2*)pred, (const float2*)target,
+                     H, W, tx, ty, win, (double*)work);
+  CSMRI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ssim_final_kernel, dim3(B), dim3(256), 0, st, (const double*)work, tx * ty,
+                     1.0 / ((double)H * (double)W), ssim);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
 // -------------------------------------------------------------------- Adam ----
 // torch.optim.Adam (2.x): denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= lr/(1-b1^t) * m/denom
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr,

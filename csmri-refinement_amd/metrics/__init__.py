@@ -107,6 +107,21 @@ class PSNRMetric(object):
     return MaxMetric(psnr.mean())
 
 
+class SSIMMetric(object):
+  """MetricFunction('ssim') of the reference (metrics/__init__.py:139, image_metrics.py:22-42,
+  pytorch_ssim/__init__.py:22-42): per image on clamp(|.|,0,1), gaussian 11x11 window; mean
+  over the batch.  One tile kernel + one per-image sum."""
+
+  def __call__(self, prediction, target, transform=True):
+    if isinstance(prediction, dict):
+      fast = prediction.get('_nhwc')
+      prediction = fast['pred'] if fast is not None else prediction['pred']
+    if isinstance(target, dict):
+      target = target['target']
+    vals = ops.ssim(_complex_nhwc(prediction), _complex_nhwc(target))
+    return MaxMetric(vals.double().mean())
+
+
 class DiscAccuracyMetric(object):
   """disc_accuracy (scalar_metrics.py:26-53): per-image mean probability, class =
   p > 0.5, accuracy against label 0 (fake) and/or 1 (real)."""
@@ -129,11 +144,13 @@ def get_metric_fn(conf, metric_name, cuda, mode, pred_key='pred', target_key='ta
   assert mode in ('train', 'test')
   if metric_name == 'psnr':
     return PSNRMetric()
+  if metric_name == 'ssim':
+    return SSIMMetric()
   if metric_name in ('binary_accuracy', 'accuracy_fake'):
     return DiscAccuracyMetric(True, False)
   if metric_name == 'accuracy_real':
     return DiscAccuracyMetric(False, True)
   if metric_name == 'accuracy':
     return DiscAccuracyMetric(True, True)
-  raise NotImplementedError("metric '%s' is outside the hot path (SURVEY 8f: SSIM is a 'next' row)"
+  raise NotImplementedError("metric '%s' is outside the hot path (SURVEY 8f: hfen / segmentation scores)"
                             % metric_name)

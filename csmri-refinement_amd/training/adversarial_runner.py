@@ -40,7 +40,7 @@ def build_runner(conf, cuda, mode):
   gen_conf = Configuration.from_dict(conf.generator_model, conf)
   gen_model = construct_model(gen_conf, gen_conf.name, cuda)
   val_metric_fns = {name: get_metric_fn(conf, name, cuda, 'test')
-                    for name in conf.get_attr('validation_metrics', default=[]) if name == 'psnr'}
+                    for name in conf.get_attr('validation_metrics', default=[])}
   if mode != 'train':
     gen_model = utils.cudaify(gen_model, cuda)
     return AdversarialRunner(gen_model, cuda=cuda, val_metric_fns=val_metric_fns)

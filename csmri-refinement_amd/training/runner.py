@@ -19,8 +19,7 @@ def build_runner(conf, cuda, mode='train'):
   model_conf = Configuration.from_dict(conf.model, conf)
   model = construct_model(model_conf, model_conf.name, cuda)
   val_metric_fns = {name: get_metric_fn(conf, name, cuda, 'test')
-                    for name in conf.get_attr('validation_metrics', default=[])
-                    if name in ('psnr',)}
+                    for name in conf.get_attr('validation_metrics', default=[])}
   model = utils.cudaify(model, cuda)
   if mode != 'train':
     return Runner(model, cuda=cuda, val_metric_fns=val_metric_fns)

@@ -339,6 +339,13 @@ int csmri_bce_logits_bwd(const float* logits, long long n, float target, const f
  * hold B*33 floats (the tail is the per-image partial-sum workspace). */
 int csmri_psnr_mse(const float* pred, const float* target, int B, long long HW,
                    float* mse, void* stream);
+/* SSIM validation metric (metrics/image_metrics.py:22-42 -> metrics/pytorch_ssim/__init__.py:22-42,
+ * with the output transform of rec_transforms.py:79-85): per image, on clamp(|.|,0,1) of the
+ * interleaved-complex [B,H,W,2] fp32 inputs, 11x11 gaussian window (sigma 1.5), zero padding;
+ * ssim[b] = mean of the SSIM map.  work: csmri_ssim_work_bytes(B,H,W). */
+size_t csmri_ssim_work_bytes(int B, int H, int W);
+int csmri_ssim(const float* pred, const float* target, int B, int H, int W, float* ssim, void* work,
+               void* stream);
 
 /* Adam (training/optimizers.py:19-22 -> torch.optim.Adam, eps 1e-8, no decay) on a
  * flat fp32 parameter buffer; step is the 1-based step count. */

@@ -519,6 +519,38 @@ def psnr_batch(pred, target):
   return float(np.mean(vals))
 
 
+def ssim_window(window_size=11, sigma=1.5):
+  """Normalised 1-D gaussian and its outer product (metrics/pytorch_ssim/__init__.py:12-20)."""
+  g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2))
+                    for x in range(window_size)], dtype=torch.float32)
+  g = g / g.sum()
+  return g, g.unsqueeze(1).mm(g.unsqueeze(0)).float()
+
+
+def ssim_images(pred, target, window_size=11):
+  """MetricFunction(ssim) per image: clamp(|.|,0,1) (rec_transforms.py:79-85), then
+  pytorch_ssim.ssim (metrics/pytorch_ssim/__init__.py:22-42, image_metrics.py:22-42): gaussian
+  11x11 window, zero padding, C1 = 0.01^2, C2 = 0.03^2, mean of the SSIM map.  Returns the
+  list of per-image values (their mean is the batch metric, metrics/__init__.py:38-72)."""
+  p = torch.clamp(complex_abs(pred), 0.0, 1.0)
+  t = torch.clamp(complex_abs(target), 0.0, 1.0)
+  _, w2 = ssim_window(window_size)
+  w = w2[None, None]
+  pad = window_size // 2
+  vals = []
+  for i in range(p.shape[0]):
+    a, b = p[i:i + 1], t[i:i + 1]
+    mu1, mu2 = F.conv2d(a, w, padding=pad), F.conv2d(b, w, padding=pad)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = F.conv2d(a * a, w, padding=pad) - mu1_sq
+    s2 = F.conv2d(b * b, w, padding=pad) - mu2_sq
+    s12 = F.conv2d(a * b, w, padding=pad) - mu12
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))
+    vals.append(float(m.mean()))
+  return vals
+
+
 def binary_accuracy_fake(prob_fake):
   """disc metric 'binary_accuracy' = accuracy on the fake batch:
   per-image mean prob, class = prob > .5, target 0.  scalar_metrics.py:11-53."""

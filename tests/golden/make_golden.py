@@ -10,7 +10,7 @@ the reference's source is stored -- only data.
 
 Fixtures: F1 synthetic batch + mask rows, F2 DC fwd/adjoint,
 F3 RecNet fwd/loss/grads/Adam steps, F4 RefinementWrapper, F5 discriminator,
-F6 VGG loss, F7 full GAN train steps, F8 PSNR.
+F6 VGG loss, F7 full GAN train steps, F8 PSNR, F9 SSIM.
 """
 import collections
 import collections.abc
@@ -530,8 +530,32 @@ def f8():
   save('F8_psnr', pred=pred.numpy(), target=target.numpy(), psnr=np.float64(val))
 
 
+# ------------------------------------------------------------------ F9 ----
+# SSIM validation metric: the reference's MetricFunction('ssim') on a batch.
+# metrics/image_metrics.py:41 reads `.data[0]` of a 0-dim tensor (torch-0.3 idiom): only that
+# read is replaced; the arithmetic is the reference's own metrics/pytorch_ssim module.
+
+
+def f9():
+  from metrics import pytorch_ssim as ref_ssim
+  ref_image_metrics.compute_ssim = \
+      lambda p, t, window_size=11: float(ref_ssim.ssim(p, t, window_size=window_size).item())
+  conf = _gan_conf()
+  fn = ref_metrics.get_metric_fn(conf, 'ssim', '', 'test')
+  g = torch.Generator().manual_seed(9)
+  yy, xx = torch.meshgrid(torch.linspace(-1, 1, 48), torch.linspace(-1, 1, 48), indexing='ij')
+  base = torch.exp(-3.0 * (xx ** 2 + yy ** 2))[None, None] * torch.rand(3, 1, 1, 1, generator=g)
+  target = torch.cat([base + 0.05 * torch.rand(3, 1, 48, 48, generator=g),
+                      0.02 * torch.randn(3, 1, 48, 48, generator=g)], 1) * 1.1
+  pred = target + 0.05 * torch.randn(3, 2, 48, 48, generator=g)
+  per_image = [fn({'pred': pred[i:i + 1]}, {'target': target[i:i + 1]}).value for i in range(3)]
+  val = fn({'pred': pred}, {'target': target}).value
+  save('F9_ssim', pred=pred.numpy(), target=target.numpy(), ssim=np.float64(val),
+       ssim_per_image=np.array(per_image, dtype=np.float64))
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9']
   for name in which:
     print('==', name)
     globals()[name]()

@@ -5,6 +5,7 @@ bf16 path: relative L2 error <= 1e-2 (inputs and weights are rounded to bf16
 before the oracle runs so only accumulation order / output rounding differ).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -14,6 +15,7 @@ import torch.nn.functional as F
 import csmri_oracle as O
 
 pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
 @pytest.fixture(scope='module')
@@ -339,3 +341,20 @@ def test_small_ops(hip):
     opt.step()
     ops.adam_step(pd, gr.cuda(), m, v, 2e-4, 0.5, 0.999, 1e-8, step)
   assert torch.allclose(pd.cpu(), pt.detach(), atol=1e-7, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_ssim_vs_reference_golden_and_oracle(hip):
+  """csmri_ssim against the reference's own values (F9) and the oracle on a
+  256x256 batch; fp32, tolerance 2e-5 absolute on values in [0, 1]."""
+  from csmri_hip import ops
+  f = np.load(os.path.join(GOLDEN, 'F9_ssim.npz'))
+  pred, target = torch.from_numpy(f['pred']), torch.from_numpy(f['target'])
+  got = ops.ssim(pred.permute(0, 2, 3, 1).contiguous().cuda(), target.permute(0, 2, 3, 1).contiguous().cuda())
+  assert np.allclose(got.cpu().numpy(), f['ssim_per_image'], rtol=0, atol=2e-5), (got, f['ssim_per_image'])
+  g = torch.Generator().manual_seed(3)
+  t2 = torch.rand(2, 2, 256, 200, generator=g)
+  p2 = t2 + 0.1 * torch.randn(2, 2, 256, 200, generator=g)
+  want = O.ssim_images(p2, t2)
+  got2 = ops.ssim(p2.permute(0, 2, 3, 1).contiguous().cuda(), t2.permute(0, 2, 3, 1).contiguous().cuda())
+  assert np.allclose(got2.cpu().numpy(), want, rtol=0, atol=2e-5), (got2, want)

@@ -489,3 +489,56 @@ def test_grouped_disc_pass_equals_two_passes(env, dtype, size, small):
       close(s2[k], s1[k], k)
     if 'num_batches_tracked' in k:
       assert int(s1[k]) == int(s2[k]) == 2, k
+
+
+@pytest.mark.gpu
+def test_validation_path_eval_mode_psnr_ssim_fp32(env):
+  """AdversarialRunner.validate (reference training/base_runner.py:86-108,
+  adversarial_runner.py:527-557,588-597) -- generator and discriminator in eval mode (BatchNorm on
+  its running statistics), PSNR + SSIM validation metrics, generator validation losses -- against
+  the oracle run with the same weights and (perturbed, non-trivial) running statistics."""
+  Configuration, set_dtype = env
+  from training import build_runner
+  from csmri_hip import ops
+  f = load('F7_gan_step')
+  set_dtype('fp32')
+  conf = gan_conf(Configuration, 'fp32')
+  assert list(conf.validation_metrics) == ['psnr', 'ssim']
+  runner = build_runner(conf, 'adversarial', '0', 'train')
+  g = torch.Generator().manual_seed(21)
+  sg, sd_ = sub(f, 'G0.'), sub(f, 'D0.')
+  for state in (sg, sd_):
+    for k in state:
+      if k.endswith('running_mean'):
+        state[k] = 0.1 * torch.randn(state[k].shape, generator=g)
+      elif k.endswith('running_var'):
+        state[k] = 0.5 + torch.rand(state[k].shape, generator=g)
+  runner.gen.load_state_dict(sg)
+  runner.disc.load_state_dict(sd_)
+  ops.bump_weight_epoch()
+  batch = O.synth_batch(2, 128, 128, acc=4, seed=77)
+  data, losses, metrics = runner.validate(Loader([batch]), num_batches_to_return=1)
+  PG = {k: v for k, v in sg.items() if 'running' not in k and 'num_batches' not in k}
+  SG = {k: v.clone() for k, v in sg.items() if 'running' in k}
+  want = O.refinement_forward(PG, SG, batch['inp'], batch['kspace'], batch['mask'], training=False)
+  pred = data[0][1]['pred'] if isinstance(data[0], (tuple, list)) else data[0]['pred']
+  err = float((pred.float().cpu() - want['pred']).abs().max())
+  assert err < 2e-5, err
+  psnr_o = O.psnr_batch(want['pred'], batch['target'])
+  ssim_o = float(np.mean(O.ssim_images(want['pred'], batch['target'])))
+  print('val psnr hip %.5f oracle %.5f   ssim hip %.6f oracle %.6f'
+        % (metrics['gen_psnr'].value, psnr_o, metrics['gen_ssim'].value, ssim_o))
+  assert abs(metrics['gen_psnr'].value - psnr_o) < 1e-3
+  assert abs(metrics['gen_ssim'].value - ssim_o) < 2e-5
+  fp_o = float(O.feature_penalty(want))
+  assert abs(losses['gen_loss_FeaturePenalty'].value - fp_o) < 1e-5 * max(1.0, abs(fp_o))
+  # discriminator in eval mode on the real target
+  small_disc = dict(O.DISC_CONF, filters=[8, 16, 32, 64, 64, 64])
+  PD = {k: v for k, v in sd_.items() if 'running' not in k and 'num_batches' not in k}
+  SD = {k: v.clone() for k, v in sd_.items() if 'running' in k}
+  runner._set_test()
+  with torch.no_grad():
+    x_real = O.complex_abs(batch['target'])
+    got = runner.disc(inp=x_real.cuda())
+    wantd = O.disc_forward(PD, SD, x_real, False, small_disc)
+  assert float((got['logits'].cpu() - wantd['logits']).abs().max()) < 2e-4 * max(1.0, float(wantd['logits'].abs().max()))

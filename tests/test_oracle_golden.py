@@ -268,3 +268,11 @@ def test_f8_psnr():
   f = load('F8_psnr')
   v = O.psnr_batch(T(f['pred']), T(f['target']))
   assert abs(v - float(f['psnr'])) < 1e-6
+
+
+def test_f9_ssim():
+  """SSIM validation metric against the reference's own pytorch_ssim."""
+  f = load('F9_ssim')
+  vals = O.ssim_images(T(f['pred']), T(f['target']))
+  assert np.allclose(vals, f['ssim_per_image'], rtol=0, atol=2e-6), (vals, f['ssim_per_image'])
+  assert abs(float(np.mean(vals)) - float(f['ssim'])) < 2e-6
