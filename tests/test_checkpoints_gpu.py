@@ -1,0 +1,92 @@
+"""checkpoint save / restore and the pretrained-weights hand-off that chains the
+RecNet run (1-recnet) into the refinement run (2-refinement), reference utils/checkpoints.py:9-41,
+96-121 and configs/2-refinement.json:29 -- same pickle layout {'conf','runner','epoch',
+'best_val_metrics'}, runner state under 'model' / 'generator','discriminator','gen_optimizer',
+'disc_optimizer', state-dict keys of the reference (SURVEY A-12)."""
+import os
+
+import pytest
+import torch
+
+import csmri_oracle as O
+from conftest import PKG
+
+pytestmark = pytest.mark.gpu
+
+
+class Loader(list):
+  batch_size = 2
+
+
+def _confs(tmp_path, dtype='fp32'):
+  from utils.config import Configuration
+  from models.utils import set_default_compute_dtype
+  set_default_compute_dtype(dtype)
+  c1 = Configuration.from_json(os.path.join(PKG, 'configs', '1-recnet.json'))
+  c1.batch_size = 2
+  c1.model['num_blocks'], c1.model['num_filters'], c1.model['compute_dtype'] = 3, 8, dtype
+  c2 = Configuration.from_json(os.path.join(PKG, 'configs', '2-refinement.json'))
+  c2.batch_size = 2
+  c2.vgg_loss = {'seed': 19}
+  g, d = c2.generator_model, c2.discriminator_model
+  g['pretrained_model'].update(num_filters=8, compute_dtype=dtype)
+  g['learnable_model'].update(encode_filters=[8, 16, 32], decode_filters=[16, 8], compute_dtype=dtype)
+  d.update(num_filters_per_layer=[8, 16, 32, 64, 64, 64], compute_dtype=dtype)
+  return c1, c2
+
+
+def test_recnet_checkpoint_feeds_refinement_pretrained_model(tmp_path):
+  import csmri_hip  # noqa: F401
+  from training import build_runner
+  from utils.checkpoints import save_checkpoint
+  c1, c2 = _confs(tmp_path)
+  r1 = build_runner(c1, 'standard', '0', 'train')
+  r1.train_epoch(Loader([O.synth_batch(2, 128, 128, acc=4, seed=5)]), 1)
+  path = str(tmp_path / 'recnet_0001.pth')
+  save_checkpoint(path, c1, r1, 1, None)
+  ck = torch.load(path, map_location='cpu', weights_only=False)
+  assert sorted(ck) == ['best_val_metrics', 'conf', 'epoch', 'runner'] and 'model' in ck['runner']
+  c2.generator_model['pretrained_model']['pretrained_weights'] = [path, 'model']
+  r2 = build_runner(c2, 'adversarial', '0', 'train')
+  want = r1.model.state_dict()
+  got = r2.gen.pretrained_model.state_dict()
+  assert sorted(want) == sorted(got)
+  for k in want:
+    assert torch.equal(want[k].cpu(), got[k].cpu()), k
+  assert all(not p.requires_grad for p in r2.gen.pretrained_model.parameters())
+
+
+def test_adversarial_checkpoint_resume_is_exact(tmp_path):
+  """train 1 step -> save -> restore into a fresh runner -> both continue with the same batch
+  and the same injected randomness: identical losses and parameters (kernels are deterministic)."""
+  import csmri_hip  # noqa: F401
+  from training import build_runner
+  from utils.checkpoints import save_checkpoint, restore_checkpoint
+  _, c2 = _confs(tmp_path)
+  batches = [O.synth_batch(2, 128, 128, acc=4, seed=s) for s in (6, 7)]
+  a = build_runner(c2, 'adversarial', '0', 'train')
+  a.train_epoch(Loader(batches[:1]), 1)
+  path = str(tmp_path / 'gan_0001.pth')
+  save_checkpoint(path, c2, a, 1, {'psnr': 1.0})
+  ck = torch.load(path, map_location='cpu', weights_only=False)
+  assert sorted(ck['runner']) == ['disc_optimizer', 'discriminator', 'gen_optimizer', 'generator']
+  b = build_runner(c2, 'adversarial', '0', 'train')
+  conf, epoch, best = restore_checkpoint(path, b)
+  assert epoch == 1 and best == {'psnr': 1.0}
+  g = torch.Generator().manual_seed(4)
+  chans = [f for _, bn, drop, f in a.disc._layers if bn is not None and drop]
+  masks = [(torch.rand(2, c, generator=g) < 0.5).float() * 2.0 for _ in range(3) for c in chans]
+  outs = []
+  for r in (a, b):
+    r.disc.injected_dropout = [m.clone() for m in masks]
+    pool = getattr(r.disc_input_fn, 'image_pool', None)
+    if pool is not None:
+      import random
+      random.seed(123)
+    torch.manual_seed(99)
+    losses, _ = r.train_epoch(Loader(batches[1:]), 2)
+    outs.append({k: v.value for k, v in losses.items()})
+  assert outs[0] == outs[1], (outs[0], outs[1])
+  for (n, p), (_, q) in zip(list(a.gen.state_dict().items()) + list(a.disc.state_dict().items()),
+                            list(b.gen.state_dict().items()) + list(b.disc.state_dict().items())):
+    assert torch.equal(p.cpu(), q.cpu()), n
