@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
   constexpr int TILE_Q = BM * 128, BUF = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
   const int t = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
   // an XCD owns a contiguous run of t: make the operand that is re-read across that run the small one
@@ -63,9 +63,15 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
   int k0 = s_begin * 64;
   int tap = k0 / p.Cin, ci = k0 - tap * p.Cin;
   int ty = tap / p.TW, tx = tap - ty * p.TW;
-  int pix[GA];
-  auto compute_pix = [&]() {
+  // Per-row source pointers, recomputed only when the tap or the concat source changes (every
+  // Cin/64 or c0/64 steps); in between a step costs one 64-bit add per LDS-DMA: the kernel used to
+  // spend 3 vector instructions per MFMA on rebuilding these addresses every step.
+  const char* aptr[GA]; unsigned ainc[GA];
+  auto compute_ptrs = [&]() {
     const int oy_ = ty * p.dys, ox_ = tx * p.dxs;
+    const bool second = ci >= p.c0;                     // wave-uniform: c0 % 64 == 0
+    const char* src = second ? p.in1 + (size_t)(ci - p.c0 + chunk * 8) * 2 : p.in0 + (size_t)(ci + chunk * 8) * 2;
+    const size_t ps = (size_t)(second ? p.ps1 : p.ps0) * 2;
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
       int u = by[j] + oy_, v = bx[j] + ox_;
@@ -73,30 +79,32 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
       if (p.border == CSMRI_BORDER_REFLECT) { u = reflect_idx(u, Hv); v = reflect_idx(v, Wv); }
       else ok = ok && (unsigned)u < (unsigned)Hv && (unsigned)v < (unsigned)Wv;
       if (p.ups) { u >>= 1; v >>= 1; }
-      pix[j] = ok ? ib[j] + u * p.Win + v : -1;
+      const int pix = ib[j] + u * p.Win + v;
+      aptr[j] = ok ? src + (size_t)pix * ps : g_zero_page;
+      ainc[j] = ok ? 128u : 0u;
     }
   };
-  compute_pix();
-  const char* wrow[GB];
+  compute_ptrs();
+  const char* wptr[GB];
 #pragma unroll
   for (int j = 0; j < GB; ++j)
-    wrow[j] = p.w + ((size_t)cls * (size_t)p.wcs + (size_t)(n0 + (j * 4 + wid) * 8 + lrow) * p.Kp + chunk * 8) * 2;
+    wptr[j] = p.w + ((size_t)cls * (size_t)p.wcs + (size_t)(n0 + (j * 4 + wid) * 8 + lrow) * p.Kp + chunk * 8) * 2 +
+              (size_t)s_begin * 128;
 
   auto issue = [&](int s, char* buf) {
-    const bool second = ci >= p.c0;                     // wave-uniform: c0 % 64 == 0
-    const char* src = second ? p.in1 + (size_t)(ci - p.c0 + chunk * 8) * 2 : p.in0 + (size_t)(ci + chunk * 8) * 2;
-    const size_t ps = (size_t)(second ? p.ps1 : p.ps0) * 2;
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
-      const char* g = pix[j] >= 0 ? src + (size_t)pix[j] * ps : g_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(buf + (j * 4 + wid) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(buf + (j * 4 + wid) * 1024), 16, 0, 0);
+      aptr[j] += ainc[j];
     }
 #pragma unroll
-    for (int j = 0; j < GB; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wrow[j] + (size_t)s * 128),
-                                       (lptr_t)(buf + TILE_Q + (j * 4 + wid) * 1024), 16, 0, 0);
+    for (int j = 0; j < GB; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(buf + TILE_Q + (j * 4 + wid) * 1024), 16, 0, 0);
+      wptr[j] += 128;
+    }
     ci += 64;
-    if (ci == p.Cin) { ci = 0; if (++tx == p.TW) { tx = 0; ++ty; } compute_pix(); }
+    if (ci == p.Cin) { ci = 0; if (++tx == p.TW) { tx = 0; ++ty; } compute_ptrs(); }
+    else if (ci == p.c0) compute_ptrs();                // switch to the second concat source
   };
 
   f32x4_t acc[FN][FM];
