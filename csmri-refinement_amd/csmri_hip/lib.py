@@ -96,6 +96,7 @@ _SIGS = {
                                   i32, vp, i32, f32, vp]),
     'csmri_fold_halo': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, f32, vp]),
     'csmri_dc': (i32, [vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
+    'csmri_undersample': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     'csmri_dc_work_bytes': (sz, [i32, i32, i32]),
     'csmri_nchw_to_nhwc': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),
     'csmri_nhwc_to_nchw': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),

@@ -780,6 +780,19 @@ def copy_channels(x, c_dst, dtype=None):
   return out
 
 
+def undersample(img, mask_u8):
+  """Forward model on the device: img interleaved complex fp32 [B,H,W,2], mask uint8 [B,H,W]
+  -> (kspace, inp), both [B,H,W,2] fp32: kspace = m*FFT2(img), inp = IFFT2(kspace) (ortho)."""
+  _need_gpu(img)
+  img = img.contiguous().float()
+  b, h, w, _ = img.shape
+  ks = torch.empty(b, h, w, 2, dtype=torch.float32, device=img.device)
+  inp = torch.empty(b, h, w, 2, dtype=torch.float32, device=img.device)
+  lib.call('csmri_undersample', img.data_ptr(), mask_u8.contiguous().data_ptr(), ks.data_ptr(), inp.data_ptr(),
+           b, h, w, stream())
+  return ks, inp
+
+
 def dc_raw(x, k0, mask_u8, pad_dtype=None):
   """x: interleaved complex fp32 [B,H,W,2] or channels 0,1 of a [B,H,W,8] fp32
   conv output; k0: dense [B,H,W,2]; mask uint8 [B,H,W].  Returns (out [B,H,W,2]

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(
 // pass 2: per strip of DC_T columns: FFT along H, merge, inverse FFT along H.
 __global__ __launch_bounds__(DC_THREADS) void dc_cols_kernel(
     float2* __restrict__ data, const float2* __restrict__ k0, const uint8_t* __restrict__ mask,
-    int H, int W, float scale) {
+    int H, int W, float scale, float2* __restrict__ kout, int keep_sampled) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float2* a = (float2*)smem;
   float2* b = a + H * DC_TP;
@@ -151,8 +151,10 @@ __global__ __launch_bounds__(DC_THREADS) void dc_cols_kernel(
     float2 k = res[h * DC_TP + c];
     k.x *= scale; k.y *= scale;
     // (1 - m) * k + k0 with m in {0,1}: bit-exact integer mask test
-    float2 v = mask[o] ? make_float2(0.f, 0.f) : k;
+    // keep_sampled (forward model, csmri_undersample): m * k instead, and the k-space is an output
+    float2 v = (mask[o] != 0) == (keep_sampled != 0) ? k : make_float2(0.f, 0.f);
     if (k0) { float2 q = k0[o]; v.x += q.x; v.y += q.y; }
+    if (kout) kout[o] = v;
     res[h * DC_TP + c] = v;
   }
   __syncthreads();
@@ -198,10 +200,41 @@ extern "C" int csmri_dc(const float* x, int x_pix_stride, const float* k0, const
                      x, x_pix_stride, (float2*)out, (void*)nullptr, 0, W, -1, 1.0f);
   CSMRI_LAUNCH_CHECK();
   hipLaunchKernelGGL(dc_cols_kernel, dim3(col_blocks), dim3(DC_THREADS), lds_cols, st,
-                     (float2*)out, (const float2*)k0, mask, H, W, scale);
+                     (float2*)out, (const float2*)k0, mask, H, W, scale, (float2*)nullptr, 0);
   CSMRI_LAUNCH_CHECK();
   hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
                      (const float*)out, 2, (float2*)out, out_pad, out_pad_dtype, W, +1, scale);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+// The forward model that produces a training sample from a (complex) image, on the device:
+//   kspace = m * orthoFFT2(img),   inp = orthoIFFT2(kspace)
+// (data/reconstruction/rec_transforms.py:18-57 -> compressed_sensing.py:460-512: numpy complex128
+// on the host in the reference).  Same three passes as csmri_dc with the merge replaced by the
+// mask product and the k-space strip written out on the way.
+extern "C" int csmri_undersample(const float* img, const uint8_t* mask, float* kspace, float* inp, int B, int H,
+                                 int W, void* stream) {
+  CSMRI_CHECK_ARG(img && mask && kspace && inp && B > 0);
+  if (!is_pow2_in_range(H) || !is_pow2_in_range(W)) return CSMRI_E_UNSUPPORTED;
+  if (((uintptr_t)img | (uintptr_t)kspace | (uintptr_t)inp) & 15) return CSMRI_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = 1.0f / sqrtf((float)H * (float)W);
+  const int lds_rows = (2 * W * DC_TP + W) * (int)sizeof(float2);
+  const int lds_cols = (2 * H * DC_TP + H) * (int)sizeof(float2);
+  hipError_t e = hipFuncSetAttribute((const void*)dc_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rows);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute((const void*)dc_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cols);
+  if (e != hipSuccess) return (int)e;
+  const int row_blocks = B * H / DC_T, col_blocks = B * (W / DC_T);
+  hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
+                     img, 2, (float2*)inp, (void*)nullptr, 0, W, -1, 1.0f);
+  CSMRI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dc_cols_kernel, dim3(col_blocks), dim3(DC_THREADS), lds_cols, st,
+                     (float2*)inp, (const float2*)nullptr, mask, H, W, scale, (float2*)kspace, 1);
+  CSMRI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
+                     (const float*)inp, 2, (float2*)inp, (void*)nullptr, 0, W, +1, scale);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -84,3 +84,23 @@ class SyntheticLoader(object):
   def __iter__(self):
     for i in range(self.num_batches):
       yield self.batches[i % len(self.batches)]
+
+
+def synth_batch_device(b, h, w, acc=4, seed=0, sample_n=8, device=None):
+  """Same samples as synth_batch with the forward model on the GPU: the phantom
+  and the mask rows are drawn on the host exactly as above (tiny, RNG-defined), the two FFTs per
+  slice run in ``csmri_undersample`` in fp32.  Returns NHWC device tensors: inp, kspace, target
+  interleaved complex [B,H,W,2] fp32 and mask in the reference's batch layout [B,2,H,W]."""
+  from csmri_hip import ops
+  device = device or torch.device('cuda', torch.cuda.current_device())
+  imgs, masks = [], []
+  for i in range(b):
+    s = seed + 1000 + i
+    imgs.append(phantom(h, w, s))
+    masks.append(cartesian_mask((1, h, w), acc, sample_n, np.random.RandomState(s + 7919))[0])
+  img = torch.from_numpy(np.stack(imgs).astype(np.float32)).to(device)
+  mask = torch.from_numpy(np.stack(masks).astype(np.float32)).to(device)
+  target = torch.stack((img, torch.zeros_like(img)), dim=-1).contiguous()       # [B,H,W,2]
+  kspace, inp = ops.undersample(target, (mask != 0).to(torch.uint8))
+  return {'inp': inp, 'kspace': kspace, 'target': target,
+          'mask': torch.stack((mask, mask), dim=1).contiguous()}

@@ -201,6 +201,12 @@ int csmri_fold_pad_grad(int dtype, const void* gpad, void* out, int out_pix_stri
 int csmri_dc(const float* x, int x_pix_stride, const float* k0, const uint8_t* mask, float* out,
              void* out_pad, int out_pad_dtype, float* work, int B, int H, int W,
              void* stream);
+/* forward model of a training sample on the device (rec_transforms.py:18-57,
+ * compressed_sensing.py:460-512): kspace = m * orthoFFT2(img), inp = orthoIFFT2(kspace);
+ * img, kspace, inp interleaved complex fp32 [B,H,W,2], mask uint8 [B,H,W]; H, W powers of two
+ * in [32, 512]. */
+int csmri_undersample(const float* img, const uint8_t* mask, float* kspace, float* inp, int B,
+                      int H, int W, void* stream);
 size_t csmri_dc_work_bytes(int B, int H, int W);
 
 /* layout converters (H2D boundary: batch dict tensors are NCHW fp32,

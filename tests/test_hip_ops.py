@@ -358,3 +358,22 @@ def test_ssim_vs_reference_golden_and_oracle(hip):
   want = O.ssim_images(p2, t2)
   got2 = ops.ssim(p2.permute(0, 2, 3, 1).contiguous().cuda(), t2.permute(0, 2, 3, 1).contiguous().cuda())
   assert np.allclose(got2.cpu().numpy(), want, rtol=0, atol=2e-5), (got2, want)
+
+
+@pytest.mark.parametrize('size', [64, 256])
+def test_device_forward_model_matches_host_synthesis(hip, size):
+  """csmri_undersample (fp32 FFTs on the GPU) against the host forward model in
+  complex128 (the oracle's synth_batch, reference compressed_sensing.py:460-512): kspace and inp
+  within 2e-6 of max|.| (fp32 FFT rounding), sampled set bit-exact (zeros stay exact zeros)."""
+  from data.synthetic import synth_batch_device
+  want = O.synth_batch(3, size, size, acc=4, seed=31)
+  got = synth_batch_device(3, size, size, acc=4, seed=31)
+  for k in ('inp', 'kspace', 'target'):
+    g = got[k].permute(0, 3, 1, 2).cpu()
+    scale = float(want[k].abs().max())
+    err = float((g - want[k]).abs().max())
+    assert err < 2e-6 * max(scale, 1.0), (k, err, scale)
+  assert torch.equal(got['mask'].cpu(), want['mask'])
+  ks = got['kspace'].cpu()
+  m = want['mask'][:, 0] != 0
+  assert float(ks[~m].abs().max()) == 0.0
