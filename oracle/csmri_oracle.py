@@ -733,6 +733,41 @@ def cartesian_mask(shape, acc, sample_n=8, rng=None):
   return np.fft.ifftshift(m, axes=(-1, -2))
 
 
+def radial_mask(shape, n_lines, angle_begin=0.0, rand=False, golden_angle=False, centred=False, rng=None):
+  """radial_sampling (compressed_sensing.py:568-647) for square slices: spokes gridded to the
+  nearest Cartesian sample, un-centred by default (ifftshift) as the training transform uses it
+  (BASELINE config 5: `acceleration_factor` = number of spokes, myImageTransformations.py:63-70).
+  Integer 0/1 mask of ``shape`` = (..., nx, ny)."""
+  rng = np.random if rng is None else rng
+  golden = np.pi / ((1 + np.sqrt(5)) / 2)
+  n, nx, ny = int(np.prod(shape[:-2])), shape[-2], shape[-1]
+  assert nx == ny, 'square slices only (the reference pads otherwise)'
+  mask = np.zeros((n, nx, ny), dtype=int)
+  if rand:
+    angle_begin = np.pi * rng.random()
+  y = np.arange(-nx / 2, nx / 2, 1)
+  x = np.arange(-ny / 2, ny / 2, 1)
+  if golden_angle:
+    angles = [angle_begin + i * golden for i in range(n_lines * n)]
+  else:
+    angles = np.tile(np.arange(0, np.pi, np.pi / n_lines), n)
+    angles = angles + np.repeat(rng.random(n) * np.pi / n_lines, n_lines)
+  kloc = np.outer(y, np.cos(angles)) + 1j * np.outer(x, np.sin(angles))
+  k1 = np.round(kloc + (0.5 + 0.5j)) + ((nx / 2) + (ny / 2) * 1j)
+  re, im = np.real(k1), np.imag(k1)
+  re = re - nx * (re > nx)
+  im = im - ny * (im > ny)
+  re = re + nx * (re < 1)
+  im = im + ny * (im < 1)
+  t = np.repeat(np.arange(n), n_lines * nx)
+  xi = (re.transpose().reshape(-1) - 1).astype(int)
+  yi = (im.transpose().reshape(-1) - 1).astype(int)
+  mask[t, xi, yi] = 1
+  if not centred:
+    mask = np.fft.ifftshift(mask, axes=(-2, -1))
+  return mask.reshape(shape)
+
+
 def phantom(h, w, seed):
   """Seeded band-limited random phantom in [0,1] with a few ellipses, divided
   by its max (mirrors x/np.max(np.abs(x)), rec_transforms.py:47).  Strictly

@@ -10,7 +10,7 @@ the reference's source is stored -- only data.
 
 Fixtures: F1 synthetic batch + mask rows, F2 DC fwd/adjoint,
 F3 RecNet fwd/loss/grads/Adam steps, F4 RefinementWrapper, F5 discriminator,
-F6 VGG loss, F7 full GAN train steps, F8 PSNR, F9 SSIM.
+F6 VGG loss, F7 full GAN train steps, F8 PSNR, F9 SSIM, F10 radial masks.
 """
 import collections
 import collections.abc
@@ -554,8 +554,25 @@ def f9():
        ssim_per_image=np.array(per_image, dtype=np.float64))
 
 
+# ----------------------------------------------------------------- F10 ----
+# radial undersampling masks (BASELINE config 5 data format): the reference's radial_sampling,
+# golden-angle with random start and uniform spokes; stored as sample indices (bit-exact test).
+
+
+def f10():
+  out = {}
+  for tag, (n, nx, lines, golden) in {'g512': (2, 512, 70, True), 'u128': (2, 128, 24, False),
+                                      'g64': (1, 64, 8, True)}.items():
+    rng = np.random.RandomState(4321)
+    m = ref_cs.radial_sampling((n, nx, nx), lines, rand=True, golden_angle=golden, centred=False, rng=rng)
+    out['idx_' + tag] = np.flatnonzero(m).astype(np.int64)
+    out['shape_' + tag] = np.array(m.shape, dtype=np.int64)
+    out['args_' + tag] = np.array([n, nx, lines, int(golden)], dtype=np.int64)
+  save('F10_radial', **out)
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10']
   for name in which:
     print('==', name)
     globals()[name]()

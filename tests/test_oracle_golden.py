@@ -276,3 +276,14 @@ def test_f9_ssim():
   vals = O.ssim_images(T(f['pred']), T(f['target']))
   assert np.allclose(vals, f['ssim_per_image'], rtol=0, atol=2e-6), (vals, f['ssim_per_image'])
   assert abs(float(np.mean(vals)) - float(f['ssim'])) < 2e-6
+
+
+def test_f10_radial_masks_bit_exact():
+  """Radial undersampling (BASELINE config 5 data format): sample indices equal the reference's."""
+  f = load('F10_radial')
+  for tag in ('g512', 'u128', 'g64'):
+    n, nx, lines, golden = (int(v) for v in f['args_' + tag])
+    m = O.radial_mask((n, nx, nx), lines, rand=True, golden_angle=bool(golden), centred=False,
+                      rng=np.random.RandomState(4321))
+    assert tuple(m.shape) == tuple(int(v) for v in f['shape_' + tag])
+    assert np.array_equal(np.flatnonzero(m), f['idx_' + tag]), tag
