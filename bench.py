@@ -153,8 +153,18 @@ def roofline(runner, loader, steps=2):
   dom = max(agg, key=lambda k: agg[k][2])
   n, fl, sec = agg[dom]
   achieved = fl / sec / 1e12
+  # HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very
+  # command (tools/pmc_bench.sh; FETCH_SIZE doubled per the gfx950 correction), committed under profiles/
+  traffic, traffic_src = None, None
+  tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_bench_traffic.json')
+  if os.path.exists(tpath):
+    for name, rec in json.load(open(tpath)).items():
+      if dom in name:
+        traffic = round(rec['fetch_bytes_per_launch'] + rec['write_bytes_per_launch'])
+        traffic_src = 'profiles/r01_pmc_bench_traffic.json (rocprofv3 --pmc, %d launches)' % rec['launches']
   rl = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS,
-        'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+        'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+        'traffic_unit': 'B/launch (HBM, PMC)', 'traffic_source': traffic_src,
         'avg_launch_us': round(sec / n * 1e6, 2), 'event_pair_overhead_us': round(ovh * 1e6, 2),
         'launches': n // steps,
         'algorithmic_gflop_per_launch': round(fl / n / 1e9, 3)}

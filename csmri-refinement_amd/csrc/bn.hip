@@ -46,7 +46,7 @@ __device__ __forceinline__ void block_sum2(double& a, double& b) {
 
 // write one partial row: reduce the per-thread (a, b) over the pixel lanes of the block
 __device__ __forceinline__ void write_partial_row(f32x4_t a, f32x4_t b, int nv, int lanes, int cv,
-                                                  int pl, int C, float* row) {
+                                                  int pl, int C, float* partial, size_t R, size_t r) {
   __shared__ float red[2][256][4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { red[0][threadIdx.x][q] = a[q]; red[1][threadIdx.x][q] = b[q]; }
@@ -55,8 +55,12 @@ __device__ __forceinline__ void write_partial_row(f32x4_t a, f32x4_t b, int nv, 
     for (int l = 1; l < lanes; ++l)
 #pragma unroll
       for (int q = 0; q < 4; ++q) { a[q] += red[0][l * nv + cv][q]; b[q] += red[1][l * nv + cv][q]; }
-    *(f32x4_t*)(row + cv * 4) = a;
-    *(f32x4_t*)(row + C + cv * 4) = b;
+    // channel-major partials [2][C][R]: the finalize kernels read a channel's rows contiguously
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      partial[(size_t)(cv * 4 + q) * R + r] = a[q];
+      partial[(size_t)(C + cv * 4 + q) * R + r] = b[q];
+    }
   }
 }
 
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* y, int ps, in
     f32x4_t v = ld4<DT>(y, (long long)(base + p) * ps + cv * 4);
     a += v; b += v * v;
   }
-  write_partial_row(a, b, nv, lanes, cv, pl, C, partial + ((size_t)g * rows + blockIdx.x) * 2 * C);
+  write_partial_row(a, b, nv, lanes, cv, pl, C, partial, (size_t)gridDim.y * rows, (size_t)g * rows + blockIdx.x);
 }
 extern "C" int csmri_bn_stats(int dtype, const void* y, int pix_stride, int npix, int C, float* partial,
                               int groups, void* stream) {
@@ -95,10 +99,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
   const int c = blockIdx.x;       // one block per channel, fixed-order tree over the rows
   // rows, count: per group.  Groups are finalized in order, so the running statistics see the
   // same sequence of momentum updates as `groups` separate forward calls would give.
+  const size_t R = (size_t)rows * groups;             // partial: [2][C][R], group-major rows
   for (int g = 0; g < groups; ++g) {
-    const float* part = partial + (size_t)g * rows * 2 * C;
+    const float* p1 = partial + (size_t)c * R + (size_t)g * rows;
+    const float* p2 = partial + ((size_t)C + c) * R + (size_t)g * rows;
     double s1 = 0, s2 = 0;
-    for (int r = threadIdx.x; r < rows; r += 256) { s1 += part[(size_t)r * 2 * C + c]; s2 += part[(size_t)r * 2 * C + C + c]; }
+    for (int r = threadIdx.x; r < rows; r += 256) { s1 += p1[r]; s2 += p2[r]; }
     __syncthreads();
     block_sum2(s1, s2);
     if (threadIdx.x != 0) continue;
@@ -221,7 +227,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dz, int 
       b[q] += d * (yy[q] - mu[q]) * is[q];
     }
   }
-  write_partial_row(a, b, nv, lanes, cv, pl, C, partial + ((size_t)grp * rows + blockIdx.x) * 2 * C);
+  write_partial_row(a, b, nv, lanes, cv, pl, C, partial, (size_t)gridDim.y * rows + gridDim.y,
+                    (size_t)grp * rows + blockIdx.x);
 }
 extern "C" int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride, const void* y, int y_pix_stride,
                                    const void* z, int z_pix_stride, int B, int HW, int C, const float* mean,
@@ -245,16 +252,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* partial, in
   const int c = blockIdx.x;
   // rows: per group; the totals of group g go to row (groups*rows + g)
   float acc1 = 0.f, acc2 = 0.f;
+  const size_t R = (size_t)rows * groups + groups;    // [2][C][R]: the last `groups` entries are the totals
   for (int g = 0; g < groups; ++g) {
-    const float* part = partial + (size_t)g * rows * 2 * C;
+    float* p1 = partial + (size_t)c * R;
+    float* p2 = partial + ((size_t)C + c) * R;
     double s1 = 0, s2 = 0;
-    for (int r = threadIdx.x; r < rows; r += 256) { s1 += part[(size_t)r * 2 * C + c]; s2 += part[(size_t)r * 2 * C + C + c]; }
+    for (int r = threadIdx.x; r < rows; r += 256) { s1 += p1[(size_t)g * rows + r]; s2 += p2[(size_t)g * rows + r]; }
     __syncthreads();
     block_sum2(s1, s2);
     if (threadIdx.x != 0) continue;
-    float* tot = partial + ((size_t)groups * rows + g) * 2 * C;
-    tot[c] = (float)s1;
-    tot[C + c] = (float)s2;
+    p1[(size_t)groups * rows + g] = (float)s1;
+    p2[(size_t)groups * rows + g] = (float)s2;
     acc1 += (float)s1; acc2 += (float)s2;
   }
   if (threadIdx.x == 0 && c < C_real) {
@@ -274,11 +282,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
                                                            const float* __restrict__ gamma, float slope,
                                                            const float* __restrict__ drop,
                                                            const float* __restrict__ totals, float inv_count,
-                                                           const float* __restrict__ snap) {
+                                                           const float* __restrict__ snap, int totals_R) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
   // npix: per group; blockIdx.y = group
   const int grp = blockIdx.y, pbase = grp * npix;
-  totals += (size_t)grp * 2 * C;
   const f32x4_t mu = *(const f32x4_t*)(mean + grp * C + c), is = *(const f32x4_t*)(invstd + grp * C + c);
   f32x4_t fsc = is, fbe = is;
   if (RECOMP) { fsc = is * *(const f32x4_t*)(snap + c); fbe = *(const f32x4_t*)(snap + C + c); }
@@ -286,8 +293,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     gs[q] = c + q < C_real ? gamma[c + q] * is[q] : 0.f;
-    m1[q] = totals[c + q] * inv_count;
-    m2[q] = totals[C + c + q] * inv_count;
+    m1[q] = totals[(size_t)(c + q) * totals_R + grp] * inv_count;        // totals: &partial[rows_total], stride R
+    m2[q] = totals[(size_t)(C + c + q) * totals_R + grp] * inv_count;
   }
   const int chunk = (npix + gridDim.x - 1) / gridDim.x, q0 = blockIdx.x * chunk, q1 = min(npix, q0 + chunk);
 #pragma unroll 4
@@ -324,9 +331,10 @@ extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, 
   const int npix = B * HW, lanes = 256 / (C / 4);
   const int blocks = csmri_bn_stats_rows(npix, C);
   (void)lanes;
-  const float* totals = partial + (size_t)rows * 2 * C;
+  const float* totals = partial + rows;                // [2][C][rows + groups]: totals follow each channel's rows
+  const int totals_R = rows + groups;
   const float inv = 1.0f / ((float)B * (float)HW);
-#define BN_APP(DT_, RC_) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT_, RC_>), dim3(blocks, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv, affine_snap)
+#define BN_APP(DT_, RC_) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT_, RC_>), dim3(blocks, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv, affine_snap, totals_R)
   if (dtype == CSMRI_BF16) { if (z) BN_APP(CSMRI_BF16, false); else BN_APP(CSMRI_BF16, true); }
   else { if (z) BN_APP(CSMRI_F32, false); else BN_APP(CSMRI_F32, true); }
 #undef BN_APP

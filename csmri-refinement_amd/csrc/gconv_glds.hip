@@ -222,8 +222,9 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
         for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
         const int n = n0 + wn * WTN + i * 16 + g * 4 + r;
         if (r16 == 0) {
-          float* row = p.stats + (size_t)(mt * WM + wm) * 2 * p.Cout;
-          row[n] = a; row[p.Cout + n] = b;
+          // partial sums are channel-major: [2][Cout][rows], rows = mtiles * WM (finalize reads coalesced)
+          const size_t R = (size_t)p.mtiles * WM, r = (size_t)mt * WM + wm;
+          p.stats[(size_t)n * R + r] = a; p.stats[((size_t)p.Cout + n) * R + r] = b;
         }
       }
   }

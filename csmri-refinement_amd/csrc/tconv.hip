@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
         for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
         const int n = n0 + i * 16 + g * 4 + r;
         if (r16 == 0 && n < p.Cout) {
-          float* row = p.stats + (size_t)(blockIdx.x * 4 + wv) * 2 * p.Cout;
-          row[n] = a1; row[p.Cout + n] = a2;
+          const size_t R = (size_t)gridDim.x * 4, r = (size_t)blockIdx.x * 4 + wv;   // [2][Cout][rows]
+          p.stats[(size_t)n * R + r] = a1; p.stats[((size_t)p.Cout + n) * R + r] = a2;
         }
       }
   }

@@ -94,7 +94,7 @@ typedef struct csmri_gconv_desc {
   float act_slope;           /* 1 = none */
   const void* g_src; int g_pix_stride; float g_slope; /* dtype = out_dtype... see .c */
   int g_dtype;
-  float* stats_partial;      /* NULL or [stats_rows][2][Cout]: per-wave-row sum / sumsq */
+  float* stats_partial;      /* NULL or [2][Cout][stats_rows]: per-wave-row sum / sumsq */
   /* split-K */
   int splitk;                /* >=1; >1 needs slab */
   float* slab;               /* [splitk][M][Cout] fp32 workspace */
@@ -229,9 +229,10 @@ int csmri_mask_to_u8(const float* mask_nchw, int B, int H, int W, uint8_t* dst, 
  * (own batch statistics each; running statistics updated once per group, in order),
  * which lets the two discriminator passes of training/adversarial_runner.py:333-341
  * (fake, then real) run as one launch sequence.  mean/invstd are [groups][C]; partial
- * rows are group-major ([groups][rows/groups][2][C]).
+ * sums are channel-major, [2][C][rows] with the rows group-major (the finalize kernels read a
+ * channel's rows contiguously).
  * ---------------------------------------------------------------------- */
-/* per-channel partial sums of a tensor: partial [rows][2][C] (rows returned by
+/* per-channel partial sums of a tensor: partial [2][C][rows] (rows returned by
  * csmri_bn_stats_rows) -- used when the conv epilogue did not produce them */
 int csmri_bn_stats_rows(int npix, int C);
 int csmri_bn_stats(int dtype, const void* y, int pix_stride, int npix, int C,
