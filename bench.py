@@ -238,6 +238,12 @@ def main():
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
 
+  # the instrumented roofline pass trains too (its steps all-reduce): every rank takes part
+  rl_out = None
+  if not args.no_roofline:
+    rl_out = roofline(runner, loader)
+  if ws > 1:
+    torch.distributed.barrier()
   if rank != 0:
     return
   slices = ws * args.batch * args.steps
@@ -257,8 +263,8 @@ def main():
       'final_losses': {k: round(v.value, 5) for k, v in losses.items()},
       'gen_psnr': round(metrics['gen_psnr'].value, 4) if 'gen_psnr' in metrics else None,
   }
-  if not args.no_roofline:
-    rl, table, conv_ms = roofline(runner, loader)
+  if rl_out is not None:
+    rl, table, conv_ms = rl_out
     line['roofline'] = rl
     line['conv_kernels'] = table
     line['conv_ms_per_step'] = round(conv_ms, 3)
