@@ -42,6 +42,8 @@ def parse():
   p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--no-roofline', action='store_true')
+  p.add_argument('--no-prefetch', action='store_true',
+                 help='do not issue the frozen RecNet forward of the next batch during the current step')
   p.add_argument('--batch', type=int, default=PER_GPU_BATCH)
   p.add_argument('--no-graphs', action='store_true', help='eager launches instead of hipGraph replay')
   p.add_argument('--no-overlap', action='store_true', help='keep the VGG branch on the main stream')
@@ -129,6 +131,7 @@ def roofline(runner, loader, steps=2):
   from csmri_hip import ops
   runner.disable_graphs()       # per-launch events need eager launches
   runner.overlap_streams = False  # ... on ONE stream: concurrent side-stream kernels would inflate the brackets
+  runner.prefetch_pretrained = False
   ops.PROFILE = []
   runner.train_epoch(DeviceLoader(loader.batches, steps), 1)
   torch.cuda.synchronize()
@@ -211,6 +214,7 @@ def main():
   # undo the BN running-stat update of that probe forward? it does not affect training outputs
 
   runner.overlap_streams = not args.no_overlap
+  runner.prefetch_pretrained = not (args.no_prefetch or args.no_overlap)
   if not args.no_graphs:
     # capture the step once (3 eager steps inside); the timed region replays hipGraphs
     try:
@@ -239,6 +243,7 @@ def main():
     dt = float(t.item())
 
   # the instrumented roofline pass trains too (its steps all-reduce): every rank takes part
+  prefetch_on = bool(runner.prefetch_pretrained)
   rl_out = None
   if not args.no_roofline:
     rl_out = roofline(runner, loader)
@@ -253,6 +258,7 @@ def main():
       'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+      'prefetch': 'frozen RecNet forward of batch t+1 on a side stream during step t' if prefetch_on else None,
       'launch_mode': 'eager' if args.no_graphs else ('hipGraph replay (one graph per step)' if ws == 1 else
                                                       'hipGraph replay (4 segments, collectives eager)'),
       'config': {'workload': 'C3/C4 2-refinement GAN step: frozen RecNet(3,3,32)+3 DC, UNET, CNNDiscriminator, '

@@ -62,13 +62,23 @@ class RefinementWrapper(nn.Module):
       return params
     return filter(lambda p: p.requires_grad, params)
 
+  def precompute(self, inp, kspace, mask):
+    """The frozen pretrained reconstruction alone (no autograd): it depends only on the batch, so
+    a runner may issue it for the NEXT batch while the current step trains (forward_with_pre)."""
+    assert self.freeze_pretrained_model
+    with torch.no_grad():
+      pre = self.pretrained_model(inp.detach(), kspace.detach(), mask.detach())
+    return pre.detach()
+
   def forward(self, inp, kspace, mask):
     if self.freeze_pretrained_model:
-      with torch.no_grad():
-        pre = self.pretrained_model(inp.detach(), kspace.detach(), mask.detach())
-      pre = pre.detach()
+      pre = self.precompute(inp, kspace, mask)
     else:
       pre = self.pretrained_model(inp, kspace, mask)
+    return self.forward_with_pre(inp, kspace, mask, pre)
+
+  def forward_with_pre(self, inp, kspace, mask, pre):
+    """forward() given the pretrained model's output for this batch."""
     unet = self.learnable_model
     x = ops.ToNHWC.apply(pre, unet.dtype, 8)
     u = unet.forward_nhwc(x)                                      # [B,H,W,8], channel 0

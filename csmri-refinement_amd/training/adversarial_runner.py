@@ -141,6 +141,11 @@ class AdversarialRunner(BaseRunner):
     self._last_metrics = None
     self.overlap_streams = False
     self._side_stream = None
+    # software pipelining of the FROZEN pretrained reconstruction: its forward for the next batch
+    # runs on a side stream while this step trains (exact reordering; bench.py turns it on)
+    self.prefetch_pretrained = False
+    self._pf = None
+    self._pf_stream = None
     self.third_pass_early = os.environ.get('CSMRI_THIRD_EARLY', '1') != '0'   # with vgg_early (single GPU)
     self._side_stream3 = None
     self.vgg_early = None                 # None: decided at the first step (True on a single GPU)
@@ -213,12 +218,22 @@ class AdversarialRunner(BaseRunner):
     batch = st['batch']
     if self.vgg_early is None:
       from training import distributed as dist_utils
-      import os
       env = os.environ.get('CSMRI_VGG_EARLY')          # A/B knob
       self.vgg_early = (env == '1') if env in ('0', '1') else dist_utils.world_size() == 1
     gen_inp = self.train_model_input_fn(batch)
     st['gen_inp0'] = gen_inp[0]
-    out_gen = self.gen(*gen_inp)
+    if st.get('batch_next') is not None:
+      if self._pf_stream is None:
+        self._pf_stream = torch.cuda.Stream()
+      self._pf_stream.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(self._pf_stream):
+        st['pre_next'] = self.gen.precompute(*self.train_model_input_fn(st['batch_next']))
+      st['_pf_pending'] = True
+    if st.get('pre_cur') is not None:
+      st['pre_cur'].record_stream(torch.cuda.current_stream())   # produced on the prefetch stream
+      out_gen = self.gen.forward_with_pre(*gen_inp, pre=st['pre_cur'])
+    else:
+      out_gen = self.gen(*gen_inp)
     st['out_gen'] = out_gen
     st['side_results'] = {}
     if self.overlap_streams and self.vgg_early:
@@ -263,6 +278,19 @@ class AdversarialRunner(BaseRunner):
       torch.cuda.current_stream().wait_stream(self._side_stream)
     if st['out_disc_fake_early'] is not None:
       torch.cuda.current_stream().wait_stream(self._side_stream3)
+    self._join_prefetch(st, 1)
+
+  def _join_prefetch(self, st, seg):
+    """Join the look-ahead stream.  A captured segment must end with every stream joined: with one
+    graph per step (single GPU) the frozen forward of batch t+1 may run until the end of step t,
+    with one graph per segment it is joined inside segment 1."""
+    if not st.get('_pf_pending'):
+      return
+    from training import distributed as dist_utils
+    last = int(os.environ.get('CSMRI_PF_JOIN', '4' if dist_utils.world_size() == 1 else '1'))   # A/B knob
+    if seg >= last:
+      torch.cuda.current_stream().wait_stream(self._pf_stream)
+      st['_pf_pending'] = False
 
   def _third_disc_pass(self, st):
     self.disc.set_wgrad(False)     # D's weight gradients of this pass are discarded (A-5)
@@ -310,6 +338,7 @@ class AdversarialRunner(BaseRunner):
     if side and forked_here:
       torch.cuda.current_stream().wait_stream(self._side_stream)
     st['total_gen'] = self._weighted_total(gen_losses, self.gen_loss_weights)
+    self._join_prefetch(st, 2)
 
   def _seg3(self, st):
     if st.get('out_disc_fake_early') is not None:
@@ -327,9 +356,11 @@ class AdversarialRunner(BaseRunner):
     ops.join_wgrad_stream()
     st['names'].append('gen_loss')
     st['vals'].append(st['total_gen'].detach())
+    self._join_prefetch(st, 3)
 
   def _seg4(self, st):
     self.gen_optimizer.apply()
+    self._join_prefetch(st, 4)
     data = (st['batch'], st['out_gen'], st['out_disc_fake'], st['out_disc_real'])
     metrics = self._compute_train_metrics(data)
     st['metric_names'] = list(metrics.keys())
@@ -354,12 +385,16 @@ class AdversarialRunner(BaseRunner):
     assert self.pool_decisions is None and not self.disc.injected_dropout, \
         'graph mode draws its own randomness'
     static = {k: v.detach().clone() for k, v in example_batch.items()}
+    static_next = static_pre = None
+    if self.prefetch_pretrained:
+      static_next = {k: v.detach().clone() for k, v in example_batch.items()}
+      static_pre = self.gen.precompute(*self.train_model_input_fn(static)).clone()
     self._set_train()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
       for _ in range(warmup):
-        self._run_segments_eager({'batch': static})
+        self._run_segments_eager({'batch': static, 'batch_next': static_next, 'pre_cur': static_pre})
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     pool = getattr(self.disc_input_fn, 'image_pool', None)
@@ -369,7 +404,7 @@ class AdversarialRunner(BaseRunner):
       pool.prepare(torch.empty((static['inp'].shape[0],) + tuple(pool.buffer.shape[1:]),
                                dtype=pool.buffer.dtype, device=self.device))
       pool.external_plan = True
-    st = {'batch': static}
+    st = {'batch': static, 'batch_next': static_next, 'pre_cur': static_pre}
     graphs = []
     # a cyclic-GC pass in the middle of a capture may destroy graphs/events of an earlier
     # runner, which the runtime rejects while a stream is capturing: collect now, pause GC
@@ -401,7 +436,8 @@ class AdversarialRunner(BaseRunner):
     finally:
       if gc_was_enabled:
         gc.enable()
-    self._graph = {'graphs': graphs, 'static': static, 'st': st, 'pool': pool,
+    self._graph = {'graphs': graphs, 'static': static, 'static_next': static_next, 'static_pre': static_pre,
+                   'st': st, 'pool': pool,
                    'bn_delta': [(m, m.batches_tracked - b) for m, b in zip(bns, before)]}
     # the capture pass did not execute anything: optimizer host mirrors advanced, undo
     self.disc_optimizer.step_count -= 1
@@ -416,11 +452,16 @@ class AdversarialRunner(BaseRunner):
       g['pool'].external_plan = False
     self._graph = None
 
-  def _run_segments_graphed(self, batch):
+  def _run_segments_graphed(self, batch, batch_next=None, pre_cur=None):
     from csmri_hip import ops
     G = self._graph
     for k, v in G['static'].items():
       v.copy_(batch[k], non_blocking=True)
+    if G['static_next'] is not None:
+      nb = batch_next if batch_next is not None else batch       # last step of an epoch: nothing to prefetch
+      for k, v in G['static_next'].items():
+        v.copy_(nb[k], non_blocking=True)
+      G['static_pre'].copy_(pre_cur, non_blocking=True)
     if G['pool'] is not None:
       G['pool'].external_plan = False
       G['pool'].prepare(G['pool'].buffer[:G['static']['inp'].shape[0]])
@@ -444,17 +485,37 @@ class AdversarialRunner(BaseRunner):
     ops.bump_weight_epoch()
     return G['st']
 
+  def train_epoch(self, loader, epoch, *args, **kwargs):
+    self._pf = None                      # the look-ahead never crosses an epoch boundary
+    return super(AdversarialRunner, self).train_epoch(loader, epoch, *args, **kwargs)
+
   def _train_single_step(self, loader):
-    batch = self._request_data(loader)
-    if batch is None:
-      return 0, None, None
+    batch_next = pre_cur = None
+    if self.prefetch_pretrained:
+      # this step's batch was fetched (and its pretrained reconstruction issued) one step ago
+      if self._pf is None:
+        batch = self._request_data(loader)
+        if batch is None:
+          return 0, None, None
+        pre_cur = self.gen.precompute(*self.train_model_input_fn(batch))
+      else:
+        batch, pre_cur = self._pf
+        if batch is None:
+          return 0, None, None
+      batch_next = self._request_data(loader) if self.data_iter is not None else None
+    else:
+      batch = self._request_data(loader)
+      if batch is None:
+        return 0, None, None
     if getattr(self, '_graph', None) is not None:
-      st = self._run_segments_graphed(batch)
+      st = self._run_segments_graphed(batch, batch_next, pre_cur)
       vec = st['vec'].clone()
     else:
-      st = {'batch': batch}
+      st = {'batch': batch, 'batch_next': batch_next, 'pre_cur': pre_cur}
       self._run_segments_eager(st)
       vec = st['vec']
+    if self.prefetch_pretrained:
+      self._pf = (batch_next, st['pre_next'] if batch_next is not None else None)
     n = len(st['names'])
     loss_metrics = {name: get_loss_metric(vec[i]) for i, name in enumerate(st['names'])}
     self._last_metrics = {name: MaxMetric(vec[n + j]) for j, name in enumerate(st['metric_names'])}

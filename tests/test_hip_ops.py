@@ -406,3 +406,63 @@ def test_radial_512_forward_model_and_dc(hip):
   out, _ = ops.dc_raw(x.cuda(), ks, mu8)
   got = out.cpu().permute(0, 3, 1, 2)
   assert rel_l2(got, ref) < 5e-6 and torch.allclose(got, ref, rtol=1e-4, atol=2e-5)
+
+
+def test_fp32_kernels_exact_next_to_mfma_kernels_in_one_graph(hip):
+  """Two branches of one hipGraph: a chain of data-consistency layers (fp32 VALU + LDS) next to
+  a chain of MFMA convolutions.  The DC results must be bit-identical to the serial run.  This
+  failed on MI355X while the fp32 kernels were built with packed-fp32 VALU instructions
+  (csrc/Makefile): it guards the build flag and every multi-stream graph."""
+  ops = hip.ops
+  b, size, depth = 8, 256, 4
+  g = torch.Generator().manual_seed(3)
+  x = torch.randn(b, size, size, 2, generator=g).cuda()
+  k0 = torch.randn(b, size, size, 2, generator=g).cuda()
+  m8 = (torch.rand(b, size, size, generator=g) < 0.25).to(torch.uint8).cuda()
+  wt = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+  layer = ops.ConvLayer(torch.nn.Parameter(wt.cuda()), None, 1, (1, 1, 1, 1), 'zero', torch.bfloat16)
+  act = torch.randn(b, size, size, 64, generator=g).bfloat16().cuda()
+
+  def dc_chain():
+    t, outs = x, []
+    for _ in range(depth):
+      t, _ = ops.dc_raw(t, k0, m8, None)
+      outs.append(t)
+    return outs
+
+  def conv_chain():
+    t = act
+    for _ in range(6):
+      t, _ = ops.conv_forward(layer, t, use_bias=False, act_slope=0.2)
+    return t
+
+  with torch.no_grad():
+    ref = [t.clone() for t in dc_chain()]
+    ref_conv_out = conv_chain().clone()
+  s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+  def both():
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur)
+    s2.wait_stream(cur)
+    with torch.no_grad():
+      with torch.cuda.stream(s2):
+        c = conv_chain()
+      with torch.cuda.stream(s1):
+        d = dc_chain()
+    cur.wait_stream(s1)
+    cur.wait_stream(s2)
+    return d, c
+
+  for _ in range(2):
+    both()
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+    d, c = both()
+  for _ in range(10):
+    graph.replay()
+    torch.cuda.synchronize()
+    for got, want in zip(d, ref):
+      assert torch.equal(got, want)
+    assert torch.equal(c, ref_conv_out)

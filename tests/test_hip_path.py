@@ -542,3 +542,50 @@ def test_validation_path_eval_mode_psnr_ssim_fp32(env):
     got = runner.disc(inp=x_real.cuda())
     wantd = O.disc_forward(PD, SD, x_real, False, small_disc)
   assert float((got['logits'].cpu() - wantd['logits']).abs().max()) < 2e-4 * max(1.0, float(wantd['logits'].abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('graphs', [False, True])
+def test_pretrained_prefetch_is_an_exact_reordering(env, graphs):
+  """prefetch_pretrained (the frozen RecNet forward of batch t+1 issued during step t) must not
+  change anything: same losses and parameters as the plain schedule over an epoch of 4 batches."""
+  Configuration, set_dtype = env
+  from training import build_runner
+  from csmri_hip import ops
+  set_dtype('bf16')
+  batches = [{k: v.cuda() for k, v in O.synth_batch(2, 128, 128, acc=4, seed=60 + i).items()} for i in range(4)]
+  outs = []
+  for prefetch in (False, True):
+    torch.manual_seed(7)
+    import utils
+    conf = gan_conf(Configuration, 'bf16')
+    utils.set_random_seeds(conf.seed)
+    r = build_runner(conf, 'adversarial', '0', 'train')
+    r.overlap_streams = True
+    r.prefetch_pretrained = prefetch
+    r._request_data = lambda loader, volatile=False, r=r: _next_or_none(r)
+    chans = [f for _, bn, drop, f in r.disc._layers if bn is not None and drop]
+    g = torch.Generator().manual_seed(3)
+    if graphs:
+      r.enable_graphs(batches[0])
+      torch.manual_seed(11)
+    else:
+      r.disc.injected_dropout = [(torch.rand(2, c, generator=g) < 0.5).float() * 2.0
+                                 for _ in range(4 * 3) for c in chans]
+    import random
+    random.seed(5)
+    losses, _ = r.train_epoch(Loader(batches), 1)
+    torch.cuda.synchronize()
+    outs.append(({k: v.value for k, v in losses.items()},
+                 torch.cat([p.detach().float().reshape(-1) for p in r.gen.parameters() if p.requires_grad] +
+                           [p.detach().float().reshape(-1) for p in r.disc.parameters()]).cpu()))
+  assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+  assert torch.equal(outs[0][1], outs[1][1])
+
+
+def _next_or_none(r):
+  try:
+    return next(r.data_iter)
+  except StopIteration:
+    r.data_iter = None
+    return None
