@@ -27,6 +27,28 @@ def test_library_exports_every_declared_symbol():
   assert csmri_hip.lib.raw('csmri_version')() >= 100
 
 
+def test_device_code_has_no_packed_fp32_instructions(tmp_path):
+  """csrc/Makefile builds the gfx950 code without v_pk_*_f32 (such kernels
+  return wrong lanes next to MFMA kernels of another hipGraph branch).  Disassemble what ships."""
+  import glob
+  import shutil
+  import subprocess
+  objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+  if not os.path.exists(objdump):
+    pytest.skip('llvm-objdump not available')
+  lib = shutil.copy(os.path.join(PKG, 'csmri_hip', 'libcsmri_hip.so'), str(tmp_path / 'lib.so'))
+  subprocess.run([objdump, '--offloading', 'lib.so'], cwd=str(tmp_path), check=True,
+                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+  objs = glob.glob(str(tmp_path / 'lib.so.*gfx950*'))
+  assert len(objs) >= 8, objs                       # one code object per .hip source
+  mfma = 0
+  for o in objs:
+    asm = subprocess.run([objdump, '-d', o], check=True, capture_output=True, text=True).stdout
+    assert not re.search(r'\bv_pk_(add|mul|fma)_f32\b', asm), 'packed fp32 VALU op in %s' % os.path.basename(o)
+    mfma += len(re.findall(r'\bv_mfma_f32_16x16x32_bf16\b', asm))
+  assert mfma > 500                                 # the disassembly is the real thing
+
+
 def test_argument_validation_needs_no_gpu():
   import ctypes as C
   import csmri_hip
