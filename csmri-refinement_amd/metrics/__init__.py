@@ -11,6 +11,54 @@ import torch
 from csmri_hip import ops
 
 
+class SharedVec(object):
+  """A device vector that several metrics index into (all loss scalars of one training step).
+  The sum of two shared vectors is computed once, however many of their elements are added:
+  accumulating the per-step losses over an epoch costs one launch per step, not one per loss."""
+
+  def __init__(self, t):
+    self.t = t
+    self._sum = None
+
+  def plus(self, other):
+    if self._sum is None or self._sum[0] is not other:
+      self._sum = (other, SharedVec(self.t + other.t))
+    return self._sum[1]
+
+  def scaled(self, f):
+    if self._sum is None or self._sum[0] != ('scale', f):
+      self._sum = (('scale', f), SharedVec(self.t * f))
+    return self._sum[1]
+
+
+class VecRef(object):
+  """Element ``idx`` of a SharedVec, usable where a 0-dim tensor or a float is."""
+
+  def __init__(self, shared, idx):
+    self.shared, self.idx = shared, idx
+
+  def tensor(self):
+    return self.shared.t[self.idx]
+
+  def item(self):
+    return self.tensor().item()
+
+  def __float__(self):
+    return float(self.item())
+
+  def __add__(self, other):
+    if isinstance(other, VecRef):
+      if other.idx == self.idx:
+        return VecRef(self.shared.plus(other.shared), self.idx)
+      return self.tensor() + other.tensor()
+    return self.tensor() + other
+
+  __radd__ = __add__
+
+  def __truediv__(self, n):
+    return VecRef(self.shared.scaled(1.0 / n), self.idx)
+
+
 class Metric(object):
   """Running mean; ``values`` may be a float, a 0-dim device tensor or an iterable."""
   higher_is_better = True
@@ -30,7 +78,7 @@ class Metric(object):
 
   @staticmethod
   def _f(v):
-    return float(v.item()) if isinstance(v, torch.Tensor) else float(v)
+    return float(v.item()) if isinstance(v, (torch.Tensor, VecRef)) else float(v)
 
   @property
   def value(self):

@@ -24,7 +24,7 @@ import os
 import torch
 
 import utils
-from metrics import get_metric_fn, get_loss_metric, MaxMetric
+from metrics import get_metric_fn, get_loss_metric, MaxMetric, SharedVec, VecRef
 from models import construct_model
 from models.criteria import get_criterion
 from training.adversarial_training import get_discriminator_input_fn
@@ -148,6 +148,7 @@ class AdversarialRunner(BaseRunner):
     self._pf_stream = None
     self.third_pass_early = os.environ.get('CSMRI_THIRD_EARLY', '1') != '0'   # with vgg_early (single GPU)
     self._side_stream3 = None
+    self._metric_stream = None
     self.vgg_early = None                 # None: decided at the first step (True on a single GPU)
     self.batch_disc_passes = True         # D(fake) and D(real) of the D phase as one grouped pass
 
@@ -340,7 +341,23 @@ class AdversarialRunner(BaseRunner):
     st['total_gen'] = self._weighted_total(gen_losses, self.gen_loss_weights)
     self._join_prefetch(st, 2)
 
+  def _fork_train_metrics(self, st):
+    """The training metrics only read forward results: compute them on their own stream next to
+    the generator backward instead of as a serial tail of ~20 tiny launches after the G step."""
+    data = (st['batch'], st['out_gen'], st['out_disc_fake'], st['out_disc_real'])
+    if not self.overlap_streams:
+      with torch.no_grad():
+        st['train_metrics'] = self._compute_train_metrics(data)
+      return
+    if self._metric_stream is None:
+      self._metric_stream = torch.cuda.Stream()
+    self._metric_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(self._metric_stream), torch.no_grad():
+      st['train_metrics'] = self._compute_train_metrics(data)
+    st['_metrics_pending'] = True
+
   def _seg3(self, st):
+    self._fork_train_metrics(st)
     if st.get('out_disc_fake_early') is not None:
       # the third D pass lives on its own stream: run D's Adam there too.  Only that pass's
       # backward (data gradients through the UPDATED D, ordering A) needs the new weights; the
@@ -356,13 +373,14 @@ class AdversarialRunner(BaseRunner):
     ops.join_wgrad_stream()
     st['names'].append('gen_loss')
     st['vals'].append(st['total_gen'].detach())
+    if st.pop('_metrics_pending', False):
+      torch.cuda.current_stream().wait_stream(self._metric_stream)
     self._join_prefetch(st, 3)
 
   def _seg4(self, st):
     self.gen_optimizer.apply()
     self._join_prefetch(st, 4)
-    data = (st['batch'], st['out_gen'], st['out_disc_fake'], st['out_disc_real'])
-    metrics = self._compute_train_metrics(data)
+    metrics = st.pop('train_metrics')
     st['metric_names'] = list(metrics.keys())
     vec = [v.float().reshape(()) for v in st['vals']] + \
           [m.sum_values.float().reshape(()) if torch.is_tensor(m.sum_values)
@@ -455,13 +473,17 @@ class AdversarialRunner(BaseRunner):
   def _run_segments_graphed(self, batch, batch_next=None, pre_cur=None):
     from csmri_hip import ops
     G = self._graph
-    for k, v in G['static'].items():
-      v.copy_(batch[k], non_blocking=True)
+    dst = list(G['static'].values())
+    src = [batch[k] for k in G['static']]
     if G['static_next'] is not None:
       nb = batch_next if batch_next is not None else batch       # last step of an epoch: nothing to prefetch
-      for k, v in G['static_next'].items():
-        v.copy_(nb[k], non_blocking=True)
-      G['static_pre'].copy_(pre_cur, non_blocking=True)
+      dst += list(G['static_next'].values()) + [G['static_pre']]
+      src += [nb[k] for k in G['static_next']] + [pre_cur]
+    if all(t.is_cuda for t in src):
+      torch._foreach_copy_(dst, src)                             # one multi-tensor launch
+    else:
+      for d, t in zip(dst, src):
+        d.copy_(t, non_blocking=True)
     if G['pool'] is not None:
       G['pool'].external_plan = False
       G['pool'].prepare(G['pool'].buffer[:G['static']['inp'].shape[0]])
@@ -517,8 +539,9 @@ class AdversarialRunner(BaseRunner):
     if self.prefetch_pretrained:
       self._pf = (batch_next, st['pre_next'] if batch_next is not None else None)
     n = len(st['names'])
-    loss_metrics = {name: get_loss_metric(vec[i]) for i, name in enumerate(st['names'])}
-    self._last_metrics = {name: MaxMetric(vec[n + j]) for j, name in enumerate(st['metric_names'])}
+    shared = SharedVec(vec)          # epoch accumulation adds the whole vector once per step
+    loss_metrics = {name: get_loss_metric(VecRef(shared, i)) for i, name in enumerate(st['names'])}
+    self._last_metrics = {name: MaxMetric(VecRef(shared, n + j)) for j, name in enumerate(st['metric_names'])}
     return 1, loss_metrics, (st['batch'], st['out_gen'], st['out_disc_fake'], st['out_disc_real'])
 
   def _val_step(self, loader, compute_metrics=True):
