@@ -21,6 +21,15 @@ def bump_weight_epoch():
   _EPOCH[0] += 1
 
 
+def _weight_epoch(layer):
+  """Packed copies of a layer's weights are current while this value is unchanged: the global epoch
+  (loads, anything unknown) and the epoch of the layer's PackGroup (its own optimizer's steps)."""
+  if layer.frozen:
+    return -1
+  group = getattr(layer, 'group', None)
+  return (_EPOCH[0], group.epoch if group is not None else 0)
+
+
 def stream():
   return torch.cuda.current_stream().cuda_stream
 
@@ -149,7 +158,7 @@ class ConvLayer(object):
   def _pack(self, mode):
     key = mode
     ent = self._packs.get(key)
-    epoch = -1 if self.frozen else _EPOCH[0]
+    epoch = _weight_epoch(self)
     if ent is not None and ent[0] == epoch and ent[1].device == self.weight.device:
       return ent[1], ent[2], ent[3], ent[4]
     group = getattr(self, 'group', None)
@@ -171,7 +180,7 @@ class ConvLayer(object):
   def bias_padded(self):
     if self.bias is None:
       return None
-    epoch = -1 if self.frozen else _EPOCH[0]
+    epoch = _weight_epoch(self)
     if self._bias_pad is None or self._bias_pad[0] != epoch or \
         self._bias_pad[1].device != self.bias.device:
       group = getattr(self, 'group', None)
@@ -202,6 +211,22 @@ class PackGroup(object):
     for l in self.layers:
       l.group = self
     self._tables = {}
+    self.epoch = 0          # bumped by the optimizer that owns these weights (FlatAdam.pack_groups)
+
+  def bump(self):
+    self.epoch += 1
+
+  def modes(self):
+    return sorted(set(m for l in self.layers for m in l._packs))
+
+  def repack_stale(self, modes=None):
+    """Re-pack now (current stream) every mode whose packs are stale, instead of at first use."""
+    for mode in (self.modes() if modes is None else modes):
+      members = [l for l in self.layers if mode in l._packs]
+      if members and any(l._packs[mode][0] != _weight_epoch(l) for l in members):
+        self.repack(mode)
+    if any(l._bias_pad is not None and l._bias_pad[0] != _weight_epoch(l) for l in self.layers):
+      self.refresh_biases()
 
   def refresh_biases(self):
     """One multi-tensor copy of every member's bias into its zero-padded fp32 buffer."""
@@ -211,9 +236,8 @@ class PackGroup(object):
       return False
     torch._foreach_copy_([l._bias_pad[1][:l.cout] for l in members],
                          [l.bias.detach() for l in members])
-    epoch = _EPOCH[0]
     for l in members:
-      l._bias_pad = (epoch, l._bias_pad[1])
+      l._bias_pad = (_weight_epoch(l), l._bias_pad[1])
     return True
 
   def repack(self, mode):
@@ -234,10 +258,9 @@ class PackGroup(object):
       tab = (sig, host.to(members[0].weight.device), len(members))
       self._tables[mode] = tab
     lib.call('csmri_pack_weight_multi', tab[1].data_ptr(), tab[2], stream())
-    epoch = _EPOCH[0]
     for l in members:
       e = l._packs[mode]
-      l._packs[mode] = (epoch,) + tuple(e[1:])
+      l._packs[mode] = (_weight_epoch(l),) + tuple(e[1:])
     return True
 
 
@@ -461,8 +484,12 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
   def launch():
     slab = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)
     d.slab = slab.data_ptr()
-    with _Timed(_tile_label('wgrad', d.dtype, d.Cout),
-                2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw):
+    label = _tile_label('wgrad', d.dtype, d.Cout)
+    if PROFILE_SHAPES:
+      label += ' B%d %dx%d->%dx%d Cin%d Cout%d k%d s%d up%d refl%d sk%d' % (
+          b, h, w, ho, wo, layer.cin_p, layer.cout_p, layer.kh, layer.stride, int(layer.upsample),
+          int(layer.border == BORDER_REFLECT), d.splitk)
+    with _Timed(label, 2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw):
       lib.call('csmri_wgrad', C.byref(d), stream())
 
   side = _WGRAD['stream']

@@ -119,6 +119,37 @@ def ensure_pack_group(module):
   return module._pack_group
 
 
+def trainable_pack_groups(model):
+  """The PackGroups of ``model``'s sub-networks if together they hold EVERY trainable conv layer
+  of it (then an optimizer step on the model's weights only has to invalidate these), else None."""
+  owners = [m for m in model.modules() if getattr(m, '_pack_group', None) is not None]
+  groups = [ensure_pack_group(m) for m in owners]
+  covered = set(id(l) for g in groups for l in g.layers)
+  for m in model.modules():
+    if isinstance(m, ConvParams) and m.layer is not None and not m.layer.frozen and id(m.layer) not in covered:
+      return None
+  return groups
+
+
+def refresh_packs(model):
+  """After weights were replaced wholesale (checkpoint load): bring every EXISTING packed copy up
+  to date now and in place, frozen layers included -- captured graphs keep reading those buffers."""
+  owners = []
+  for m in model.modules():
+    if getattr(m, '_pack_group', None) is not None:
+      owners.append(m)
+    if isinstance(m, ConvParams) and m.layer is not None and m.layer.frozen:
+      layer = m.layer
+      for mode in list(layer._packs):
+        layer._packs[mode] = (None,) + tuple(layer._packs[mode][1:])
+        layer._pack(mode)
+      if layer._bias_pad is not None:
+        layer._bias_pad = (None, layer._bias_pad[1])
+        layer.bias_padded()
+  for m in owners:
+    ensure_pack_group(m).repack_stale()
+
+
 def freeze(module):
   for p in module.parameters():
     p.requires_grad = False

@@ -118,6 +118,15 @@ class AdversarialRunner(BaseRunner):
     super(AdversarialRunner, self).__init__(cuda)
     self.gen, self.disc = gen_model, disc_model
     self.gen_optimizer, self.disc_optimizer = gen_optimizer, disc_optimizer
+    # a step of one network's optimizer leaves the packed weights of the other current
+    from models.utils import trainable_pack_groups
+    self._group_epochs = os.environ.get('CSMRI_GROUP_EPOCH', '1') != '0'        # A/B knob
+    if not self._group_epochs:
+      pass
+    elif gen_optimizer is not None and hasattr(gen_optimizer, 'pack_groups'):
+      gen_optimizer.pack_groups = lambda: trainable_pack_groups(self.gen)
+    if self._group_epochs and disc_optimizer is not None and hasattr(disc_optimizer, 'pack_groups'):
+      disc_optimizer.pack_groups = lambda: trainable_pack_groups(self.disc)
     self.train_gen_metric_fns = train_gen_metric_fns or {}
     self.train_disc_metric_fns = train_disc_metric_fns or {}
     self.val_metric_fns = val_metric_fns or {}
@@ -174,6 +183,10 @@ class AdversarialRunner(BaseRunner):
       assert 'discriminator' in state_dict, 'Incompatible checkpoint'
       self.disc.load_state_dict(state_dict['discriminator'])
     ops.bump_weight_epoch()
+    from models.utils import refresh_packs
+    for net in (self.gen, self.disc):
+      if net is not None:
+        refresh_packs(net)
     if self.gen_optimizer is not None:
       assert 'gen_optimizer' in state_dict, 'Incompatible checkpoint'
       self.gen_optimizer.load_state_dict(state_dict['gen_optimizer'])
@@ -307,7 +320,7 @@ class AdversarialRunner(BaseRunner):
     the D-bucket all-reduce.  Autograd replays the stream assignment in the backward, so the two
     gradient chains into `pred` overlap as well."""
     if self._side_stream is None:
-      self._side_stream = torch.cuda.Stream()
+      self._side_stream = torch.cuda.Stream(priority=int(os.environ.get('CSMRI_PRIO_VGG', '0')))
     self._side_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(self._side_stream):
       for name, criterion in self.gen_criteria.items():
@@ -341,6 +354,11 @@ class AdversarialRunner(BaseRunner):
     st['total_gen'] = self._weighted_total(gen_losses, self.gen_loss_weights)
     self._join_prefetch(st, 2)
 
+  def _repack_disc(self):
+    from models.utils import trainable_pack_groups
+    for g in trainable_pack_groups(self.disc) or []:
+      g.repack_stale()
+
   def _fork_train_metrics(self, st):
     """The training metrics only read forward results: compute them on their own stream next to
     the generator backward instead of as a serial tail of ~20 tiny launches after the G step."""
@@ -373,6 +391,12 @@ class AdversarialRunner(BaseRunner):
     ops.join_wgrad_stream()
     st['names'].append('gen_loss')
     st['vals'].append(st['total_gen'].detach())
+    if st.get('out_disc_fake_early') is not None and self._group_epochs:
+      # D's forward-mode packs for the NEXT step, behind the third pass's backward on its stream
+      # (next to the rest of the generator backward) instead of in front of the next D forward
+      with torch.cuda.stream(self._side_stream3):
+        self._repack_disc()
+      torch.cuda.current_stream().wait_stream(self._side_stream3)
     if st.pop('_metrics_pending', False):
       torch.cuda.current_stream().wait_stream(self._metric_stream)
     self._join_prefetch(st, 3)
@@ -439,11 +463,13 @@ class AdversarialRunner(BaseRunner):
       segments = (whole,)
     else:
       segments = (self._seg1, self._seg2, self._seg3, self._seg4)
+    prio = int(os.environ.get('CSMRI_PRIO_MAIN', '0'))
+    cap_stream = torch.cuda.Stream(priority=prio)
     try:
       for seg in segments:
         g = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
-        with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None,
+        with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None, stream=cap_stream,
                               capture_error_mode='thread_local'):
           seg(st)
         graphs.append(g)

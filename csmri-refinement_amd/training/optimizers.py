@@ -40,6 +40,9 @@ class FlatAdam(object):
     self.bucket = GradBucket(self.flat_g)
     self.param_groups = [{'lr': lr, 'betas': self.betas, 'eps': eps, 'weight_decay': 0,
                           'amsgrad': False, 'params': list(range(len(self.params)))}]
+    # callable -> PackGroups holding packed copies of exactly these weights: a step then invalidates
+    # only those (without it: the global epoch, i.e. every trainable network's packs)
+    self.pack_groups = None
     ops.bump_weight_epoch()
 
   def zero_grad(self):
@@ -60,7 +63,12 @@ class FlatAdam(object):
                       self.param_groups[0]['lr'], self.betas[0], self.betas[1], self.eps,
                       self.step_dev, self._scale)
     self.step_count += 1
-    ops.bump_weight_epoch()
+    groups = self.pack_groups() if self.pack_groups is not None else None
+    if groups is None:
+      ops.bump_weight_epoch()
+    else:
+      for g in groups:
+        g.bump()
 
   def step(self):
     self.wait_allreduce()
