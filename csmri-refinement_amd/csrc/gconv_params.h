@@ -47,3 +47,9 @@ int gconv_glds_eligible(const csmri_gconv_desc* d);
 int gconv_glds_bn(const csmri_gconv_desc* d);
 int gconv_glds_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 void gconv_glds_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
+
+// gconv_glds256.hip
+int gconv_glds256_eligible(const csmri_gconv_desc* d);
+int gconv_glds256_splitk(const csmri_gconv_desc* d);
+const char* gconv_glds256_name(const csmri_gconv_desc* d);
+int gconv_glds256_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);

@@ -25,6 +25,11 @@ CASES = {
     'u32x64z': (32, 64, 4, 1, 'zero', False, 259, 259, 8),
     'vgg5_2b16': (512, 512, 3, 1, 'zero', False, 16, 16, 16),
     'vgg4_2b16': (512, 512, 3, 1, 'zero', False, 32, 32, 16),
+    'vgg3_2b16': (256, 256, 3, 1, 'zero', False, 64, 64, 16),
+    'vgg4_1b16': (256, 512, 3, 1, 'zero', False, 32, 32, 16),
+    'vgg3_1b16': (128, 256, 3, 1, 'zero', False, 64, 64, 16),
+    'vgg2_2b16': (128, 128, 3, 1, 'zero', False, 128, 128, 16),
+    'vgg2_1b16': (64, 128, 3, 1, 'zero', False, 128, 128, 16),
     'rec_first': (2, 32, 3, 1, 'zero', False, 256, 256, 8),
     'rec_last': (32, 2, 3, 1, 'zero', False, 256, 256, 8),
 }
