@@ -93,6 +93,8 @@ __global__ __launch_bounds__(512, 2) void gconv_glds256_kernel(const GParams p) 
       __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(buf + TILE_Q + (j * NW + wid) * 1024), 16, 0, 0);
       wptr[j] += 128;
     }
+  };
+  auto advance = [&]() {          // after every issue: on to the next 64 channels / tap / concat source
     ci += 64;
     if (ci == p.Cin) { ci = 0; if (++tx == p.TW) { tx = 0; ++ty; } compute_ptrs(); }
     else if (ci == p.c0) compute_ptrs();
@@ -105,32 +107,42 @@ __global__ __launch_bounds__(512, 2) void gconv_glds256_kernel(const GParams p) 
     for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int r16 = lane & 15, g = lane >> 4;
 
-  auto compute = [&](const char* buf) {
+  auto load_frags = [&](const char* buf, int kc, bf16x8_t* pf, bf16x8_t* qf) {
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-      bf16x8_t pf[FN], qf[FM];
+    for (int i = 0; i < FN; ++i)
+      pf[i] = *(const bf16x8_t*)(buf + TILE_Q + g256_off(wn * WTN + i * 16 + r16, kc * 4 + g));
 #pragma unroll
-      for (int i = 0; i < FN; ++i)
-        pf[i] = *(const bf16x8_t*)(buf + TILE_Q + g256_off(wn * WTN + i * 16 + r16, kc * 4 + g));
+    for (int j = 0; j < FM; ++j)
+      qf[j] = *(const bf16x8_t*)(buf + g256_off(wm * WTM + j * 16 + r16, kc * 4 + g));
+  };
+  auto mma = [&](const bf16x8_t* pf, const bf16x8_t* qf) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
 #pragma unroll
       for (int j = 0; j < FM; ++j)
-        qf[j] = *(const bf16x8_t*)(buf + g256_off(wm * WTM + j * 16 + r16, kc * 4 + g));
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
-    }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
-  // two LDS buffers: step s+1 streams in while step s is multiplied; one barrier per step
-  if (s_begin < s_end) issue(smem);
+  // two LDS buffers: step s+1 streams in while step s is multiplied; one barrier per step.  The
+  // first fragment reads of a step are issued BEFORE the next step's LDS-DMA (address updates +
+  // 8 DMA instructions per thread), so their latency runs under that issue work.
+  if (s_begin < s_end) { issue(smem); advance(); }
   for (int s = s_begin; s < s_end; ++s) {
     const int par = (s - s_begin) & 1;
+    const char* cur = smem + par * BUF;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    bf16x8_t pf[FN], qf[FM];
+    load_frags(cur, 0, pf, qf);
+    // (tried: skewing this issue between the two waves of a SIMD so that one issues while the other
+    //  multiplies -- 3 % slower than both issuing here)
     if (s + 1 < s_end) issue(smem + (par ^ 1) * BUF);
-    compute(smem + par * BUF);
+    mma(pf, qf);
+    load_frags(cur, 1, pf, qf);
+    mma(pf, qf);
+    if (s + 1 < s_end) advance();
   }
 
   // ---- epilogue (gconv_glds.hip's, without the BatchNorm partial sums) -----------------------
