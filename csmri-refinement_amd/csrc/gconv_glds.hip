@@ -131,6 +131,23 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
     }
   };
+  auto load_frags = [&](const char* buf, int kc, bf16x8_t* pf, bf16x8_t* qf) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+      pf[i] = *(const bf16x8_t*)(buf + TILE_Q + glds_off(wn * WTN + i * 16 + r16, kc * 4 + g));
+#pragma unroll
+    for (int j = 0; j < FM; ++j)
+      qf[j] = *(const bf16x8_t*)(buf + glds_off(wm * WTM + j * 16 + r16, kc * 4 + g));
+  };
+  auto mma = [&](const bf16x8_t* pf, const bf16x8_t* qf) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
   if constexpr (NST >= 3) {
     // ring of NST LDS buffers for grids of at most one workgroup per CU: NST-1 steps of LDS-DMA stay
     // in flight across the (raw) barrier, retired by counted vmcnt -- latency-bound skinny problems
@@ -156,8 +173,14 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
       char* cur = smem + ((s - s_begin) & 1) * BUF;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      // first fragment reads ahead of the next step's DMA issue (their latency runs under the address
+      // updates and the 8 or 6 DMA instructions), MFMA blocks at raised priority
+      bf16x8_t pf[FN], qf[FM];
+      load_frags(cur, 0, pf, qf);
       if (s + 1 < s_end) issue(s + 1, smem + (((s - s_begin) & 1) ^ 1) * BUF);
-      compute(cur);
+      mma(pf, qf);
+      load_frags(cur, 1, pf, qf);
+      mma(pf, qf);
     }
   } else {
     for (int s = s_begin; s < s_end; ++s) {
