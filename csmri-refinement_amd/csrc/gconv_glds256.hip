@@ -125,6 +125,9 @@ __global__ __launch_bounds__(512, 2) void gconv_glds256_kernel(const GParams p) 
     __builtin_amdgcn_s_setprio(0);
   };
 
+  // (tried: K order (64-channel chunk, tap) instead of (tap, chunk), so that the shifted re-reads of
+  //  the same input rows hit in L2 -- PMC shows ~3x the input fetched from HBM on conv3_x -- but the
+  //  per-step pointer recomputation costs more than it saves: 793 vs 900 TFLOP/s.)
   // two LDS buffers: step s+1 streams in while step s is multiplied; one barrier per step.  The
   // first fragment reads of a step are issued BEFORE the next step's LDS-DMA (address updates +
   // 8 DMA instructions per thread), so their latency runs under that issue work.
