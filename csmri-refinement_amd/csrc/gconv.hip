@@ -349,6 +349,15 @@ static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
   CSMRI_CHECK_ARG((long long)p.nsteps * bke <= d->Kp);
   p.steps_per_split = cdiv(p.nsteps, splitk);
   p.mtiles = cdiv(p.M, c.BM); p.ntiles = cdiv(d->Cout, c.BN); p.nt_major = 0;
+  auto lg2 = [](long long v) { int s = 0; while ((1ll << s) < v) ++s; return (1ll << s) == v ? s : -1; };
+  p.wo_shift = lg2(d->Wo); p.howo_shift = lg2((long long)d->Ho * d->Wo);
+  if (p.wo_shift < 0 || p.howo_shift < 0) p.wo_shift = p.howo_shift = -1;
+  p.dense_out = !d->out_halo && nclass == 1 && d->out_sy == 1 && d->out_sx == 1 && d->out_oy == 0 && d->out_ox == 0 &&
+                d->Hout_t == d->Ho && d->Wout_t == d->Wo;
+  const long long in_px = (long long)d->B * d->Hin * d->Win, out_px = (long long)d->B * d->Hout_t * d->Wout_t;
+  const long long max_ps = d->in0_pix_stride > d->in1_pix_stride ? d->in0_pix_stride : d->in1_pix_stride;
+  p.off32 = in_px * max_ps * 2 < (1ll << 31) && out_px * d->out_pix_stride * 4 < (1ll << 31) &&
+            out_px * (d->g_src ? d->g_pix_stride : 0) * 4 < (1ll << 31);
   return CSMRI_OK;
 }
 

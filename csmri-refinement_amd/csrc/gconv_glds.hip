@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
   for (int j = 0; j < GA; ++j) {
     const int m = m0 + (j * 4 + wid) * 8 + lrow;
     if (m < p.M) {
-      int b = m / HoWo, r = m - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
+      int b, oy, ox;
+      if (p.howo_shift >= 0) { b = m >> p.howo_shift; const int r = m & (HoWo - 1); oy = r >> p.wo_shift; ox = r & (p.Wo - 1); }
+      else { b = m / HoWo; const int r = m - b * HoWo; oy = r / p.Wo; ox = r - oy * p.Wo; }
       by[j] = oy * p.S + p.dy0; bx[j] = ox * p.S + p.dx0; ib[j] = b * p.Hin * p.Win;
     } else { by[j] = 0; bx[j] = 0; ib[j] = -1; }
   }
@@ -80,7 +82,9 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
       else ok = ok && (unsigned)u < (unsigned)Hv && (unsigned)v < (unsigned)Wv;
       if (p.ups) { u >>= 1; v >>= 1; }
       const int pix = ib[j] + u * p.Win + v;
-      aptr[j] = ok ? src + (size_t)pix * ps : g_zero_page;
+      // byte offset: one 32-bit multiply when the tensor is < 2 GiB (host check), else 64-bit
+      const char* g = p.off32 ? src + (unsigned)pix * (unsigned)ps : src + (size_t)pix * ps;
+      aptr[j] = ok ? g : g_zero_page;
       ainc[j] = ok ? 128u : 0u;
     }
   };
@@ -206,8 +210,14 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
     const bool mv = m < p.M;
     OutPos op; op.base = p.out; op.opix = 0; op.gpix = 0; op.g_ok = true;
     if (mv) {
-      int b = m / HoWo, r = m - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
-      op = gconv_out_pos(p, b, oy * p.osy + ooy, ox * p.osx + oox);
+      if (p.dense_out) {               // position index == m: no decomposition
+        op.opix = (size_t)m * p.ops; op.gpix = (size_t)m * p.gps;
+      } else {
+        int b, oy, ox;
+        if (p.howo_shift >= 0) { b = m >> p.howo_shift; const int r = m & (HoWo - 1); oy = r >> p.wo_shift; ox = r & (p.Wo - 1); }
+        else { b = m / HoWo; const int r = m - b * HoWo; oy = r / p.Wo; ox = r - oy * p.Wo; }
+        op = gconv_out_pos(p, b, oy * p.osy + ooy, ox * p.osx + oox);
+      }
     }
 #pragma unroll
     for (int i = 0; i < FN; ++i) {

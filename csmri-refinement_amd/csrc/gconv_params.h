@@ -14,6 +14,10 @@ struct GParams {
   int M, nsteps, steps_per_split, mtiles, ntiles;
   int nt_major;   // gconv_glds: tile order that keeps the larger operand shared inside an XCD
   char* out2; int o2ps, win_y0, win_x0, win_h, win_w;   // output window (csmri_gconv_desc.out_halo)
+  // fast paths (host-decided, wave-uniform):
+  int wo_shift, howo_shift;   // log2(Wo), log2(Ho*Wo) when both are powers of two, else -1: m -> (b,oy,ox) by shifts
+  int dense_out;              // output position index == m (no window / stride / offset / classes): no division at all
+  int off32;                  // every input / output byte offset fits 32 bits
 };
 
 // where output position (b, ty, tx) of the tensor goes: window -> dense `out`, else halo buffer
