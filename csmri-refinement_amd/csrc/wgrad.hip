@@ -473,7 +473,7 @@ typedef __attribute__((address_space(3))) void* wlptr_t;
 // origin + a per-lane constant, which cuts the address arithmetic from ~100 to ~15 vector
 // instructions per 16-byte piece; the general kernel below is vector-ALU bound on exactly that.
 template <int BP, int BQ, int WP, int WQ, bool REFLECT, bool UPS>
-__global__ __launch_bounds__(256, (BP == 128 && BQ == 128) ? 3 : 4) void wgrad_glds_row_kernel(const WParams p) {
+__global__ __launch_bounds__(256, ((BP == 128 && BQ == 128) || (BP == 256 && BQ == 64)) ? 3 : 4) void wgrad_glds_row_kernel(const WParams p) {
   constexpr int PS = 64;
   constexpr int CP = BP / 8, CQ = BQ / 8;
   constexpr int NXI = CP / 4, NYI = (CQ + 3) / 4;
@@ -722,11 +722,21 @@ __global__ __launch_bounds__(256, 3) void wgrad_glds_kernel(const WParams p) {
 }
 
 struct WConfig { int BP, BQ; };
+// geometries the row-aligned LDS-DMA kernel takes (64-pixel K steps aligned with output rows)
+static bool wgrad_row_aligned(const csmri_wgrad_desc* d) {
+  return d->Wo % 64 == 0 || (64 % d->Wo == 0 && ((long long)d->Ho * d->Wo) % 64 == 0);
+}
 static WConfig pick_wconfig(const csmri_wgrad_desc* d) {
   WConfig c;
   if (d->Cout > 64) { c.BP = 128; c.BQ = 128; }
-  else if (d->Cout > 32) { c.BP = 128; c.BQ = 64; }
-  else if (d->Cout > 16) { c.BP = 256; c.BQ = 32; }
+  else if (d->Cout > 32) {
+    // 256 x 64 with one 64 x 64 tile per wave: 1.0 transposed LDS reads per MFMA instead of 1.5
+    static const char* env = getenv("CSMRI_WGRAD_BP64");       // A/B knob
+    const bool wide = (env ? atoi(env) == 256 : true) && d->dtype == CSMRI_BF16 && !getenv("CSMRI_WGRAD_TR") &&
+                      (long long)d->KH * d->KW * d->Cin >= 256 && wgrad_row_aligned(d);
+    c.BP = wide ? 256 : 128; c.BQ = 64;
+  }
+  else if (d->Cout > 16) { c.BP = 256; c.BQ = 32; }      // (512 x 32, one 128 x 32 tile per wave: measured slower)
   else { c.BP = 256; c.BQ = 16; }
   return c;
 }
@@ -790,6 +800,18 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
   if (row_aligned) {
     const dim3 grid(p.ptiles * p.qtiles, 1, p.splitk);
     const bool refl = p.border == CSMRI_BORDER_REFLECT;
+    if (lds > 48 * 1024) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipSuccess;
+        e = hipFuncSetAttribute((const void*)wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+      }
+    }
     if (refl && p.ups) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, true>), grid, dim3(256), lds, st, p);
     else if (refl) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, false>), grid, dim3(256), lds, st, p);
     else if (p.ups) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, true>), grid, dim3(256), lds, st, p);
@@ -833,6 +855,7 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   static const char* use_tr = getenv("CSMRI_WGRAD_TR");       // A/B knob: register-staged variant
   if (d->dtype == CSMRI_BF16 && !use_tr) {
     if (c.BQ == 128) rc = launch_wgrad_glds<128, 128, 2, 2>(p, st);
+    else if (c.BQ == 64 && c.BP == 256) rc = launch_wgrad_glds<256, 64, 4, 1>(p, st);
     else if (c.BQ == 64) rc = launch_wgrad_glds<128, 64, 2, 2>(p, st);
     else if (c.BQ == 32) rc = launch_wgrad_glds<256, 32, 4, 1>(p, st);
     else rc = launch_wgrad_glds<256, 16, 4, 1>(p, st);
