@@ -86,18 +86,21 @@ __global__ __launch_bounds__(512, 2) void gconv_glds256_kernel(const GParams p) 
     wptr[j] = p.w + ((size_t)cls * (size_t)p.wcs + (size_t)(n0 + (j * NW + wid) * 8 + lrow) * p.Kp + chunk * 8) * 2 +
               (size_t)s_begin * 128;
 
-  auto issue = [&](char* buf) {
+  auto issue_a = [&](char* buf) {
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
       __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(buf + (j * NW + wid) * 1024), 16, 0, 0);
       aptr[j] += ainc[j];
     }
+  };
+  auto issue_b = [&](char* buf) {
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
       __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(buf + TILE_Q + (j * NW + wid) * 1024), 16, 0, 0);
       wptr[j] += 128;
     }
   };
+  auto issue = [&](char* buf) { issue_a(buf); issue_b(buf); };
   auto advance = [&]() {          // after every issue: on to the next 64 channels / tap / concat source
     ci += 64;
     if (ci == p.Cin) { ci = 0; if (++tx == p.TW) { tx = 0; ++ty; } compute_ptrs(); }
@@ -120,7 +123,9 @@ __global__ __launch_bounds__(512, 2) void gconv_glds256_kernel(const GParams p) 
       qf[j] = *(const bf16x8_t*)(buf + g256_off(wm * WTM + j * 16 + r16, kc * 4 + g));
   };
   auto mma = [&](const bf16x8_t* pf, const bf16x8_t* qf) {
-    __builtin_amdgcn_s_setprio(1);
+    // the second wave of each SIMD (w + 4) loses the MFMA pipe to the older one and arrives ~1100 cycles
+    // late at every barrier (in-kernel stamps): give it the higher priority
+    if (wid >= 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -135,22 +140,47 @@ __global__ __launch_bounds__(512, 2) void gconv_glds256_kernel(const GParams p) 
   // two LDS buffers: step s+1 streams in while step s is multiplied; one barrier per step.  The
   // first fragment reads of a step are issued BEFORE the next step's LDS-DMA (address updates +
   // 8 DMA instructions per thread), so their latency runs under that issue work.
+#ifdef CSMRI_DBG_STAMPS
+  // diagnostic build: per-wave cycle sums of the loop phases, written to p.slab (host passes a buffer)
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, last_t;
+#define STAMP(i) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    ph[i] += t_ - last_t; last_t = t_; } while (0)
+  { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_t) :: "memory"); }
+#else
+#define STAMP(i) do {} while (0)
+#endif
   if (s_begin < s_end) { issue(smem); advance(); }
+  STAMP(2);
   for (int s = s_begin; s < s_end; ++s) {
     const int par = (s - s_begin) & 1;
     const char* cur = smem + par * BUF;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    STAMP(0);
     bf16x8_t pf[FN], qf[FM];
     load_frags(cur, 0, pf, qf);
-    // (tried: skewing this issue between the two waves of a SIMD so that one issues while the other
-    //  multiplies -- 3 % slower than both issuing here)
-    if (s + 1 < s_end) issue(smem + (par ^ 1) * BUF);
+    STAMP(1);
+    // the next step's DMA in two halves, one in front of each MFMA block: a wave is never stuck behind
+    // eight DMA issues (in-kernel stamps: 640 of 3750 cycles per step when issued in one burst)
+    if (s + 1 < s_end) issue_a(smem + (par ^ 1) * BUF);
+    STAMP(2);
     mma(pf, qf);
+    STAMP(3);
     load_frags(cur, 1, pf, qf);
+    if (s + 1 < s_end) issue_b(smem + (par ^ 1) * BUF);
+    STAMP(4);
     mma(pf, qf);
+    STAMP(5);
     if (s + 1 < s_end) advance();
   }
+#ifdef CSMRI_DBG_STAMPS
+  if (lane == 0 && p.slab && p.splitk == 1) {
+    unsigned long long* dbg = (unsigned long long*)p.slab + ((size_t)blockIdx.x * NW + wid) * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dbg[i] = ph[i];
+  }
+#endif
 
   // ---- epilogue (gconv_glds.hip's, without the BatchNorm partial sums) -----------------------
 #pragma unroll
