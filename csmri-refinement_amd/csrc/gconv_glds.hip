@@ -95,6 +95,25 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
     wptr[j] = p.w + ((size_t)cls * (size_t)p.wcs + (size_t)(n0 + (j * 4 + wid) * 8 + lrow) * p.Kp + chunk * 8) * 2 +
               (size_t)s_begin * 128;
 
+  auto issue_a = [&](char* buf) {
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(buf + (j * 4 + wid) * 1024), 16, 0, 0);
+      aptr[j] += ainc[j];
+    }
+  };
+  auto issue_b = [&](char* buf) {
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(buf + TILE_Q + (j * 4 + wid) * 1024), 16, 0, 0);
+      wptr[j] += 128;
+    }
+  };
+  auto advance = [&]() {
+    ci += 64;
+    if (ci == p.Cin) { ci = 0; if (++tx == p.TW) { tx = 0; ++ty; } compute_ptrs(); }
+    else if (ci == p.c0) compute_ptrs();                // switch to the second concat source
+  };
   auto issue = [&](int s, char* buf) {
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
@@ -180,10 +199,12 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
       // first fragment reads ahead of the next step's DMA issue (their latency runs under the address
       // updates and the 8 or 6 DMA instructions), MFMA blocks at raised priority
       bf16x8_t pf[FN], qf[FM];
+      char* nxt = smem + (((s - s_begin) & 1) ^ 1) * BUF;
       load_frags(cur, 0, pf, qf);
-      if (s + 1 < s_end) issue(s + 1, smem + (((s - s_begin) & 1) ^ 1) * BUF);
-      mma(pf, qf);
+      if (s + 1 < s_end) issue_a(nxt);                  // the next step's DMA in two halves, one in front
+      mma(pf, qf);                                      // of each MFMA block
       load_frags(cur, 1, pf, qf);
+      if (s + 1 < s_end) { issue_b(nxt); advance(); }
       mma(pf, qf);
     }
   } else {
