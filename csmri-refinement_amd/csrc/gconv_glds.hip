@@ -171,6 +171,15 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
+#ifdef CSMRI_DBG_STAMPS
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, last_t;
+#define STAMP(i) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    ph[i] += t_ - last_t; last_t = t_; } while (0)
+  { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_t) :: "memory"); }
+#else
+#define STAMP(i) do {} while (0)
+#endif
   if constexpr (NST >= 3) {
     // ring of NST LDS buffers for grids of at most one workgroup per CU: NST-1 steps of LDS-DMA stay
     // in flight across the (raw) barrier, retired by counted vmcnt -- latency-bound skinny problems
@@ -195,28 +204,46 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
     for (int s = s_begin; s < s_end; ++s) {
       char* cur = smem + ((s - s_begin) & 1) * BUF;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(0);
       __syncthreads();
+      STAMP(1);
       // first fragment reads ahead of the next step's DMA issue (their latency runs under the address
       // updates and the 8 or 6 DMA instructions), MFMA blocks at raised priority
       bf16x8_t pf[FN], qf[FM];
       char* nxt = smem + (((s - s_begin) & 1) ^ 1) * BUF;
       load_frags(cur, 0, pf, qf);
       if (s + 1 < s_end) issue_a(nxt);                  // the next step's DMA in two halves, one in front
+      STAMP(2);
       mma(pf, qf);                                      // of each MFMA block
+      STAMP(3);
       load_frags(cur, 1, pf, qf);
       if (s + 1 < s_end) { issue_b(nxt); advance(); }
+      STAMP(4);
       mma(pf, qf);
+      STAMP(5);
     }
   } else {
     for (int s = s_begin; s < s_end; ++s) {
       issue(s, smem);
+      STAMP(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(1);
       __syncthreads();
+      STAMP(2);
       compute(smem);
+      STAMP(3);
       __syncthreads();
+      STAMP(4);
     }
   }
 
+#ifdef CSMRI_DBG_STAMPS
+  if (lane == 0 && p.slab && p.splitk == 1) {
+    unsigned long long* dbg = (unsigned long long*)p.slab + ((size_t)blockIdx.x * 4 + wid) * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dbg[i] = ph[i];
+  }
+#endif
   // ---- epilogue (same contract as gconv_kernel) --------------------------------------------
   float s1[FN][4], s2[FN][4];
   if (p.stats) {
