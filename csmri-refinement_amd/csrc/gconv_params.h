@@ -46,6 +46,11 @@ int tconv_stats_rows(const csmri_gconv_desc* d);
 int tconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 void tconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
 
+// pconv.hip
+int pconv_eligible(const csmri_gconv_desc* d);
+int pconv_stats_rows(const csmri_gconv_desc* d);
+int pconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
+
 // gconv_glds.hip
 int gconv_glds_eligible(const csmri_gconv_desc* d);
 int gconv_glds_bn(const csmri_gconv_desc* d);
