@@ -260,8 +260,8 @@ static GConfig pick_config(const csmri_gconv_desc* d) {
 static int desc_M(const csmri_gconv_desc* d) { return d->B * d->Ho * d->Wo; }
 
 extern "C" int csmri_gconv_stats_rows(const csmri_gconv_desc* d) {
-  if (tconv_eligible(d)) return tconv_stats_rows(d);
   { csmri_gconv_desc t = *d; t.splitk = 1; if (pconv_eligible(&t)) return pconv_stats_rows(d); }
+  if (tconv_eligible(d)) return tconv_stats_rows(d);
   GConfig c = pick_config(d);
   return cdiv(desc_M(d), c.BM) * c.WM;
 }
@@ -374,8 +374,8 @@ static int launch_reduce(const GParams& p, hipStream_t st) {
 // template instance csmri_gconv dispatches to for this problem, spelled as rocprofv3 prints it
 extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n) {
   CSMRI_CHECK_ARG(d && buf && n > 0);
-  if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (pconv_eligible(d)) { snprintf(buf, n, "pconv_kernel<8>"); return CSMRI_OK; }
+  if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (gconv_glds256_eligible(d)) { snprintf(buf, n, "%s", gconv_glds256_name(d)); return CSMRI_OK; }
   if (gconv_glds_eligible(d)) { gconv_glds_kernel_name(d, buf, n); return CSMRI_OK; }
   GConfig c = pick_config(d);
@@ -399,8 +399,8 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
   int rc = build_params(d, p, c);
   if (rc != CSMRI_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (tconv_eligible(d)) return tconv_launch(p, d, st);
   if (pconv_eligible(d)) return pconv_launch(p, d, st);
+  if (tconv_eligible(d)) return tconv_launch(p, d, st);
   if (gconv_glds_eligible(d)) {
     rc = gconv_glds256_eligible(d) ? gconv_glds256_launch(p, d, st) : gconv_glds_launch(p, d, st);
     if (rc != CSMRI_OK) return rc;

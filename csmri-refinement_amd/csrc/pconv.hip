@@ -1,4 +1,4 @@
-// pconv: stride-1 convolutions with MANY input channels (Cin % 64 == 0, >= 128) and at least 128
+// pconv: stride-1 convolutions with 64 or 128 input channels (Cin % 64 == 0; more: see pconv_eligible) and at least 128
 // output channels, bf16 -- the VGG19 conv2_2 .. conv4_4 layers and their data gradients.
 //
 // The 128-row implicit-GEMM kernels (gconv_glds.hip) re-fetch every input row once per filter tap
@@ -201,7 +201,9 @@ int pconv_eligible(const csmri_gconv_desc* d) {
   if (on && atoi(on) == 0) return 0;
   if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
   if (d->nclass > 1 || d->splitk > 1 || d->upsample) return 0;
-  if (d->Cin % 64 || d->Cin < 128 || d->Cout % 128) return 0;
+  // (64 input channels: +12 % over tconv on VGG conv2_1 in isolation, nothing at step level: left with tconv)
+  static const char* minc = getenv("CSMRI_PCONV_MINCIN");      // A/B knob
+  if (d->Cin % 64 || d->Cin < (minc ? atoi(minc) : 128) || d->Cout % 128) return 0;
   // measured (tools/bench_conv.py): +17..25 % over the 128-row kernel at 128 input channels (VGG conv2_2 and
   // its data gradient); at 256+ channels the one-barrier-per-64-MFMA loop with an exposed patch re-stage per
   // chunk loses to gconv_glds / gconv_glds256 (-4..-20 %), so those stay there until this loop is pipelined
