@@ -27,6 +27,9 @@ typedef __attribute__((address_space(3))) void* tlptr_t;
 // k-group) is then conflict-free for EVERY tap shift (planes are a multiple of 256 B apart, and a
 // lane group's two k-groups cover complementary pixels of one 16-pixel run), and a tap shift is a
 // plain byte offset -- no per-tap swizzle arithmetic.  Patch and weights are staged by LDS-DMA.
+#ifndef TCONV_CPS64
+#define TCONV_CPS64 4      // 64 MFMAs per wave between barriers in the 64-channel, 64-output streamed loop
+#endif
 template <int CIN, int FN, bool STREAM>
 __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GParams p) {
   constexpr int VPP = CIN / 8;                      // planes (16-byte chunks per pixel)
@@ -34,6 +37,7 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
   constexpr int KCH = CIN >= 32 ? CIN / 32 : 1;     // K chunks per tap
   constexpr int BN = FN * 16;
   constexpr int WT = BN * 64;                       // bytes of one chunk's weight tile
+  constexpr int CPS = (STREAM && CIN == 64 && FN == 4) ? TCONV_CPS64 : 2;   // chunks per streamed weight stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,8 +99,9 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
   if (!STREAM) {
     for (int q = 0; q < nq; ++q) wload(q, wl + q * WT);
   } else {
-    wload(0, wl);
-    if (nq > 1) wload(1, wl + WT);
+#pragma unroll
+    for (int c = 0; c < CPS; ++c)
+      if (c < nq) wload(c, wl + c * WT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -133,17 +138,17 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
   if (!STREAM) {
     for (int q = 0; q < nq; ++q) compute(wl + q * WT);
   } else {
-    // 2 chunks per stage, two stage buffers: stage st+1 streams in under the MFMAs of stage st
-    const int nst = (nq + 1) >> 1;
+    // CPS chunks per stage, two stage buffers: stage st+1 streams in under the MFMAs of stage st
+    const int nst = (nq + CPS - 1) / CPS;
     for (int st = 0; st < nst; ++st) {
-      char* cur = wl + (st & 1) * 2 * WT;
-      char* nxt = wl + ((st & 1) ^ 1) * 2 * WT;
-      if (st + 1 < nst) {
-        wload(2 * st + 2, nxt);
-        if (2 * st + 3 < nq) wload(2 * st + 3, nxt + WT);
+      char* cur = wl + (st & 1) * CPS * WT;
+      char* nxt = wl + ((st & 1) ^ 1) * CPS * WT;
+#pragma unroll
+      for (int c = 0; c < CPS; ++c) {
+        const int qn = CPS * (st + 1) + c;             // next stage's chunk c, issued in front of this stage's chunk c
+        if (qn < nq) wload(qn, nxt + c * WT);
+        if (CPS * st + c < nq) compute(cur + c * WT);
       }
-      compute(cur);
-      if (2 * st + 1 < nq) compute(cur + WT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -228,7 +233,8 @@ static int launch_tconv(const GParams& p0, const csmri_gconv_desc* d, hipStream_
   const int patch = (CIN / 8) * ((npix_ + 63) / 64) * 1024;      // planes of 64-pixel groups
   const int tpc = CIN >= 32 ? 1 : 32 / CIN, kch = CIN >= 32 ? CIN / 32 : 1;
   const int nq = d->TH * (d->TW / tpc) * kch;
-  const int lds = patch + (STREAM ? 2 * 2 : nq) * FN * 16 * 64;
+  const int cps = (STREAM && CIN == 64 && FN == 4) ? TCONV_CPS64 : 2;
+  const int lds = patch + (STREAM ? 2 * cps : nq) * FN * 16 * 64;
   p.nsteps = patch;                 // tconv reuses this field: byte offset of the weight tiles
   static int attr = 0;
   auto kern = tconv_kernel<CIN, FN, STREAM>;
