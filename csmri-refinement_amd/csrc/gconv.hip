@@ -281,10 +281,12 @@ extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   long long tiles = (long long)cdiv(desc_M(d), c.BM) * cdiv(d->Cout, c.BN) * nclass;
   int bke = (d->dtype == CSMRI_BF16 ? 32 : 16) * c.KC;
   int nsteps = cdiv((long long)d->TH * d->TW * d->Cin, bke);
-  // measured (tools/bench_conv.py, main + reduce): ~256-tile problems want 3 slices (768 workgroups),
-  // smaller ones are better at ~512 workgroups (less slab traffic for the same latency hiding)
+  // measured (tools/bench_conv.py, main + reduce; bench.py): from ~224 tiles on the two-buffer kernel without
+  // split-K beats 2-3 slices + reduce (36 vs 44 us on a 256-tile layer, +2 % on the step); ~192-tile problems want
+  // 3 slices (768 workgroups), smaller ones ~512 workgroups (less slab traffic for the same latency hiding)
   static const char* tgt_env = getenv("CSMRI_GCONV_BLOCKS");       // tuning knob: target workgroups
-  if (tiles >= 384) return 1;
+  static const char* nos_env = getenv("CSMRI_GCONV_NOSPLIT_TILES");   // A/B knob
+  if (tiles >= (nos_env ? atoi(nos_env) : 224)) return 1;
   const int target = tgt_env ? atoi(tgt_env) : (tiles >= 192 ? 768 : 512);
   int sk = (int)((target + tiles - 1) / tiles);
   int maxsk = nsteps / 8; if (maxsk < 1) maxsk = 1;

@@ -341,11 +341,15 @@ static int launch_glds(const GParams& p, hipStream_t st) {
 }
 
 // LDS stages by grid size: one buffer when >= 3 workgroups per CU overlap each other, two when at
-// most two are resident, a 4-deep ring when the grid is at most one workgroup per CU
+// most two are resident, a 4-deep ring for grids of at most half a workgroup per CU (re-measured after
+// the two-buffer loop was tuned: it now beats the ring on 129..256-workgroup grids, e.g. 36 vs 41 us on
+// the U-Net 128 -> 128 4x4 layer)
 static int glds_stages(long long blocks) {
   static const char* env = getenv("CSMRI_GLDS_STAGES");     // A/B knob
   if (env) return atoi(env);
-  return blocks <= 256 ? 4 : (blocks <= 512 ? 2 : 1);
+  static const char* ring = getenv("CSMRI_GLDS_RING_MAX");   // A/B knob: grids up to this size use the 4-deep ring
+  const long long ring_max = ring ? atoll(ring) : 128;
+  return blocks <= ring_max ? 4 : (blocks <= 512 ? 2 : 1);
 }
 
 int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
@@ -358,7 +362,7 @@ int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t 
   const long long x_elems = (long long)d->B * d->Hin * d->Win * d->Cin;
   static const char* ord = getenv("CSMRI_GLDS_ORDER");          // A/B knob: 0 = mt-major, 1 = nt-major
   p.nt_major = ord ? atoi(ord) : (w_elems > x_elems);
-  const int nst = glds_stages((long long)p.mtiles * p.ntiles * p.nclass * p.splitk);
+  const int nst = glds_stages((long long)p.mtiles * p.ntiles * p.nclass * p.splitk);   // (kernel_name mirrors this)
   if (bn == 128) return nst == 4 ? launch_glds<128, 4>(p, st) : nst == 2 ? launch_glds<128, 2>(p, st) : launch_glds<128, 1>(p, st);
   return nst == 4 ? launch_glds<64, 4>(p, st) : nst == 2 ? launch_glds<64, 2>(p, st) : launch_glds<64, 1>(p, st);
 }

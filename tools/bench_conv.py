@@ -30,6 +30,8 @@ CASES = {
     'vgg3_1b16': (128, 256, 3, 1, 'zero', False, 64, 64, 16),
     'vgg2_2b16': (128, 128, 3, 1, 'zero', False, 128, 128, 16),
     'vgg2_1b16': (64, 128, 3, 1, 'zero', False, 128, 128, 16),
+    'u128': (128, 128, 4, 1, 'reflection', False, 64, 64, 8),
+    'disc2b8': (64, 128, 4, 2, 'reflection', False, 64, 64, 8),
     'rec_first': (2, 32, 3, 1, 'zero', False, 256, 256, 8),
     'rec_last': (32, 2, 3, 1, 'zero', False, 256, 256, 8),
 }
