@@ -349,7 +349,9 @@ static int glds_stages(long long blocks) {
   if (env) return atoi(env);
   static const char* ring = getenv("CSMRI_GLDS_RING_MAX");   // A/B knob: grids up to this size use the 4-deep ring
   const long long ring_max = ring ? atoll(ring) : 128;
-  return blocks <= ring_max ? 4 : (blocks <= 512 ? 2 : 1);
+  static const char* two = getenv("CSMRI_GLDS_TWO_MAX");     // A/B knob: grids up to this size use two buffers
+  const long long two_max = two ? atoll(two) : 512;
+  return blocks <= ring_max ? 4 : (blocks <= two_max ? 2 : 1);
 }
 
 int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
