@@ -1040,10 +1040,14 @@ def sigmoid_prob(logits):
 
 def psnr_mse(pred, target):
   """per-image MSE of clamp(|.|,0,1); pred/target interleaved complex [B,H,W,2]."""
+  _need_gpu(pred)
   b, h, w, _ = pred.shape
+  # converted copies are bound to locals so they outlive the launch (a temporary freed before the
+  # kernel runs could be handed to the next allocation)
+  p, t = pred.contiguous().float(), target.contiguous().float()
+  assert p.shape == t.shape and p.shape[-1] == 2
   buf = torch.empty(b * 33, dtype=torch.float32, device=pred.device)   # results + 32 partials/image
-  lib.call('csmri_psnr_mse', pred.contiguous().data_ptr(), target.contiguous().data_ptr(), b, h * w,
-           buf.data_ptr(), stream())
+  lib.call('csmri_psnr_mse', p.data_ptr(), t.data_ptr(), b, h * w, buf.data_ptr(), stream())
   return buf[:b]
 
 
@@ -1054,8 +1058,9 @@ def ssim(pred, target):
   b, h, w, _ = pred.shape
   out = torch.empty(b, dtype=torch.float32, device=pred.device)
   work = torch.empty(lib.raw('csmri_ssim_work_bytes')(b, h, w) // 8, dtype=torch.float64, device=pred.device)
-  lib.call('csmri_ssim', pred.contiguous().float().data_ptr(), target.contiguous().float().data_ptr(), b, h, w,
-           out.data_ptr(), work.data_ptr(), stream())
+  p, t = pred.contiguous().float(), target.contiguous().float()
+  assert p.shape == t.shape and p.shape[-1] == 2
+  lib.call('csmri_ssim', p.data_ptr(), t.data_ptr(), b, h, w, out.data_ptr(), work.data_ptr(), stream())
   return out
 
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/csmri_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -18,6 +19,21 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 #define CSMRI_CHECK_ARG(cond) do { if (!(cond)) return CSMRI_E_ARG; } while (0)
 #define CSMRI_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// Raise a kernel's dynamic-LDS limit to `bytes_` once per call site and size.  The cache is an atomic that only grows
+// (hipFuncSetAttribute is idempotent, so two host threads racing here at worst both make the call): entry points stay
+// re-entrant across host threads and no launch pays the attribute call twice.
+#define CSMRI_SET_MAX_LDS(kern_, bytes_) \
+  do { \
+    static std::atomic<int> lds_set_{0}; \
+    const int want_ = (int)(bytes_); \
+    if (want_ > 48 * 1024 && lds_set_.load(std::memory_order_acquire) < want_) { \
+      hipError_t e_ = hipFuncSetAttribute((const void*)(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, want_); \
+      if (e_ != hipSuccess) return (int)e_; \
+      int cur_ = lds_set_.load(std::memory_order_relaxed); \
+      while (cur_ < want_ && !lds_set_.compare_exchange_weak(cur_, want_, std::memory_order_release)) {} \
+    } \
+  } while (0)
 
 template <int DT> struct DTraits;
 template <> struct DTraits<CSMRI_F32> {

@@ -184,17 +184,8 @@ extern "C" int csmri_dc(const float* x, int x_pix_stride, const float* k0, const
   const float scale = 1.0f / sqrtf((float)H * (float)W);
   const int lds_rows = (2 * W * DC_TP + W) * (int)sizeof(float2);
   const int lds_cols = (2 * H * DC_TP + H) * (int)sizeof(float2);
-  static int attr_rows = 0, attr_cols = 0;
-  if (lds_rows > attr_rows) {
-    hipError_t e = hipFuncSetAttribute((const void*)dc_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rows);
-    if (e != hipSuccess) return (int)e;
-    attr_rows = lds_rows;
-  }
-  if (lds_cols > attr_cols) {
-    hipError_t e = hipFuncSetAttribute((const void*)dc_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cols);
-    if (e != hipSuccess) return (int)e;
-    attr_cols = lds_cols;
-  }
+  CSMRI_SET_MAX_LDS(dc_rows_kernel, lds_rows);
+  CSMRI_SET_MAX_LDS(dc_cols_kernel, lds_cols);
   const int row_blocks = B * H / DC_T, col_blocks = B * (W / DC_T);
   hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
                      x, x_pix_stride, (float2*)out, (void*)nullptr, 0, W, -1, 1.0f);
@@ -222,10 +213,8 @@ extern "C" int csmri_undersample(const float* img, const uint8_t* mask, float* k
   const float scale = 1.0f / sqrtf((float)H * (float)W);
   const int lds_rows = (2 * W * DC_TP + W) * (int)sizeof(float2);
   const int lds_cols = (2 * H * DC_TP + H) * (int)sizeof(float2);
-  hipError_t e = hipFuncSetAttribute((const void*)dc_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rows);
-  if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute((const void*)dc_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cols);
-  if (e != hipSuccess) return (int)e;
+  CSMRI_SET_MAX_LDS(dc_rows_kernel, lds_rows);
+  CSMRI_SET_MAX_LDS(dc_cols_kernel, lds_cols);
   const int row_blocks = B * H / DC_T, col_blocks = B * (W / DC_T);
   hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
                      img, 2, (float2*)inp, (void*)nullptr, 0, W, -1, 1.0f);

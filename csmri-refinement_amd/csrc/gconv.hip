@@ -298,13 +298,8 @@ extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
 template <int DT, int BM, int BN, int WM, int WN, int KC>
 static int launch_gconv(const GParams& p, hipStream_t st) {
   constexpr int lds = 2 * KC * (BM + BN) * 64;
-  static bool attr_set = false;
   auto kern = gconv_kernel<DT, BM, BN, WM, WN, KC>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  CSMRI_SET_MAX_LDS(kern, lds);
   dim3 grid(p.mtiles * p.ntiles, 1, p.nclass * p.splitk);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   CSMRI_LAUNCH_CHECK();

@@ -328,13 +328,8 @@ template <int BN, int NST>
 static int launch_glds(const GParams& p, hipStream_t st) {
   constexpr int lds = (128 + BN) * 128 * NST;
   dim3 grid(p.mtiles * p.ntiles, 1, p.nclass * p.splitk);
-  static bool attr_set = false;
   auto kern = gconv_glds_kernel<BN, NST>;
-  if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  CSMRI_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;

@@ -263,14 +263,8 @@ int gconv_glds256_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream
   const long long w_elems = (long long)d->Cout * d->TH * d->TW * d->Cin * p.nclass;
   const long long x_elems = (long long)d->B * d->Hin * d->Win * d->Cin;
   p.nt_major = w_elems > x_elems;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gconv_glds256_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)gconv_glds256_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  CSMRI_SET_MAX_LDS(gconv_glds256_kernel<256>, 2 * (256 + 256) * 128);
+  CSMRI_SET_MAX_LDS(gconv_glds256_kernel<128>, 2 * (256 + 128) * 128);
   dim3 grid(p.mtiles * p.ntiles, 1, p.nclass * p.splitk);
   if (bn == 256) hipLaunchKernelGGL(gconv_glds256_kernel<256>, grid, dim3(512), 2 * (256 + 256) * 128, st, p);
   else hipLaunchKernelGGL(gconv_glds256_kernel<128>, grid, dim3(512), 2 * (256 + 128) * 128, st, p);

@@ -227,12 +227,7 @@ int pconv_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
   const int patch = 8 * ((npix_ + 63) / 64) * 1024;
   const int lds = patch + 4 * 128 * 64;
   p.nsteps = patch;                 // byte offset of the weight stage buffers (as in tconv)
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pconv_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 6 * 1024 + 4 * 128 * 64);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  CSMRI_SET_MAX_LDS(pconv_kernel<8>, 8 * 6 * 1024 + 4 * 128 * 64);
   const int tiles = d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16);
   dim3 grid(tiles, d->Cout / 128, 1);
   hipLaunchKernelGGL(pconv_kernel<8>, grid, dim3(256), lds, st, p);

@@ -236,13 +236,8 @@ static int launch_tconv(const GParams& p0, const csmri_gconv_desc* d, hipStream_
   const int cps = (STREAM && CIN == 64 && FN == 4) ? TCONV_CPS64 : 2;
   const int lds = patch + (STREAM ? 2 * cps : nq) * FN * 16 * 64;
   p.nsteps = patch;                 // tconv reuses this field: byte offset of the weight tiles
-  static int attr = 0;
   auto kern = tconv_kernel<CIN, FN, STREAM>;
-  if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr = lds;
-  }
+  CSMRI_SET_MAX_LDS(kern, lds);
   const int tiles = d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16);
   dim3 grid(tiles, (d->Cout + FN * 16 - 1) / (FN * 16), 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);

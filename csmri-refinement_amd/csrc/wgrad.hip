@@ -764,13 +764,8 @@ template <int DT, int BP, int BQ, int WP, int WQ>
 static int launch_wgrad(const WParams& p, hipStream_t st) {
   constexpr int KC = DT == CSMRI_BF16 ? 2 : 1;
   constexpr int lds = 2 * KC * (BP + BQ) * 64;
-  static bool attr_set = false;
   auto kern = wgrad_kernel<DT, BP, BQ, WP, WQ>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  CSMRI_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(p.ptiles * p.qtiles, 1, p.splitk), dim3(256), lds, st, p);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
@@ -779,13 +774,8 @@ static int launch_wgrad(const WParams& p, hipStream_t st) {
 template <int BP, int BQ, int WP, int WQ>
 static int launch_wgrad_tr(const WParams& p, hipStream_t st) {
   constexpr int lds = 2 * 64 * (BP + BQ) * 2;
-  static bool attr_set = false;
   auto kern = wgrad_tr_kernel<BP, BQ, WP, WQ>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  CSMRI_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(p.ptiles * p.qtiles, 1, p.splitk), dim3(256), lds, st, p);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
@@ -800,18 +790,10 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
   if (row_aligned) {
     const dim3 grid(p.ptiles * p.qtiles, 1, p.splitk);
     const bool refl = p.border == CSMRI_BORDER_REFLECT;
-    if (lds > 48 * 1024) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        hipError_t e = hipSuccess;
-        e = hipFuncSetAttribute((const void*)wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-      }
-    }
+    CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, true>), lds);
+    CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, false>), lds);
+    CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, true>), lds);
+    CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, false>), lds);
     if (refl && p.ups) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, true>), grid, dim3(256), lds, st, p);
     else if (refl) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, false>), grid, dim3(256), lds, st, p);
     else if (p.ups) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, true>), grid, dim3(256), lds, st, p);

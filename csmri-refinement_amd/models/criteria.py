@@ -53,7 +53,8 @@ def _get_vgg_criterion(conf, loss_name, cuda, target_key):
   from models.vgg_loss import VGGLoss
   vconf = conf.vgg_loss if conf.has_attr('vgg_loss') else {}
   vgg_loss = VGGLoss(loss_name, cuda, vconf.get('blocks', -1), vconf.get('criterion', 'MSE'),
-                     vconf.get('weights'), seed=vconf.get('seed', 0))
+                     vconf.get('weights'), seed=vconf.get('seed', 0),
+                     weights_path=vconf.get('weights_path'), allow_random=vconf.get('allow_random'))
   return CriterionWrapper(vgg_loss, target_key)
 
 

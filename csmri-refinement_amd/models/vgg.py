@@ -63,6 +63,30 @@ class VGG19(nn.Module):
     self.register_buffer('mean', torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
     self.register_buffer('std', torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
 
+  def load_pretrained(self, path):
+    """Load a torchvision vgg19 state_dict (``features.{i}.weight/bias``; a checkpoint of this
+    module, ``blocks.{b}.{i}.*``, is accepted too) into the blocks.  Every conv of the requested
+    blocks must be present; classifier entries are ignored."""
+    sd = torch.load(path, map_location='cpu')
+    if isinstance(sd, dict) and 'state_dict' in sd:
+      sd = sd['state_dict']
+    own = {}
+    for b, block in enumerate(self.blocks):
+      for idx, conv in block.items():
+        for leaf in ('weight', 'bias'):
+          src = sd.get('features.%s.%s' % (idx, leaf), sd.get('blocks.%d.%s.%s' % (b, idx, leaf)))
+          if src is None:
+            raise KeyError('VGG19 weights file %s lacks features.%s.%s' % (path, idx, leaf))
+          dst = getattr(conv, leaf)
+          if tuple(src.shape) != tuple(dst.shape):
+            raise ValueError('features.%s.%s: shape %s, expected %s' % (idx, leaf, tuple(src.shape), tuple(dst.shape)))
+          own[(b, idx, leaf)] = src
+    with torch.no_grad():
+      for (b, idx, leaf), src in own.items():
+        getattr(self.blocks[b][idx], leaf).copy_(src.to(torch.float32))
+    from models.utils import refresh_packs
+    refresh_packs(self)
+
   def forward_nhwc(self, x):
     """x: NHWC [B,H,W,8], already normalised (ComplexAbs mode 3).  Returns the list of
     NHWC feature maps of the requested blocks."""

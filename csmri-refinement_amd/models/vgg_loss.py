@@ -14,7 +14,8 @@ _KIND = {'L1': 0, 'MSE': 1}
 
 
 class VGGLoss(nn.Module):
-  def __init__(self, loss_name, cuda, blocks=-1, criterion='L1', weights=None, seed=0):
+  def __init__(self, loss_name, cuda, blocks=-1, criterion='L1', weights=None, seed=0,
+               weights_path=None, allow_random=None):
     super(VGGLoss, self).__init__()
     if loss_name != 'VGG19':
       raise ValueError('Unknown VGG loss {}'.format(loss_name))
@@ -24,6 +25,20 @@ class VGGLoss(nn.Module):
     elif not isinstance(blocks, list):
       blocks = [blocks]
     self.vgg = VGG19(blocks, requires_grad=False, seed=seed)
+    # The reference uses torchvision's ImageNet weights (models/vgg.py:35, vgg19(pretrained=True)),
+    # which need a download.  ``vgg_loss.weights_path``: a torchvision-format state_dict file
+    # (keys features.{i}.weight/bias, or this module's own blocks.{b}.{i}.*).  Without it the
+    # extractor keeps seeded kaiming weights -- a different perceptual loss than the reference's,
+    # hence the warning (or an error when the config says vgg_loss.allow_random = false).
+    if weights_path:
+      self.vgg.load_pretrained(weights_path)
+    elif allow_random is False:
+      raise RuntimeError('vgg_loss.weights_path is not set and vgg_loss.allow_random is false')
+    else:
+      import warnings
+      warnings.warn('VGG19 perceptual loss runs on seeded random weights (seed %d): set '
+                    'vgg_loss.weights_path to a torchvision vgg19 state_dict to reproduce the '
+                    "reference's ImageNet-pretrained loss" % seed, stacklevel=2)
     self.kind = _KIND[criterion]
     self.weights = list(weights) if weights is not None else [1.] * len(blocks)
     assert len(self.weights) == len(blocks)

@@ -443,8 +443,14 @@ class AdversarialRunner(BaseRunner):
     bns = [m for net in (self.gen, self.disc) for m in net.modules() if hasattr(m, 'batches_tracked')]
     before = [m.batches_tracked for m in bns]
     if pool is not None:
+      # the capture pass executes nothing: its plan must not mark slots as filled nor consume
+      # python-random draws (the first replay plans again from this very state)
+      import random as _random
+      pool_count, rnd_state = pool.count, _random.getstate()
       pool.prepare(torch.empty((static['inp'].shape[0],) + tuple(pool.buffer.shape[1:]),
                                dtype=pool.buffer.dtype, device=self.device))
+      pool.count = pool_count
+      _random.setstate(rnd_state)
       pool.external_plan = True
     st = {'batch': static, 'batch_next': static_next, 'pre_cur': static_pre}
     graphs = []

@@ -18,7 +18,6 @@ class ImagePool(object):
     self.count = 0
     self.buffer = None            # [pool_size + 1, ...]; last slot is a write-only dummy
     self._idx = None              # device int64 [4, n]: kind, pool_idx, x_idx / wslot, wsrc
-    self._host = None
     self.external_plan = False    # True while a captured graph owns the device part
 
   # -- host side ---------------------------------------------------------------
@@ -62,13 +61,17 @@ class ImagePool(object):
       self.buffer = torch.zeros((self.pool_size + 1,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     if self._idx is None or self._idx.shape[1] != n:
       self._idx = torch.zeros(5, n, dtype=torch.int64, device=x.device)
-      self._host = torch.zeros(5, n, dtype=torch.int64).pin_memory() if x.is_cuda else torch.zeros(5, n, dtype=torch.int64)
     if decisions is None:
       decisions = self.decide(n)
     rows = self.plan(decisions)
-    for r, vals in enumerate(rows):
-      self._host[r] = torch.tensor(vals, dtype=torch.int64)
-    self._idx.copy_(self._host, non_blocking=True)
+    # A FRESH pinned staging tensor per step: the host runs many steps ahead of the GPU (graph replay,
+    # no per-step read-back), so a persistent staging buffer would be rewritten by step t+k before the
+    # asynchronous H2D copy of step t has executed.  The caching host allocator keeps a block busy
+    # until the copy that reads it has completed (it records an event on the copying stream).
+    host = torch.tensor(rows, dtype=torch.int64)
+    if x.is_cuda:
+      host = host.pin_memory()
+    self._idx.copy_(host, non_blocking=True)
 
   # -- device side (fixed shape) -------------------------------------------------
   def apply_plan(self, x):

@@ -193,7 +193,8 @@ int csmri_fold_pad_grad(int dtype, const void* gpad, void* out, int out_pix_stri
  * channels 0,1 of a channel-padded conv output directly); k0, out: dense
  * interleaved complex fp32 [B][H][W][2]; mask: uint8 [B][H][W]
  * (1 = sampled).  k0 == NULL gives the adjoint (backward w.r.t. x,
- * myfft.py:92-102,119-128).  H, W in {32,64,128,256,512}.  work: 2*B*H*W*8 bytes.
+ * myfft.py:92-102,119-128).  H, W in {32,64,128,256,512}.  work: csmri_dc_work_bytes(B,H,W) bytes
+ * (currently 0: the passes run in place on `out`; NULL is accepted then).
  * out_pad (optional): also write the result as a channel-padded NHWC tensor
  * [B][H][W][8] of dtype out_pad_dtype (channels 0,1 = re,im; 2..7 = 0) -- the
  * input layout of the next conv block.
