@@ -92,6 +92,7 @@ _SIGS = {
     'csmri_wgrad': (i32, [C.POINTER(WGradDesc), vp]),
     'csmri_wgrad_slab_bytes': (sz, [C.POINTER(WGradDesc)]),
     'csmri_wgrad_suggest_splitk': (i32, [C.POINTER(WGradDesc)]),
+    'csmri_wgrad_kernel_name': (i32, [C.POINTER(WGradDesc), C.c_char_p, i32]),
     'csmri_fold_pad_grad': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                   i32, vp, i32, f32, vp]),
     'csmri_fold_halo': (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, f32, vp]),

@@ -267,6 +267,7 @@ class PackGroup(object):
 FOLD_WINDOW = True      # reflection dgrads: centre written in place + border-only halo fold
 PROFILE_SHAPES = False  # tools: append the problem shape to gconv labels
 PROFILE = None        # bench.py sets this to a list to collect per-launch HIP event timings
+LAUNCH_LOG = None     # tests set this to a list: (kind, kernel instance name, splitk) per conv-library launch
 
 
 def _tile_label(kind, dt, cout_p):
@@ -311,6 +312,10 @@ def _gconv_run(d, want_stats, flops=0.0):
     rows = lib.raw('csmri_gconv_stats_rows')(C.byref(d))
     stats = torch.empty(rows, 2, d.Cout, dtype=torch.float32, device=dev)
     d.stats_partial = stats.data_ptr()
+  if LAUNCH_LOG is not None:
+    nm = C.create_string_buffer(96)
+    lib.call('csmri_gconv_kernel_name', C.byref(d), nm, 96)
+    LAUNCH_LOG.append(('gconv', nm.value.decode(), splitk))
   if PROFILE is None:
     lib.call('csmri_gconv', C.byref(d), stream())
     return stats
@@ -480,6 +485,11 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
   d.accumulate = int(accumulate)
   d.splitk = lib.raw('csmri_wgrad_suggest_splitk')(C.byref(d))
   nbytes = lib.raw('csmri_wgrad_slab_bytes')(C.byref(d))
+
+  if LAUNCH_LOG is not None:
+    nm = C.create_string_buffer(96)
+    lib.call('csmri_wgrad_kernel_name', C.byref(d), nm, 96)
+    LAUNCH_LOG.append(('wgrad', nm.value.decode(), d.splitk))
 
   def launch():
     slab = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)

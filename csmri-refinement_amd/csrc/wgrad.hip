@@ -805,6 +805,23 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
   return CSMRI_OK;
 }
 
+// template instance csmri_wgrad dispatches to for this problem, spelled as rocprofv3 prints it
+extern "C" int csmri_wgrad_kernel_name(const csmri_wgrad_desc* d, char* buf, int n) {
+  CSMRI_CHECK_ARG(d && buf && n > 0);
+  WConfig c = pick_wconfig(d);
+  const int wp = c.BQ >= 128 || (c.BQ == 64 && c.BP == 128) ? 2 : 4, wq = wp == 2 ? 2 : 1;
+  static const char* use_tr = getenv("CSMRI_WGRAD_TR");
+  if (d->dtype != CSMRI_BF16) { snprintf(buf, n, "wgrad_kernel<%d, %d, %d, %d, %d>", d->dtype, c.BP, c.BQ, wp, wq); return CSMRI_OK; }
+  if (use_tr) { snprintf(buf, n, "wgrad_tr_kernel<%d, %d, %d, %d>", c.BP, c.BQ, wp, wq); return CSMRI_OK; }
+  const bool row = wgrad_row_aligned(d) && (long long)d->B * d->Hin * d->Win < (1 << 24) &&
+                   d->in0_pix_stride < (1 << 22) && d->in1_pix_stride < (1 << 22) &&
+                   (long long)d->B * d->Hin * d->Win * (d->in0_pix_stride > d->in1_pix_stride ? d->in0_pix_stride : d->in1_pix_stride) * 2 < (1ll << 32);
+  if (row) snprintf(buf, n, "wgrad_glds_row_kernel<%d, %d, %d, %d, %s, %s>", c.BP, c.BQ, wp, wq,
+                    d->border == CSMRI_BORDER_REFLECT ? "true" : "false", d->upsample ? "true" : "false");
+  else snprintf(buf, n, "wgrad_glds_kernel<%d, %d, %d, %d>", c.BP, c.BQ, wp, wq);
+  return CSMRI_OK;
+}
+
 extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   CSMRI_CHECK_ARG(d && d->in0 && d->dy && d->dw && d->slab);
   CSMRI_CHECK_ARG(d->dtype == CSMRI_F32 || d->dtype == CSMRI_BF16);

@@ -166,6 +166,8 @@ typedef struct csmri_wgrad_desc {
 int csmri_wgrad(const csmri_wgrad_desc* d, void* stream);
 size_t csmri_wgrad_slab_bytes(const csmri_wgrad_desc* d);
 int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d);
+/* name of the kernel instance csmri_wgrad launches for d, as profilers print it (for reports/tests) */
+int csmri_wgrad_kernel_name(const csmri_wgrad_desc* d, char* buf, int n);
 
 /* Fold the gradient w.r.t. a reflect-padded (and optionally x2-upsampled)
  * tensor back onto the un-padded tensor (backward of nn.ReflectionPad2d +

@@ -589,3 +589,201 @@ def _next_or_none(r):
   except StopIteration:
     r.data_iter = None
     return None
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: parity at the benchmarked configuration ("Next round" item 1)
+# ---------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_f6_vgg_loss_and_input_gradient_vs_reference_golden(env, dtype):
+  """F6 (written by the reference's own VGGLoss, models/vgg_loss.py:43-65, criterion MSE through
+  models/criteria.py:15-28): the loss and dL/dpred of the perceptual loss -- |pred| -> 3 channels ->
+  ImageNet normalisation -> VGG19 relu5_4 -> MSE.  fp32 compute: loss 1e-4 relative, gradient
+  relative L2 1e-4; bf16 compute (16 stacked bf16 convolutions): loss 2 %, gradient relative L2 3e-2
+  and cosine >= 0.9995."""
+  Configuration, set_dtype = env
+  from models.vgg_loss import VGGLoss
+  f = load('F6_vgg')
+  set_dtype(dtype)
+  import warnings
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    crit = VGGLoss('VGG19', '0', -1, 'MSE', None, seed=int(f['vgg_seed'])).cuda()
+  pred = T(f['pred']).cuda().requires_grad_(True)
+  loss = crit(pred, T(f['target']).cuda())
+  loss.backward()
+  torch.cuda.synchronize()
+  ref_l, ref_g = float(f['loss']), T(f['grad_pred'])
+  got_g = pred.grad.cpu()
+  err = float((got_g - ref_g).norm() / ref_g.norm())
+  cos = float((got_g * ref_g).sum() / (got_g.norm() * ref_g.norm()))
+  print('F6 %s loss hip %.8e ref %.8e rel %.3e   grad rel_l2 %.3e cos %.6f' %
+        (dtype, loss.item(), ref_l, abs(loss.item() - ref_l) / abs(ref_l), err, cos))
+  if dtype == 'fp32':
+    assert abs(loss.item() - ref_l) < 1e-4 * abs(ref_l)
+    assert err < 1e-4
+  else:
+    assert abs(loss.item() - ref_l) < 2e-2 * abs(ref_l)
+    assert err < 3e-2 and cos > 0.9995
+
+
+def test_f4_refinement_wrapper_fwd_bwd_fp32_vs_reference_golden(env):
+  """F4 (the reference's RefinementWrapper, models/refinement_wrapper.py:169-220, reduced-width U-Net,
+  128^2, scale = 0.37): the four outputs, the gradients of every U-Net tensor and of `scale` for
+  fixed upstream gradients on pred and prescaled_refinement, and the BatchNorm running statistics
+  after the forward."""
+  Configuration, set_dtype = env
+  from models import construct_model
+  from csmri_hip import ops
+  f = load('F4_refinement')
+  set_dtype('fp32')
+  conf = gan_conf(Configuration, 'fp32')
+  gconf = Configuration.from_dict(dict(conf.generator_model), conf)
+  gen = construct_model(gconf, 'RefinementWrapper').cuda()
+  gen.load_state_dict(sub(f, 'P.'))
+  ops.bump_weight_epoch()
+  gen.train()
+  batch = {k: v.cuda() for k, v in O.synth_batch(2, 128, 128, acc=4, seed=11).items()}
+  out = gen(batch['inp'], batch['kspace'], batch['mask'])
+  for k in ('pred', 'pretrained', 'prescaled_refinement', 'scaled_refinement'):
+    ref = T(f['out.' + k])
+    got = out[k].detach().float().cpu().reshape(ref.shape)
+    e = float((got - ref).abs().max())
+    print('F4 %-22s max_abs %.3e (ref max %.3e)' % (k, e, float(ref.abs().max())))
+    assert torch.allclose(got, ref, atol=2e-5 * max(1.0, float(ref.abs().max())), rtol=1e-4), k
+  ((out['pred'] * T(f['gp']).cuda()).sum() + (out['prescaled_refinement'] * T(f['gu']).cuda()).sum()).backward()
+  torch.cuda.synchronize()
+  named = dict(gen.named_parameters())
+  worst = 0.0
+  for k, g in sub(f, 'grad.').items():
+    got = named[k].grad.cpu().reshape(g.shape)
+    err = float((got - g).norm() / (g.norm() + 1e-30))
+    worst = max(worst, err)
+    assert err < 2e-4, (k, err)
+  print('F4 worst gradient rel_l2 %.3e' % worst)
+  sd = gen.state_dict()
+  for k, v in sub(f, 'S1.').items():
+    assert torch.allclose(sd[k].cpu(), v, atol=1e-5, rtol=1e-4), k
+
+
+def _full_width_runner(Configuration, set_dtype, dtype, batch_size=8, scale=0.25):
+  """The bench.py workload: configs/2-refinement.json unchanged (RecNet 3/3/32, U-Net [32,64,128],
+  D [64..1024], VGG19), with `scale` preset so that the U-Net output reaches pred (SURVEY A-10)."""
+  from training import build_runner
+  import utils
+  set_dtype(dtype)
+  conf = Configuration.from_json(os.path.join(PKG, 'configs', '2-refinement.json'))
+  conf.batch_size = batch_size
+  conf.vgg_loss = {'seed': 19}
+  for m in (conf.generator_model['pretrained_model'], conf.generator_model['learnable_model'],
+            conf.discriminator_model):
+    m['compute_dtype'] = dtype
+  utils.set_random_seeds(conf.seed)
+  runner = build_runner(conf, 'adversarial', '0', 'train')
+  with torch.no_grad():
+    runner.gen.scale.fill_(scale)
+  return runner, conf
+
+
+def _split_sd(sd):
+  P = {k: v.detach().cpu().clone() for k, v in sd.items() if 'running' not in k and 'num_batches' not in k}
+  S = {k: v.detach().cpu().clone() for k, v in sd.items() if 'running' in k}
+  return P, S
+
+
+def test_full_width_256_b8_bf16_step_vs_fp32_oracle(env):
+  """The benchmarked configuration itself -- full width, 256x256, 8 slices, bf16 compute -- one
+  AdversarialRunner step (reference training/adversarial_runner.py:322-389) against the fp32 CPU
+  oracle with the same weights, injected Dropout2d masks and (filling) image pool, scale = 0.25:
+  every loss within 2 % (gen_loss_VGG19 included), PSNR within 0.01 dB, and per-tensor gradient
+  direction of both networks (cosine; bound stated per class below)."""
+  Configuration, set_dtype = env
+  runner, conf = _full_width_runner(Configuration, set_dtype, 'bf16')
+  B = 8
+  batch = O.synth_batch(B, 256, 256, acc=4, seed=123)
+  g = torch.Generator().manual_seed(9)
+  chans = [f for _, bn, drop, f in runner.disc._layers if bn is not None and drop]
+  masks = [(torch.rand(B, c, 1, 1, generator=g) < 0.5).float() * 2.0 for _ in range(3) for c in chans]
+  PG, SG = _split_sd(runner.gen.state_dict())
+  PD, SD = _split_sd(runner.disc.state_dict())
+  PV = {k: v.detach().cpu().clone() for k, v in
+        runner.gen_criteria['VGG19'].criterion.vgg.state_dict().items() if k.startswith('blocks')}
+  grads = {}
+
+  def snap(opt, model, tag):
+    orig, names = opt.apply, {id(p): n for n, p in model.named_parameters()}
+
+    def apply():
+      grads[tag] = {names[id(p)]: p.grad.detach().float().cpu().clone() for p in opt.params}
+      orig()
+    opt.apply = apply
+  snap(runner.gen_optimizer, runner.gen, 'G')
+  snap(runner.disc_optimizer, runner.disc, 'D')
+  runner.disc.injected_dropout = [m.clone() for m in masks]
+  losses, metrics = runner.train_epoch(Loader([batch]), 1)
+  torch.cuda.synchronize()
+  got = {k: v.value for k, v in losses.items()}
+
+  PG = {k: (v.requires_grad_(True) if not k.startswith('pretrained_model') else v) for k, v in PG.items()}
+  PD = {k: v.requires_grad_(True) for k, v in PD.items()}
+  gopt = O.make_adam([v for v in PG.values() if v.requires_grad], 2e-4, 0.5, 0.999)
+  dopt = O.make_adam(PD.values(), 2e-4, 0.5, 0.999)
+  ref_g = {}
+  for opt, P, tag in ((gopt, PG, 'G'), (dopt, PD, 'D')):
+    orig = opt.step
+
+    def step(orig=orig, P=P, tag=tag):
+      ref_g[tag] = {k: v.grad.detach().clone() for k, v in P.items() if v.requires_grad and v.grad is not None}
+      orig()
+    opt.step = step
+  dm = [masks[0:3], masks[3:6], masks[6:9]]
+  ref, ref_m, _ = O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=O.ImagePool(80), dropout_masks=dm)
+  for k in sorted(ref):
+    rel = abs(got[k] - ref[k]) / max(1e-12, abs(ref[k]))
+    print('full-width bf16 %-26s hip %.6e oracle %.6e rel %.3e' % (k, got[k], ref[k], rel))
+  dpsnr = abs(metrics['gen_psnr'].value - ref_m['gen_psnr'])
+  print('full-width bf16 gen_psnr hip %.5f oracle %.5f delta %.5f dB' %
+        (metrics['gen_psnr'].value, ref_m['gen_psnr'], dpsnr))
+  worst = {}
+  for tag in ('G', 'D'):
+    for k, gr in ref_g[tag].items():
+      gh = grads[tag][k].reshape(gr.shape)
+      cos = float((gh * gr).sum() / (gh.norm() * gr.norm() + 1e-30))
+      err = float((gh - gr).norm() / (gr.norm() + 1e-30))
+      cls = 'bias/bn' if gr.dim() <= 1 else 'weight'
+      w = worst.setdefault((tag, cls), [1.0, 0.0, ''])
+      if cos < w[0]:
+        worst[(tag, cls)] = [cos, err, k]
+      print('full-width grad %s %-62s cos %.5f rel_l2 %.3e' % (tag, k, cos, err))
+  print('worst per class:', worst)
+  for k in ref:
+    assert abs(got[k] - ref[k]) <= 2e-2 * abs(ref[k]) + 1e-7, (k, got[k], ref[k])
+  assert dpsnr < 0.01, dpsnr
+  # conv weight tensors (>= 1e3 summed products each): direction within 0.999; per-channel vectors
+  # (BN gamma/beta, biases: sums with heavy cancellation over B*H*W positions): 0.99
+  for (tag, cls), (cos, err, k) in worst.items():
+    assert cos > (0.999 if cls == 'weight' else 0.99), (tag, cls, k, cos, err)
+
+
+def test_bf16_psnr_within_0p01_db_where_the_unet_contributes(env):
+  """The 0.01 dB criterion with the U-Net switched ON: full-width generator, 256^2,
+  8 slices, scale = 0.25 (SURVEY A-10: at scale = 0 pred == pretrained and the U-Net is multiplied
+  by zero), train-mode BatchNorm, bf16 vs the fp32 CPU oracle on the same weights and batch."""
+  Configuration, set_dtype = env
+  runner, conf = _full_width_runner(Configuration, set_dtype, 'bf16')
+  batch = O.synth_batch(8, 256, 256, acc=4, seed=321)
+  PG, SG = _split_sd(runner.gen.state_dict())
+  runner._set_train()
+  with torch.no_grad():
+    out = runner.gen(batch['inp'].cuda(), batch['kspace'].cuda(), batch['mask'].cuda())
+    pred = out['pred'].float().cpu()
+    want = O.refinement_forward(PG, SG, batch['inp'], batch['kspace'], batch['mask'], True)
+  p_hip, p_ref = O.psnr_batch(pred, batch['target']), O.psnr_batch(want['pred'], batch['target'])
+  p_pre = O.psnr_batch(want['pretrained'], batch['target'])
+  rel = float((pred - want['pred']).norm() / want['pred'].norm())
+  print('psnr scale=0.25: hip %.5f oracle %.5f delta %.5f dB (pretrained alone %.5f) rel_l2 %.3e' %
+        (p_hip, p_ref, abs(p_hip - p_ref), p_pre, rel))
+  assert abs(p_ref - p_pre) > 0.05, 'the U-Net must actually move the prediction for this test to mean anything'
+  assert abs(p_hip - p_ref) < 0.01
