@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: train slices/s of the 256x256 GAN-refinement step (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config c3|c2] [--dtype bf16|fp32]
 
 N>1 is launched by the driver as torch.distributed.run with one rank per GPU (RCCL).
-A "step" is one AdversarialRunner._train_single_step on a batch of synthetic
-undersampled k-space resident in HBM: generator forward (frozen 3-block RecNet with 3
-data-consistency layers + U-Net), three discriminator forwards, two VGG19 forwards,
-discriminator backward + Adam, generator backward (through D and VGG) + Adam, gradient
-all-reduce.  Per-GPU batch is fixed at 8 slices (BASELINE C4: 64 over 8 GPUs) -> weak
-scaling.  Rank 0 prints ONE JSON line.
+
+--config c3 (default; BASELINE configs C3/C4): a "step" is one AdversarialRunner._train_single_step on
+  8 slices/GPU of 256x256 synthetic undersampled k-space: generator forward (frozen 3-block RecNet with
+  3 data-consistency layers + U-Net), three discriminator forwards, two VGG19 forwards, discriminator
+  backward + Adam, generator backward (through D and VGG) + Adam, gradient all-reduce.  Weak scaling.
+--config c2 (BASELINE config C2): one Runner._train_step of RecNet(5 blocks, 3 convs, 32 filters) with
+  MSE loss on 64 slices/GPU of 256x256: 5 conv blocks + 5 data-consistency layers forward, their
+  adjoints backward, Adam.
+
+SURVEY 8(d): the batch arrives from PINNED HOST memory; its H2D copy is issued on a copy stream and is
+inside the timed region (the copy of batch t+1 runs under step t).  Rank 0 prints ONE JSON line.
 
 Extra legs (rank 0, outside the timed region):
-  roofline     per-launch HIP-event timing of the conv kernels over instrumented steps
-               of the same workload; the dominant kernel's algorithmic FLOP/s vs the
-               dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s)
-  cpu_baseline the CPU oracle's (plain torch fp32) GAN step on a bounded sample
-               (N=1 only), plus the PSNR of both paths on the same batch/weights.
+  roofline      HIP-event brackets around every conv-library launch over instrumented eager steps of the
+                same workload; the dominant kernel's algorithmic FLOP/s vs the dense MFMA peak of the dtype
+  roofline_hbm  the same brackets around the HBM-bound entry points (data consistency, BatchNorm passes,
+                Adam) with their algorithmic bytes vs 8 TB/s
+  cpu_baseline  the CPU oracle's (plain torch fp32) step on the SAME batch (N=1 only), timed at 32 threads
+                and at os.cpu_count() threads, plus the PSNR of both paths on the same batch/weights.
 """
 import argparse
 import json
@@ -28,117 +34,212 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, 'csmri-refinement_amd')
 sys.path.insert(0, PKG)
 
-PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0                           # HBM3E spec (same table; ~6.3 TB/s achievable)
 GAN_GFLOP_PER_SLICE = 299.2   # algorithmic conv FLOPs of one 256^2 GAN step
-SIZE, PER_GPU_BATCH = 256, 8
-CPU_SAMPLE_SLICES, CPU_SAMPLE_STEPS = 4, 4
+C2_GFLOP_PER_SLICE = 20.31    # RecNet 5/3/32 MSE step at 256^2
+SIZE = 256
+DEFAULT_BATCH = {'c3': 8, 'c2': 64}
+N_HOST_BATCHES = 8
 
 
 def parse():
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
-  p.add_argument('--steps', type=int, default=20)
-  p.add_argument('--warmup', type=int, default=5)
+  p.add_argument('--steps', type=int, default=250)
+  p.add_argument('--warmup', type=int, default=10)
+  p.add_argument('--config', default='c3', choices=['c3', 'c2'])
   p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--no-roofline', action='store_true')
   p.add_argument('--no-prefetch', action='store_true',
                  help='do not issue the frozen RecNet forward of the next batch during the current step')
-  p.add_argument('--batch', type=int, default=PER_GPU_BATCH)
+  p.add_argument('--batch', type=int, default=0)
   p.add_argument('--no-graphs', action='store_true', help='eager launches instead of hipGraph replay')
   p.add_argument('--no-overlap', action='store_true', help='keep the VGG branch on the main stream')
-  return p.parse_args()
+  p.add_argument('--device-resident', action='store_true',
+                 help='A/B: batches already in HBM (no H2D in the timed region)')
+  a = p.parse_args()
+  if a.batch <= 0:
+    a.batch = DEFAULT_BATCH[a.config]
+  return a
 
 
-def build_runner(dtype, batch):
-  import torch
+def build_runner(config, dtype, batch):
+  import warnings
   from utils.config import Configuration
   from models.utils import set_default_compute_dtype
   from training import build_runner as _build
   import utils
   set_default_compute_dtype(dtype)
-  conf = Configuration.from_json(os.path.join(PKG, 'configs', '2-refinement.json'))
+  if config == 'c3':
+    conf = Configuration.from_json(os.path.join(PKG, 'configs', '2-refinement.json'))
+    kind = 'adversarial'
+  else:
+    conf = Configuration.from_json(os.path.join(PKG, 'configs', '1-recnet.json'))
+    conf.model['num_blocks'], conf.model['num_convs'], conf.model['num_filters'] = 5, 3, 32
+    conf.model['compute_dtype'] = dtype
+    kind = 'standard'
   conf.batch_size = batch
   utils.set_random_seeds(conf.seed)
-  return _build(conf, 'adversarial', '0', 'train'), conf
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')      # seeded VGG weights: documented in DESIGN.md (no ImageNet file offline)
+    return _build(conf, kind, '0', 'train'), conf
 
 
-class DeviceLoader(object):
-  """Synthetic batches already resident in HBM (cycled)."""
+class PinnedHostLoader(object):
+  """Synthetic batches in PINNED HOST memory; batch t+1 is copied host->device on a copy stream while
+  step t runs (4 rotating device buffer sets).  The consumer's stream waits for the copy's event."""
 
-  def __init__(self, batches, n):
-    self.batches, self.n, self.batch_size = batches, n, batches[0]['inp'].shape[0]
+  def __init__(self, host_batches, n, device, resident=False):
+    import torch
+    self.n, self.batch_size = n, host_batches[0]['inp'].shape[0]
+    self.resident = resident
+    if resident:
+      self.dev = [{k: v.to(device) for k, v in b.items()} for b in host_batches]
+      return
+    self.host = [{k: v.pin_memory() for k, v in b.items()} for b in host_batches]
+    self.copy_stream = torch.cuda.Stream()
+    self.dev = [{k: torch.empty_like(v, device=device) for k, v in host_batches[0].items()} for _ in range(4)]
+    self.ready = [torch.cuda.Event() for _ in self.dev]
 
   def __len__(self):
     return self.n
 
+  def _issue(self, i):
+    import torch
+    j = i % len(self.dev)
+    # the buffer set was last read by step i-4; everything enqueued so far on the consumer's stream
+    # (steps <= i-2) must be done before it is overwritten
+    guard = torch.cuda.Event()
+    guard.record()
+    self.copy_stream.wait_event(guard)
+    with torch.cuda.stream(self.copy_stream):
+      src = self.host[i % len(self.host)]
+      for k, d in self.dev[j].items():
+        d.copy_(src[k], non_blocking=True)
+      self.ready[j].record(self.copy_stream)
+
   def __iter__(self):
+    import torch
+    if self.resident:
+      for i in range(self.n):
+        yield self.dev[i % len(self.dev)]
+      return
+    self._issue(0)
     for i in range(self.n):
-      yield self.batches[i % len(self.batches)]
+      if i + 1 < self.n:
+        self._issue(i + 1)
+      torch.cuda.current_stream().wait_event(self.ready[i % len(self.dev)])
+      yield self.dev[i % len(self.dev)]
 
 
-def cpu_baseline(runner, host_batch, sample_b=CPU_SAMPLE_SLICES, steps=CPU_SAMPLE_STEPS):
-  """The oracle's GAN step on the host cores, same weights, first `sample_b` slices."""
-  sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-  import torch
-  import csmri_oracle as O
-  # small-batch conv2d on the host stops scaling (and then collapses) well before the
-  # GPU box's 256 hardware threads; 32 is what the timing below uses
-  torch.set_num_threads(min(32, os.cpu_count() or 1))
-
-  def split(sd):
-    P = {k: v.detach().cpu().clone() for k, v in sd.items() if 'running' not in k and 'num_batches' not in k}
-    S = {k: v.detach().cpu().clone() for k, v in sd.items() if 'running' in k}
-    return P, S
-
-  PG, SG = split(runner.gen.state_dict())
-  PD, SD = split(runner.disc.state_dict())
-  PV = {k: v.detach().cpu().clone() for k, v in
-        runner.gen_criteria['VGG19'].criterion.vgg.state_dict().items() if k.startswith('blocks')}
-  PG = {k: (v.requires_grad_(True) if not k.startswith('pretrained_model') else v) for k, v in PG.items()}
-  PD = {k: v.requires_grad_(True) for k, v in PD.items()}
-  gopt = O.make_adam([v for v in PG.values() if v.requires_grad], 2e-4, 0.5, 0.999)
-  dopt = O.make_adam(PD.values(), 2e-4, 0.5, 0.999)
-  batch = {k: v[:sample_b].clone() for k, v in host_batch.items()}
-  with torch.no_grad():
-    out0 = O.refinement_forward(PG, {k: v.clone() for k, v in SG.items()}, batch['inp'], batch['kspace'],
-                                batch['mask'], True)
-  psnr_cpu = O.psnr_batch(out0['pred'], batch['target'])
-  pool = O.ImagePool(80)
-  O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=pool)          # warm-up
-  t0 = time.time()
-  for _ in range(steps):
-    O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=pool)
-  dt = time.time() - t0
-  cpu_model = ''
+def _cpu_model():
   try:
     with open('/proc/cpuinfo') as f:
       for line in f:
         if line.startswith('model name'):
-          cpu_model = line.split(':', 1)[1].strip()
-          break
+          return line.split(':', 1)[1].strip()
   except OSError:
     pass
-  return {'value': round(sample_b * steps / dt, 4), 'unit': 'slices/s', 'cores': torch.get_num_threads(),
-          'kind': 'port', 'cpu': cpu_model,
-          'sample': 'oracle (plain torch fp32) GAN step, %d slices of 256x256, %d timed steps after 1 warm-up'
-                    % (sample_b, steps)}, psnr_cpu
+  return ''
 
 
-def roofline(runner, loader, steps=2):
-  """Instrumented steps: HIP events around every conv-library launch."""
+def _split_sd(sd):
+  P = {k: v.detach().cpu().clone() for k, v in sd.items() if 'running' not in k and 'num_batches' not in k}
+  S = {k: v.detach().cpu().clone() for k, v in sd.items() if 'running' in k}
+  return P, S
+
+
+def cpu_baseline_c3(runner, host_batch, steps=2):
+  """The oracle's GAN step on the host cores: same weights, the SAME batch (all slices), timed at 32 threads
+  (small-batch conv2d stops scaling well before the box's hardware threads) and at os.cpu_count()."""
+  sys.path.insert(0, os.path.join(ROOT, 'oracle'))
   import torch
-  from csmri_hip import ops
-  runner.disable_graphs()       # per-launch events need eager launches
-  runner.overlap_streams = False  # ... on ONE stream: concurrent side-stream kernels would inflate the brackets
-  runner.prefetch_pretrained = False
-  ops.PROFILE = []
-  runner.train_epoch(DeviceLoader(loader.batches, steps), 1)
+  import csmri_oracle as O
+  b = host_batch['inp'].shape[0]
+  PV = {k: v.detach().cpu().clone() for k, v in
+        runner.gen_criteria['VGG19'].criterion.vgg.state_dict().items() if k.startswith('blocks')}
+  out = {}
+  for threads in sorted(set([min(32, os.cpu_count() or 1), os.cpu_count() or 1])):
+    torch.set_num_threads(threads)
+    PG, SG = _split_sd(runner.gen.state_dict())
+    PD, SD = _split_sd(runner.disc.state_dict())
+    PG = {k: (v.requires_grad_(True) if not k.startswith('pretrained_model') else v) for k, v in PG.items()}
+    PD = {k: v.requires_grad_(True) for k, v in PD.items()}
+    gopt = O.make_adam([v for v in PG.values() if v.requires_grad], 2e-4, 0.5, 0.999)
+    dopt = O.make_adam(PD.values(), 2e-4, 0.5, 0.999)
+    batch = {k: v.clone() for k, v in host_batch.items()}
+    pool = O.ImagePool(80)
+    O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=pool)          # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+      O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=pool)
+    out[threads] = b * steps / (time.time() - t0)
+  best = max(out, key=out.get)
+  return {'value': round(out[best], 4), 'unit': 'slices/s', 'cores': best, 'kind': 'port', 'cpu': _cpu_model(),
+          'by_threads': {str(k): round(v, 4) for k, v in out.items()}, 'host_threads': os.cpu_count(),
+          'sample': 'oracle (plain torch fp32) GAN step on the same %d slices of 256x256 as the GPU run, '
+                    '%d timed steps after 1 warm-up, per thread count' % (b, steps)}
+
+
+def psnr_probe_c3(runner, host_batch, scale):
+  """PSNR of the HIP generator vs the fp32 oracle on the same weights/batch with `scale` preset (train-mode
+  BatchNorm); at the reference's initial scale = 0 the U-Net is multiplied by zero (SURVEY A-10)."""
+  import torch
+  import csmri_oracle as O
+  with torch.no_grad():
+    old = float(runner.gen.scale)
+    runner.gen.scale.fill_(scale)
+    PG, SG = _split_sd(runner.gen.state_dict())
+    runner._set_train()
+    dev = {k: v.cuda() for k, v in host_batch.items()}
+    pred = runner.gen(dev['inp'], dev['kspace'], dev['mask'])['pred'].float().cpu()
+    want = O.refinement_forward(PG, SG, host_batch['inp'], host_batch['kspace'], host_batch['mask'], True)
+    runner.gen.scale.fill_(old)
+  return O.psnr_batch(pred, host_batch['target']), O.psnr_batch(want['pred'], host_batch['target'])
+
+
+def cpu_baseline_c2(runner, host_batch, sample_b=16, steps=3):
+  sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+  import torch
+  import csmri_oracle as O
+  out, psnr = {}, None
+  batch = {k: v[:sample_b].clone() for k, v in host_batch.items()}
+  for threads in sorted(set([min(32, os.cpu_count() or 1), os.cpu_count() or 1])):
+    torch.set_num_threads(threads)
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in runner.model.state_dict().items()}
+    opt = O.make_adam(P.values(), 2e-4, 0.9, 0.999)
+    if psnr is None:
+      with torch.no_grad():
+        psnr = O.psnr_batch(O.recnet_forward(P, batch['inp'], batch['kspace'], batch['mask'], 5), batch['target'])
+    O.recnet_mse_step(P, opt, batch, 5)
+    t0 = time.time()
+    for _ in range(steps):
+      O.recnet_mse_step(P, opt, batch, 5)
+    out[threads] = sample_b * steps / (time.time() - t0)
+  best = max(out, key=out.get)
+  return {'value': round(out[best], 4), 'unit': 'slices/s', 'cores': best, 'kind': 'port', 'cpu': _cpu_model(),
+          'by_threads': {str(k): round(v, 4) for k, v in out.items()}, 'host_threads': os.cpu_count(),
+          'sample': 'oracle (plain torch fp32) RecNet(5,3,32) MSE step, first %d slices of the batch, %d timed '
+                    'steps after 1 warm-up, per thread count' % (sample_b, steps)}, psnr
+
+
+def roofline(runner, loader_factory, dtype, steps=2):
+  """Instrumented eager steps on ONE stream: HIP events (torch's current stream = the stream the library
+  launches on) around every conv-library launch and every HBM-bound entry point."""
+  import torch
+  from csmri_hip import ops, lib
+  if hasattr(runner, 'disable_graphs'):
+    runner.disable_graphs()       # per-launch events need eager launches
+    runner.overlap_streams = False  # concurrent side-stream kernels would inflate the brackets
+    runner.prefetch_pretrained = False
+  ops.PROFILE, lib.HBM_PROFILE = [], []
+  runner.train_epoch(loader_factory(steps), 1)
   torch.cuda.synchronize()
   recs, ops.PROFILE = ops.PROFILE, None
-  # an empty event pair costs this much by itself; it is REPORTED, not subtracted: with a kernel
-  # between the markers most of it overlaps the kernel, and the raw brackets are what agrees with
-  # rocprofv3's per-kernel average of a single-stream run (profiles/*_single_stream.csv)
+  hrecs, lib.HBM_PROFILE = lib.HBM_PROFILE, None
+  # cost of an empty event pair (reported, not subtracted)
   pairs = []
   for _ in range(200):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -155,26 +256,42 @@ def roofline(runner, loader, steps=2):
   table = {k: {'launches_per_step': v[0] // steps, 'gflop_per_step': round(v[1] / steps / 1e9, 2),
                'ms_per_step': round(v[2] / steps * 1e3, 4),
                'tflops': round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None} for k, v in agg.items()}
-  dom = max(agg, key=lambda k: agg[k][2])
+  flop_kernels = {k: v for k, v in agg.items() if v[1] > 0}
+  dom = max(flop_kernels, key=lambda k: flop_kernels[k][2])
   n, fl, sec = agg[dom]
   achieved = fl / sec / 1e12
+  peak = PEAK_TFLOPS[dtype]
   # HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very
   # command (tools/pmc_bench.sh; FETCH_SIZE doubled per the gfx950 correction), committed under profiles/
   traffic, traffic_src = None, None
-  tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_bench_traffic.json')
-  if os.path.exists(tpath):
-    for name, rec in json.load(open(tpath)).items():
-      if dom in name:
-        traffic = round(rec['fetch_bytes_per_launch'] + rec['write_bytes_per_launch'])
-        traffic_src = 'profiles/r01_pmc_bench_traffic.json (rocprofv3 --pmc, %d launches)' % rec['launches']
-  rl = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS,
-        'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+  for tname in ('r02_pmc_bench_traffic.json', 'r01_pmc_bench_traffic.json'):
+    tpath = os.path.join(ROOT, 'profiles', tname)
+    if traffic is None and os.path.exists(tpath):
+      for name, rec in json.load(open(tpath)).items():
+        if dom in name:
+          traffic = round(rec['fetch_bytes_per_launch'] + rec['write_bytes_per_launch'])
+          traffic_src = 'profiles/%s (rocprofv3 --pmc, %d launches)' % (tname, rec['launches'])
+  rl = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak,
+        'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
         'traffic_unit': 'B/launch (HBM, PMC)', 'traffic_source': traffic_src,
         'avg_launch_us': round(sec / n * 1e6, 2), 'event_pair_overhead_us': round(ovh * 1e6, 2),
         'launches': n // steps,
         'algorithmic_gflop_per_launch': round(fl / n / 1e9, 3)}
   conv_ms = sum(v[2] for v in agg.values()) / steps * 1e3
-  return rl, table, conv_ms
+  hagg = {}
+  for label, nbytes, e0, e1 in hrecs:
+    a = hagg.setdefault(label, [0, 0.0, 0.0])
+    a[0] += 1
+    a[1] += nbytes
+    a[2] += e0.elapsed_time(e1) * 1e-3
+  hbm = []
+  for k, (cnt, nbytes, sec) in sorted(hagg.items(), key=lambda kv: -kv[1][2]):
+    gbs = nbytes / sec / 1e9 if sec > 0 else 0.0
+    hbm.append({'bound': 'hbm', 'kernel': k, 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': round(gbs / PEAK_HBM_GBS, 4), 'launches': cnt // steps,
+                'algorithmic_mb_per_launch': round(nbytes / cnt / 1e6, 3),
+                'avg_launch_us': round(sec / cnt * 1e6, 2), 'ms_per_step': round(sec / steps * 1e3, 4)})
+  return rl, table, conv_ms, hbm
 
 
 def main():
@@ -188,14 +305,15 @@ def main():
   assert ws == max(1, args.gpus) or ws == 1, (ws, args.gpus)
 
   from data.synthetic import synth_batch
-  runner, conf = build_runner(args.dtype, args.batch)
+  runner, conf = build_runner(args.config, args.dtype, args.batch)
   host_batches = [synth_batch(args.batch, SIZE, SIZE, acc=4, seed=conf.seed + 97 * rank + 100000 * i)
-                  for i in range(2)]
+                  for i in range(N_HOST_BATCHES)]
   dev = torch.device('cuda', torch.cuda.current_device())
-  batches = [{k: v.to(dev) for k, v in b.items()} for b in host_batches]
-  runner._request_data_orig = runner._request_data
 
-  def request(loader, volatile=False):      # inputs are already this rank's shard, in HBM
+  def loader_factory(n):
+    return PinnedHostLoader(host_batches, n, dev, resident=args.device_resident)
+
+  def request(loader, volatile=False):      # batches come off the loader as this rank's shard, on the device
     try:
       return next(runner.data_iter)
     except StopIteration:
@@ -203,35 +321,28 @@ def main():
       return None
   runner._request_data = request
 
-  # PSNR of the untrained generator on batch 0 (compared with the oracle below)
-  runner._set_train()
-  with torch.no_grad():
-    out0 = runner.gen(batches[0]['inp'], batches[0]['kspace'], batches[0]['mask'])
-  from metrics import PSNRMetric
-  psnr_hip_all = PSNRMetric()(out0, batches[0]).value
-  ns = min(CPU_SAMPLE_SLICES, args.batch)
-  psnr_hip = PSNRMetric()({'pred': out0['pred'][:ns]}, {'target': batches[0]['target'][:ns]}).value
-  # undo the BN running-stat update of that probe forward? it does not affect training outputs
-
-  runner.overlap_streams = not args.no_overlap
-  runner.prefetch_pretrained = not (args.no_prefetch or args.no_overlap)
-  if not args.no_graphs:
-    # capture the step once (3 eager steps inside); the timed region replays hipGraphs
-    try:
-      runner.enable_graphs(batches[0])
-    except Exception as e:            # keep the measurement alive: eager launches, same kernels
-      sys.stderr.write('bench: hipGraph capture failed (%r); running eager\n' % (e,))
-      runner.disable_graphs()
-      args.no_graphs = True
-  loader = DeviceLoader(batches, args.warmup)
+  gan = args.config == 'c3'
+  if gan:
+    runner.overlap_streams = not args.no_overlap
+    runner.prefetch_pretrained = not (args.no_prefetch or args.no_overlap)
+    if not args.no_graphs:
+      # capture the step once (3 eager steps inside); the timed region replays hipGraphs
+      try:
+        runner.enable_graphs({k: v.to(dev) for k, v in host_batches[0].items()})
+      except Exception as e:            # keep the measurement alive: eager launches, same kernels
+        sys.stderr.write('bench: hipGraph capture failed (%r); running eager\n' % (e,))
+        runner.disable_graphs()
+        args.no_graphs = True
+  else:
+    args.no_graphs = True
   if args.warmup > 0:
-    runner.train_epoch(loader, 1)
+    runner.train_epoch(loader_factory(args.warmup), 1, steps_per_train_summary=10 ** 9)
   torch.cuda.synchronize()
   if ws > 1:
     torch.distributed.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
-  losses, metrics = runner.train_epoch(DeviceLoader(batches, args.steps), 1, steps_per_train_summary=10 ** 9)
+  losses, metrics = runner.train_epoch(loader_factory(args.steps), 1, steps_per_train_summary=10 ** 9)
   torch.cuda.synchronize()
   if ws > 1:
     torch.distributed.barrier()
@@ -243,46 +354,78 @@ def main():
     dt = float(t.item())
 
   # the instrumented roofline pass trains too (its steps all-reduce): every rank takes part
-  prefetch_on = bool(runner.prefetch_pretrained)
+  prefetch_on = bool(getattr(runner, 'prefetch_pretrained', False))
   rl_out = None
   if not args.no_roofline:
-    rl_out = roofline(runner, loader)
+    rl_out = roofline(runner, loader_factory, args.dtype)
   if ws > 1:
     torch.distributed.barrier()
   if rank != 0:
     return
   slices = ws * args.batch * args.steps
   value = slices / dt
+  gf = GAN_GFLOP_PER_SLICE if gan else C2_GFLOP_PER_SLICE
+  if gan:
+    workload = ('C3/C4 2-refinement GAN step: frozen RecNet(3,3,32)+3 DC, UNET, CNNDiscriminator, '
+                'VGG19 loss, Adam x2; 256x256, 4x Cartesian, %d slices/GPU' % args.batch)
+    metric = 'train slices/sec, 256x256 GAN refinement step'
+    mode = 'eager' if args.no_graphs else ('hipGraph replay (one graph per step)' if ws == 1 else
+                                           'hipGraph replay (4 segments, collectives eager)')
+  else:
+    workload = ('C2 RecNet(5 blocks,3 convs,32 filters)+5 DC MSE training step incl. DC adjoints, Adam; '
+                '256x256, 4x Cartesian, %d slices/GPU' % args.batch)
+    metric = 'train slices/sec, 256x256 RecNet (5-cascade DC-CNN) MSE step'
+    mode = 'eager'
   line = {
-      'metric': 'train slices/sec, 256x256 GAN refinement step', 'value': round(value, 2), 'unit': 'slices/s',
+      'metric': metric, 'value': round(value, 2), 'unit': 'slices/s',
       'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+      'input': 'HBM-resident batches (A/B mode)' if args.device_resident else
+               'pinned host batches, H2D on a copy stream inside the timed region (%d distinct batches cycled)'
+               % N_HOST_BATCHES,
+      'timed_region_s': round(dt, 3),
       'prefetch': 'frozen RecNet forward of batch t+1 on a side stream during step t' if prefetch_on else None,
-      'launch_mode': 'eager' if args.no_graphs else ('hipGraph replay (one graph per step)' if ws == 1 else
-                                                      'hipGraph replay (4 segments, collectives eager)'),
-      'config': {'workload': 'C3/C4 2-refinement GAN step: frozen RecNet(3,3,32)+3 DC, UNET, CNNDiscriminator, '
-                             'VGG19 loss, Adam x2; 256x256, 4x Cartesian, %d slices/GPU' % args.batch,
-                 'per_gpu_batch': args.batch, 'global_batch': ws * args.batch,
+      'launch_mode': mode,
+      'config': {'workload': workload, 'per_gpu_batch': args.batch, 'global_batch': ws * args.batch,
                  'parallelism': 'dp%d' % ws, 'image': [SIZE, SIZE]},
-      'algorithmic_tflops': round(value * GAN_GFLOP_PER_SLICE / 1e3, 2),
+      'algorithmic_tflops': round(value * gf / 1e3, 2),
       'final_losses': {k: round(v.value, 5) for k, v in losses.items()},
-      'gen_psnr': round(metrics['gen_psnr'].value, 4) if 'gen_psnr' in metrics else None,
   }
+  for k in ('gen_psnr', 'psnr'):
+    if k in metrics:
+      line[k] = round(metrics[k].value, 4)
   if rl_out is not None:
-    rl, table, conv_ms = rl_out
+    rl, table, conv_ms, hbm = rl_out
     line['roofline'] = rl
+    line['roofline_hbm'] = hbm
     line['conv_kernels'] = table
     line['conv_ms_per_step'] = round(conv_ms, 3)
   if ws == 1 and not args.no_cpu_baseline:
     # fresh runner with the same seed = same initial weights as the HIP run started from
-    ref_runner, _ = build_runner(args.dtype, args.batch)
-    base, psnr_cpu = cpu_baseline(ref_runner, host_batches[0], sample_b=min(CPU_SAMPLE_SLICES, args.batch))
-    line['cpu_baseline'] = base
-    line['psnr_hip_db'] = round(psnr_hip, 5)
-    line['psnr_cpu_db'] = round(psnr_cpu, 5)
-    line['psnr_delta_db'] = round(abs(psnr_hip - psnr_cpu), 5)
-    line['gpu_over_cpu'] = round(value / base['value'], 1)
+    ref_runner, _ = build_runner(args.config, args.dtype, args.batch)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    if gan:
+      line['cpu_baseline'] = cpu_baseline_c3(ref_runner, host_batches[0])
+      # the 0.01 dB criterion where the U-Net contributes (scale preset; the reference starts at scale = 0
+      # where pred == pretrained, reported beside it)
+      for tag, sc in (('', 0.02), ('_scale0p25', 0.25), ('_scale0', 0.0)):
+        ph, pc = psnr_probe_c3(ref_runner, host_batches[0], sc)
+        line['psnr_hip_db' + tag], line['psnr_cpu_db' + tag] = round(ph, 5), round(pc, 5)
+        line['psnr_delta_db' + tag] = round(abs(ph - pc), 5)
+      line['psnr_probe'] = ('generator forward (train-mode BatchNorm) on batch 0, initial weights, RefinementWrapper.scale '
+                            'preset to 0.02 (headline psnr_delta_db), 0.25 and 0 (the reference\'s initial value)')
+    else:
+      base, psnr_cpu = cpu_baseline_c2(ref_runner, host_batches[0])
+      line['cpu_baseline'] = base
+      with torch.no_grad():
+        ref_runner.model.train()
+        d0 = {k: v[:16].cuda() for k, v in host_batches[0].items()}
+        import csmri_oracle as O
+        ph = O.psnr_batch(ref_runner.model(d0['inp'], d0['kspace'], d0['mask']).float().cpu(), host_batches[0]['target'][:16])
+      line['psnr_hip_db'], line['psnr_cpu_db'] = round(ph, 5), round(psnr_cpu, 5)
+      line['psnr_delta_db'] = round(abs(ph - psnr_cpu), 5)
+    line['gpu_over_cpu'] = round(value / line['cpu_baseline']['value'], 1)
   print(json.dumps(line))
 
 

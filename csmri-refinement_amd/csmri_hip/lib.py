@@ -153,9 +153,49 @@ def error_string(code):
   return s.decode() if s else 'code %d' % code
 
 
+# bench.py: HIP-event brackets around the HBM-bound entry points, with their ALGORITHMIC bytes
+# (the bytes any implementation has to move: each operand tensor once).
+HBM_PROFILE = None      # list of (label, bytes, start_event, end_event) while profiling
+
+
+def _es(dt):
+  return 4 if dt == 0 else 2
+
+
+def _dc_bytes(a):
+  # csmri_dc(x, xs, k0, mask, out, out_pad, pad_dt, work, B, H, W): read x, k0 (forward only), the
+  # uint8 mask; write out (+ the channel-padded copy when requested)
+  b, h, w = a[8], a[9], a[10]
+  n = b * h * w
+  return n * 8 * (3 if a[2] else 2) + n + (n * 8 * _es(a[6]) if a[5] else 0)
+
+
+HBM_BYTES = {
+    'csmri_dc': ('dc (3 passes)', _dc_bytes),
+    # (dt, y, ys, z, zs, b, hw, cp, ...): read y, write z
+    'csmri_bn_act': ('bn_act_kernel', lambda a: 2 * a[5] * a[6] * a[7] * _es(a[0])),
+    # (dt, gz, gzs, y, ys, r, rs, b, hw, cp, ...): read gz, y
+    'csmri_bn_bwd_reduce': ('bn_bwd_reduce_kernel', lambda a: 2 * a[7] * a[8] * a[9] * _es(a[0])),
+    # (dt, gz, gzs, y, ys, r, rs, gy, gys, b, hw, cp, ...): read gz, y; write gy
+    'csmri_bn_bwd_apply': ('bn_bwd_apply_kernel', lambda a: 3 * a[9] * a[10] * a[11] * _es(a[0])),
+    # (p, g, m, v, n, ...): read p, g, m, v; write p, m, v
+    'csmri_adam_dev': ('adam_dev_kernel', lambda a: 7 * a[4] * 4),
+    'csmri_adam': ('adam_kernel', lambda a: 7 * a[4] * 4),
+}
+
+
 def call(name, *args):
   """Call a status-returning entry point; raise RuntimeError on failure."""
-  rc = getattr(_lib, name)(*args)
+  if HBM_PROFILE is not None and name in HBM_BYTES:
+    import torch
+    label, fn = HBM_BYTES[name]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = getattr(_lib, name)(*args)
+    e1.record()
+    HBM_PROFILE.append((label, int(fn(args)), e0, e1))
+  else:
+    rc = getattr(_lib, name)(*args)
   if rc != 0:
     raise RuntimeError('%s failed: %s (%d)' % (name, error_string(rc), rc))
 
