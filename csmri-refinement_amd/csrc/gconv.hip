@@ -274,6 +274,7 @@ extern "C" size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d) {
 
 extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   { csmri_gconv_desc t = *d; t.splitk = 1; if (tconv_eligible(&t) || pconv_eligible(&t)) return 1; }
+  if (gconv8p_eligible(d)) return gconv8p_splitk(d);
   if (gconv_glds256_eligible(d)) return gconv_glds256_splitk(d);
   GConfig c = pick_config(d);
   if (gconv_glds_eligible(d)) { c.BM = 128; c.BN = gconv_glds_bn(d); }
@@ -373,6 +374,7 @@ extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int
   CSMRI_CHECK_ARG(d && buf && n > 0);
   if (pconv_eligible(d)) { snprintf(buf, n, "pconv_kernel<8>"); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
+  if (gconv8p_eligible(d)) { snprintf(buf, n, "gconv8p_kernel"); return CSMRI_OK; }
   if (gconv_glds256_eligible(d)) { snprintf(buf, n, "%s", gconv_glds256_name(d)); return CSMRI_OK; }
   if (gconv_glds_eligible(d)) { gconv_glds_kernel_name(d, buf, n); return CSMRI_OK; }
   GConfig c = pick_config(d);
@@ -399,7 +401,8 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
   if (pconv_eligible(d)) return pconv_launch(p, d, st);
   if (tconv_eligible(d)) return tconv_launch(p, d, st);
   if (gconv_glds_eligible(d)) {
-    rc = gconv_glds256_eligible(d) ? gconv_glds256_launch(p, d, st) : gconv_glds_launch(p, d, st);
+    rc = gconv8p_eligible(d) ? gconv8p_launch(p, d, st)
+         : gconv_glds256_eligible(d) ? gconv_glds256_launch(p, d, st) : gconv_glds_launch(p, d, st);
     if (rc != CSMRI_OK) return rc;
     if (p.splitk > 1 && !(d->flags & CSMRI_GCONV_DEFER_REDUCE)) return launch_reduce(p, st);
     return CSMRI_OK;

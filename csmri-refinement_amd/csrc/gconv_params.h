@@ -62,3 +62,8 @@ int gconv_glds256_eligible(const csmri_gconv_desc* d);
 int gconv_glds256_splitk(const csmri_gconv_desc* d);
 const char* gconv_glds256_name(const csmri_gconv_desc* d);
 int gconv_glds256_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
+
+// gconv8p.hip
+int gconv8p_eligible(const csmri_gconv_desc* d);
+int gconv8p_splitk(const csmri_gconv_desc* d);
+int gconv8p_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);

@@ -30,6 +30,7 @@ from models.criteria import get_criterion
 from training.adversarial_training import get_discriminator_input_fn
 from training.base_runner import BaseRunner
 from training.optimizers import get_optimizer
+from training.lr_schedulers import get_lr_scheduler, is_pre_epoch_scheduler, is_post_epoch_scheduler
 from csmri_hip import ops
 from training import distributed as dist_utils
 from utils.checkpoints import initialize_pretrained_model
@@ -67,15 +68,14 @@ def build_runner(conf, cuda, mode):
 
   gen_opt_conf = Configuration.from_dict(conf.generator_optimizer, conf)
   disc_opt_conf = Configuration.from_dict(conf.discriminator_optimizer, conf)
-  for oc in (gen_opt_conf, disc_opt_conf):
-    if oc.has_attr('lr_scheduler') or oc.get_attr('updates_per_step', 1) != 1:
-      raise NotImplementedError('lr schedulers / multiple updates per step are outside the hot '
-                                'path (SURVEY 8f rank 4)')
-  if conf.get_attr('pretrain_generator_epochs') or conf.get_attr('pretrain_discriminator_epochs'):
-    raise NotImplementedError('pretraining schedules are outside the hot path (SURVEY 8f rank 4)')
   # Important: construct optimizers after moving the models to the GPU
   gen_optimizer = get_optimizer(gen_opt_conf, gen_opt_conf.name, gen_model.parameters())
   disc_optimizer = get_optimizer(disc_opt_conf, disc_opt_conf.name, disc_model.parameters())
+  gen_lr_scheduler = disc_lr_scheduler = None      # reference adversarial_runner.py:58-73
+  if gen_opt_conf.has_attr('lr_scheduler'):
+    gen_lr_scheduler = get_lr_scheduler(gen_opt_conf, gen_opt_conf.lr_scheduler, gen_optimizer)
+  if disc_opt_conf.has_attr('lr_scheduler'):
+    disc_lr_scheduler = get_lr_scheduler(disc_opt_conf, disc_opt_conf.lr_scheduler, disc_optimizer)
 
   train_gen_metric_fns = {n: get_metric_fn(conf, n, cuda, 'train')
                           for n in conf.get_attr('train_generator_metrics', default=[])}
@@ -84,12 +84,17 @@ def build_runner(conf, cuda, mode):
   disc_input_fn = get_discriminator_input_fn(conf, disc_conf, dtype_fn=lambda: disc_model.dtype)
   val_disc_input_fn = get_discriminator_input_fn(conf, disc_conf, no_pool=True,
                                                  dtype_fn=lambda: disc_model.dtype)
-  return AdversarialRunner(gen_model, disc_model, gen_optimizer, disc_optimizer, None, None,
+  return AdversarialRunner(gen_model, disc_model, gen_optimizer, disc_optimizer,
+                           gen_lr_scheduler, disc_lr_scheduler,
                            gen_adv, gen_crit, disc_adv,
                            conf.get_attr('generator_loss_weights', {}),
                            conf.get_attr('discriminator_loss_weights', {}), cuda,
                            train_gen_metric_fns, train_disc_metric_fns, val_metric_fns, {},
-                           disc_input_fn=disc_input_fn, val_disc_input_fn=val_disc_input_fn)
+                           gen_updates_per_step=gen_opt_conf.get_attr('updates_per_step', 1),
+                           disc_updates_per_step=disc_opt_conf.get_attr('updates_per_step', 1),
+                           disc_input_fn=disc_input_fn, val_disc_input_fn=val_disc_input_fn,
+                           pretrain_generator_epochs=conf.get_attr('pretrain_generator_epochs'),
+                           pretrain_discriminator_epochs=conf.get_attr('pretrain_discriminator_epochs'))
 
 
 def _split_disc_output(out, b):
@@ -118,6 +123,7 @@ class AdversarialRunner(BaseRunner):
     super(AdversarialRunner, self).__init__(cuda)
     self.gen, self.disc = gen_model, disc_model
     self.gen_optimizer, self.disc_optimizer = gen_optimizer, disc_optimizer
+    self.gen_lr_scheduler, self.disc_lr_scheduler = gen_lr_scheduler, disc_lr_scheduler
     # a step of one network's optimizer leaves the packed weights of the other current
     from models.utils import trainable_pack_groups
     self._group_epochs = os.environ.get('CSMRI_GROUP_EPOCH', '1') != '0'        # A/B knob
@@ -133,8 +139,12 @@ class AdversarialRunner(BaseRunner):
     self.val_disc_metric_fns = val_disc_metric_fns or {}
     self.train_model_input_fn = self._get_model_input_fn(self.gen, train_input_batch_transform)
     self.test_model_input_fn = self._get_model_input_fn(self.gen, test_input_batch_transform)
-    assert gen_updates_per_step == 1 and disc_updates_per_step == 1
-    self._train_step = self._train_single_step
+    self.gen_updates_per_step, self.disc_updates_per_step = gen_updates_per_step, disc_updates_per_step
+    # reference adversarial_runner.py:176-180
+    if gen_updates_per_step == 1 and disc_updates_per_step == 1:
+      self._train_step = self._train_single_step
+    else:
+      self._train_step = self._train_multiple_steps
     self.disc_input_fn, self.val_disc_input_fn = disc_input_fn, val_disc_input_fn
     self.gen_adv_criteria = OrderedDict(gen_adv_criteria or {})
     self.gen_criteria = OrderedDict(gen_criteria or {})
@@ -145,6 +155,16 @@ class AdversarialRunner(BaseRunner):
                                                     self.disc_adv_criteria)
     self.discriminator_enabled = True
     self.generator_enabled = True
+
+    def _get_pretraining_schedule(epochs):          # reference adversarial_runner.py:195-209
+      if epochs is None:
+        return (-1, -1)
+      elif isinstance(epochs, int):
+        return (1, epochs + 1)
+      assert epochs[0] < epochs[1], 'Starting epoch must be smaller than ending epoch'
+      return tuple(epochs)
+    self.generator_pretraining_schedule = _get_pretraining_schedule(pretrain_generator_epochs)
+    self.discriminator_pretraining_schedule = _get_pretraining_schedule(pretrain_discriminator_epochs)
     self.pool_decisions = None            # optional injected image-pool decisions (tests)
     self._graph = None
     self._last_metrics = None
@@ -544,6 +564,9 @@ class AdversarialRunner(BaseRunner):
     return super(AdversarialRunner, self).train_epoch(loader, epoch, *args, **kwargs)
 
   def _train_single_step(self, loader):
+    if not (self.discriminator_enabled and self.generator_enabled):
+      self._pf = None
+      return self._train_single_step_general(loader)
     batch_next = pre_cur = None
     if self.prefetch_pretrained:
       # this step's batch was fetched (and its pretrained reconstruction issued) one step ago
@@ -575,6 +598,175 @@ class AdversarialRunner(BaseRunner):
     loss_metrics = {name: get_loss_metric(VecRef(shared, i)) for i, name in enumerate(st['names'])}
     self._last_metrics = {name: MaxMetric(VecRef(shared, n + j)) for j, name in enumerate(st['metric_names'])}
     return 1, loss_metrics, (st['batch'], st['out_gen'], st['out_disc_fake'], st['out_disc_real'])
+
+  # -- epoch hooks: LR schedulers and pretraining schedules (reference adversarial_runner.py:267-305) --
+  def epoch_beginning(self, epoch):
+    lrs = [o.param_groups[0]['lr'] for o in (self.gen_optimizer, self.disc_optimizer) if o is not None]
+    if is_pre_epoch_scheduler(self.gen_lr_scheduler):
+      self.gen_lr_scheduler.step()
+    if is_pre_epoch_scheduler(self.disc_lr_scheduler):
+      self.disc_lr_scheduler.step()
+    start, end = self.generator_pretraining_schedule
+    if start <= epoch < end:
+      logging.debug('Pretraining generator, discriminator disabled')
+      self.discriminator_enabled = False
+      self.generator_enabled = True
+    else:
+      self.discriminator_enabled = True
+    if start == epoch:
+      logging.info('Start pretraining generator in epoch {}'.format(epoch))
+    elif end == epoch:
+      logging.info('Stop pretraining generator before epoch {}'.format(epoch))
+    start, end = self.discriminator_pretraining_schedule
+    if start <= epoch < end:
+      logging.debug('Pretraining discriminator, generator disabled')
+      self.discriminator_enabled = True
+      self.generator_enabled = False
+    else:
+      self.generator_enabled = True
+    if start == epoch:
+      logging.info('Start pretraining discriminator in epoch {}'.format(epoch))
+    elif end == epoch:
+      logging.info('Stop pretraining discriminator before epoch {}'.format(epoch))
+    self._after_lr_change(lrs)
+
+  def epoch_finished(self, epoch):
+    lrs = [o.param_groups[0]['lr'] for o in (self.gen_optimizer, self.disc_optimizer) if o is not None]
+    if is_post_epoch_scheduler(self.gen_lr_scheduler):
+      self.gen_lr_scheduler.step()
+    if is_post_epoch_scheduler(self.disc_lr_scheduler):
+      self.disc_lr_scheduler.step()
+    self._after_lr_change(lrs)
+
+  def _after_lr_change(self, old_lrs):
+    """The learning rate is a launch argument of the fused Adam kernel, i.e. baked into a captured
+    hipGraph: capture again (same static buffers' shapes) when a scheduler moved it."""
+    new = [o.param_groups[0]['lr'] for o in (self.gen_optimizer, self.disc_optimizer) if o is not None]
+    if new != old_lrs and getattr(self, '_graph', None) is not None:
+      example = {k: v.clone() for k, v in self._graph['static'].items()}
+      self.disable_graphs()
+      self.enable_graphs(example, warmup=0)
+
+  # -- the reference's control flow, literally: used whenever a network is disabled by a pretraining
+  #    schedule or several updates per step are configured (the fused 4-segment step above is the
+  #    both-enabled, one-update-each case) ---------------------------------------------------------------
+  def _disc_forward_pair(self, out_gen, gen_inp0, target):
+    out_fake = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp0, out_gen, is_real_input=False, detach=True,
+                                                 pool_decisions=self.pool_decisions))
+    out_real = self.disc(nhwc=self.disc_input_fn(target, gen_inp0, out_gen, is_real_input=True, detach=True))
+    return out_fake, out_real
+
+  def _general_update(self, optimizer, losses, weights):
+    assert len(losses) == int(weights.numel()), \
+        'got %d losses for %d loss weights (the reference fails the same way: adversarial generator ' \
+        'losses are weighted but not computed while the discriminator is disabled)' % (len(losses), weights.numel())
+    return self._update_step(optimizer, losses, weights)
+
+  def _train_single_step_general(self, loader):
+    """reference adversarial_runner.py:322-389 with its enabled flags."""
+    batch = self._request_data(loader)
+    if batch is None:
+      return 0, None, None
+    loss_metrics = {}
+    gen_inp = self.train_model_input_fn(batch)
+    out_gen = self.gen(*gen_inp)
+    out_disc_fake = out_disc_real = None
+    if self.discriminator_enabled:
+      out_disc_fake, out_disc_real = self._disc_forward_pair(out_gen, gen_inp[0], batch['target'])
+      disc_losses = []
+      for name, criterion in self.disc_adv_criteria.items():
+        loss = criterion(out_disc_fake, out_disc_real)
+        disc_losses.append(loss)
+        loss_metrics['disc_loss_' + name] = get_loss_metric(loss.detach())
+    if self.generator_enabled:
+      gen_losses = []
+      if self.discriminator_enabled:
+        out_disc_fake = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False,
+                                                          detach=False))
+        for name, criterion in self.gen_adv_criteria.items():
+          loss = criterion(out_disc_fake, out_disc_real)
+          gen_losses.append(loss)
+          loss_metrics['gen_loss_' + name] = get_loss_metric(loss.detach())
+      for name, criterion in self.gen_criteria.items():
+        loss = criterion(out_gen, batch)
+        gen_losses.append(loss)
+        loss_metrics['gen_loss_' + name] = get_loss_metric(loss.detach())
+    if self.discriminator_enabled:
+      total = self._general_update(self.disc_optimizer, disc_losses, self.disc_loss_weights)
+      loss_metrics['disc_loss'] = get_loss_metric(total)
+    if self.generator_enabled:
+      total = self._general_update(self.gen_optimizer, gen_losses, self.gen_loss_weights)
+      loss_metrics['gen_loss'] = get_loss_metric(total)
+    if not self.discriminator_enabled:
+      out_disc_fake = out_disc_real = None
+    return 1, loss_metrics, (batch, out_gen, out_disc_fake, out_disc_real)
+
+  def _train_multiple_steps(self, loader):
+    """Several discriminator / generator updates per step (reference adversarial_runner.py:391-525):
+    max(updates) batches are drawn up front; the discriminator trains on the first
+    disc_updates_per_step of them, then the generator on the first gen_updates_per_step (fresh
+    forward passes through the already updated discriminator; the real pass is repeated only for
+    the feature-matching loss).  Loss metrics are averaged over the updates; the returned data is
+    that of the last update."""
+    from metrics import accumulate_metric
+    last_batch = None
+    max_updates = max(self.disc_updates_per_step, self.gen_updates_per_step)
+    batches = []
+    for _ in range(max_updates):
+      batch = self._request_data(loader)
+      if batch is None:
+        break
+      batches.append(batch)
+    gen_uses_feature_matching = 'FeatureMatching' in self.gen_adv_criteria
+    loss_metrics = {}
+    out_gen = out_disc_fake = out_disc_real = None
+    for idx, batch in enumerate(batches[:self.disc_updates_per_step]):
+      if not self.discriminator_enabled:
+        continue
+      last_batch = batch
+      gen_inp = self.train_model_input_fn(batch)
+      out_gen = self.gen(*gen_inp)
+      out_disc_fake, out_disc_real = self._disc_forward_pair(out_gen, gen_inp[0], batch['target'])
+      disc_losses = []
+      for name, criterion in self.disc_adv_criteria.items():
+        loss = criterion(out_disc_fake, out_disc_real)
+        disc_losses.append(loss)
+        accumulate_metric(loss_metrics, 'disc_loss_' + name, get_loss_metric(loss.detach()))
+      total = self._general_update(self.disc_optimizer, disc_losses, self.disc_loss_weights)
+      accumulate_metric(loss_metrics, 'disc_loss', get_loss_metric(total))
+    for idx, batch in enumerate(batches[:self.gen_updates_per_step]):
+      if not self.generator_enabled:
+        continue
+      last_batch = batch
+      gen_losses = []
+      gen_inp = self.train_model_input_fn(batch)
+      out_gen = self.gen(*gen_inp)
+      if self.discriminator_enabled:
+        out_disc_fake = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False,
+                                                          detach=False))
+        if gen_uses_feature_matching:
+          out_disc_real = self.disc(nhwc=self.disc_input_fn(batch['target'], gen_inp[0], out_gen,
+                                                            is_real_input=True, detach=True))
+        else:
+          out_disc_real = None
+        for name, criterion in self.gen_adv_criteria.items():
+          loss = criterion(out_disc_fake, out_disc_real)
+          gen_losses.append(loss)
+          accumulate_metric(loss_metrics, 'gen_loss_' + name, get_loss_metric(loss.detach()))
+      for name, criterion in self.gen_criteria.items():
+        loss = criterion(out_gen, batch)
+        gen_losses.append(loss)
+        accumulate_metric(loss_metrics, 'gen_loss_' + name, get_loss_metric(loss.detach()))
+      total = self._general_update(self.gen_optimizer, gen_losses, self.gen_loss_weights)
+      accumulate_metric(loss_metrics, 'gen_loss', get_loss_metric(total))
+    if len(batches) > 0:
+      avg = {name: m.average() for name, m in loss_metrics.items()}
+      if not self.discriminator_enabled:
+        out_disc_fake = out_disc_real = None
+      data = (last_batch, out_gen, out_disc_fake, out_disc_real)
+    else:
+      avg, data = None, None
+    return len(batches), avg, data
 
   def _val_step(self, loader, compute_metrics=True):
     batch = self._request_data(loader, volatile=True)

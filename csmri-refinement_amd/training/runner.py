@@ -9,6 +9,7 @@ from models import construct_model
 from models.criteria import get_criterion
 from training.base_runner import BaseRunner
 from training.optimizers import get_optimizer
+from training.lr_schedulers import get_lr_scheduler, is_pre_epoch_scheduler, is_post_epoch_scheduler
 from training import distributed as dist_utils
 from utils.checkpoints import initialize_pretrained_model
 from utils.config import Configuration
@@ -34,12 +35,13 @@ def build_runner(conf, cuda, mode='train'):
     initialize_pretrained_model(model_conf, model, cuda, conf.file)
   dist_utils.broadcast_module(model)
   opt_conf = Configuration.from_dict(conf.optimizer, conf)
-  if opt_conf.has_attr('lr_scheduler'):
-    raise NotImplementedError('lr schedulers are outside the hot path (SURVEY 8f)')
   optimizer = get_optimizer(opt_conf, opt_conf.name, model.parameters())
+  lr_scheduler = None
+  if opt_conf.has_attr('lr_scheduler'):          # reference training/runner.py:48-52
+    lr_scheduler = get_lr_scheduler(opt_conf, opt_conf.lr_scheduler, optimizer)
   train_metric_fns = {name: get_metric_fn(conf, name, cuda, 'train')
                       for name in conf.get_attr('train_metrics', default=[])}
-  return Runner(model, criteria, conf.get_attr('loss_weights', {}), optimizer, None, cuda,
+  return Runner(model, criteria, conf.get_attr('loss_weights', {}), optimizer, lr_scheduler, cuda,
                 train_metric_fns, val_metric_fns)
 
 
@@ -52,6 +54,7 @@ class Runner(BaseRunner):
     self.criteria = criteria or {}
     self.loss_weights = self._get_loss_weights(loss_weights or {}, self.criteria)
     self.optimizer = optimizer
+    self.lr_scheduler = lr_scheduler
     self.train_metric_fns = train_metric_fns or {}
     self.val_metric_fns = val_metric_fns or {}
     self.train_model_input_fn = self._get_model_input_fn(model, train_input_batch_transform)
@@ -78,6 +81,14 @@ class Runner(BaseRunner):
 
   def __str__(self):
     return 'Model:\n' + str(self.model)
+
+  def epoch_beginning(self, epoch):               # reference training/runner.py:140-142
+    if is_pre_epoch_scheduler(self.lr_scheduler):
+      self.lr_scheduler.step()
+
+  def epoch_finished(self, epoch):                # reference training/runner.py:144-146
+    if is_post_epoch_scheduler(self.lr_scheduler):
+      self.lr_scheduler.step()
 
   def predict(self, batch):
     return self.model(*self.train_model_input_fn(batch, use_batch_transform=False))

@@ -691,6 +691,109 @@ def gan_train_step(PG, SG, PD, SD, PV, gen_opt, disc_opt, batch, pool=None,
   return losses, metrics, out_gen
 
 
+def lr_multistep(base_lr, milestones, gamma, epoch):
+  """MultiStepLR as built by training/lr_schedulers.py:26-31 (``multistep``): the value in force while
+  the scheduler's epoch counter is ``epoch`` (the runner steps it once per epoch_beginning, so training
+  epoch e runs at epoch index e; index 0 is the construction-time value)."""
+  return base_lr * gamma ** sum(1 for m in milestones if m <= epoch)
+
+
+def lr_polynomial(base_lr, end_lr, decay_epochs, epoch, from_epoch=0, power=1.0):
+  """LambdaLR with _get_polynomial_decay, training/lr_schedulers.py:4-15,32-42 (``linear`` is
+  power 1)."""
+  if epoch < from_epoch:
+    return base_lr
+  end_epoch = float(from_epoch + decay_epochs)
+  e = min(epoch, end_epoch)
+  return (base_lr - end_lr) * (1.0 - e / end_epoch) ** power + end_lr
+
+
+def pretraining_flags(epoch, gen_schedule=None, disc_schedule=None):
+  """(discriminator_enabled, generator_enabled) for an epoch: AdversarialRunner.epoch_beginning,
+  adversarial_runner.py:273-298, with _get_pretraining_schedule (:195-209): an int n means epochs
+  1..n, a pair [a, b) is used as is, None never applies.  The generator schedule is evaluated first
+  and the discriminator schedule may re-enable the discriminator it switched off."""
+  def sched(e):
+    if e is None:
+      return (-1, -1)
+    if isinstance(e, int):
+      return (1, e + 1)
+    return tuple(e)
+  disc_en = gen_en = True
+  start, end = sched(gen_schedule)
+  if start <= epoch < end:
+    disc_en, gen_en = False, True
+  else:
+    disc_en = True
+  start, end = sched(disc_schedule)
+  if start <= epoch < end:
+    disc_en, gen_en = True, False
+  else:
+    gen_en = True
+  return disc_en, gen_en
+
+
+def gan_train_multi_step(PG, SG, PD, SD, PV, gen_opt, disc_opt, batches, disc_updates=1,
+                         gen_updates=1, disc_enabled=True, gen_enabled=True, pool=None,
+                         dropout_masks=None, weights=GEN_LOSS_WEIGHTS, label_smoothing=0.1):
+  """AdversarialRunner._train_multiple_steps, adversarial_runner.py:391-525.
+
+  ``batches``: the max(disc_updates, gen_updates) batches drawn up front.  The discriminator is
+  updated on batches[:disc_updates] (generator forward, D(fake.detach via pool), D(real), loss,
+  backward, step), then the generator on batches[:gen_updates] (generator forward, D(fake) through the
+  UPDATED discriminator, D(real) again only for FeatureMatching, all generator losses, backward,
+  step).  dropout_masks: one [3 layers] list per discriminator forward, in call order.  Returns the
+  per-name averages of the loss values over the updates (reference :509-511) and the last out_gen."""
+  masks = list(dropout_masks) if dropout_masks is not None else None
+
+  def next_masks():
+    return masks.pop(0) if masks is not None else None
+  sums, counts = {}, {}
+
+  def acc(name, v):
+    sums[name] = sums.get(name, 0.0) + float(v.detach() if torch.is_tensor(v) else v)
+    counts[name] = counts.get(name, 0) + 1
+  out_gen = None
+  d_params = [p for g in disc_opt.param_groups for p in g['params']]
+  if disc_enabled:
+    for batch in batches[:disc_updates]:
+      out_gen = refinement_forward(PG, SG, batch['inp'], batch['kspace'], batch['mask'], True)
+      fake_in = complex_abs(out_gen['pred']).detach()
+      if pool is not None:
+        fake_in = pool.query(fake_in, None)
+      out_fake = disc_forward(PD, SD, fake_in, True, dropout_masks=next_masks())
+      out_real = disc_forward(PD, SD, complex_abs(batch['target']).detach(), True, dropout_masks=next_masks())
+      l = gan_loss_disc(out_fake, out_real, label_smoothing)
+      acc('disc_loss_gan', l)
+      disc_opt.zero_grad()
+      (1.0 * l).backward()
+      disc_opt.step()
+      acc('disc_loss', l)
+  if gen_enabled:
+    for batch in batches[:gen_updates]:
+      out_gen = refinement_forward(PG, SG, batch['inp'], batch['kspace'], batch['mask'], True)
+      total = 0.0
+      if disc_enabled:
+        out_fake = disc_forward(PD, SD, complex_abs(out_gen['pred']), True, dropout_masks=next_masks())
+        out_real = disc_forward(PD, SD, complex_abs(batch['target']).detach(), True, dropout_masks=next_masks())
+        l_gan, l_fm = gan_loss_gen(out_fake), feature_matching_loss(out_fake, out_real)
+        acc('gen_loss_gan', l_gan)
+        acc('gen_loss_FeatureMatching', l_fm)
+        total = weights['gan'] * l_gan + weights['FeatureMatching'] * l_fm
+      l_vgg, l_fp = vgg_loss(PV, out_gen['pred'], batch['target']), feature_penalty(out_gen)
+      acc('gen_loss_VGG19', l_vgg)
+      acc('gen_loss_FeaturePenalty', l_fp)
+      total = total + weights['VGG19'] * l_vgg + weights['FeaturePenalty'] * l_fp
+      gen_opt.zero_grad()
+      saved = [p.grad.clone() if p.grad is not None else None for p in d_params]
+      total.backward()
+      for p, g in zip(d_params, saved):      # gradients deposited in D by the generator backward are unused (A-5)
+        p.grad = g
+      gen_opt.step()
+      acc('gen_loss', total)
+  return {k: sums[k] / counts[k] for k in sums}, out_gen
+
+
 # --------------------------------------------------------------------------
 # synthetic inputs      compressed_sensing.py:82-123,460-512; dnn_io.py:4-61;
 #                       myImageTransformations.py:1196-1238; rec_transforms.py:47

@@ -10,7 +10,7 @@ the reference's source is stored -- only data.
 
 Fixtures: F1 synthetic batch + mask rows, F2 DC fwd/adjoint,
 F3 RecNet fwd/loss/grads/Adam steps, F4 RefinementWrapper, F5 discriminator,
-F6 VGG loss, F7 full GAN train steps, F8 PSNR, F9 SSIM, F10 radial masks.
+F6 VGG loss, F7 full GAN train steps, F8 PSNR, F9 SSIM, F10 radial masks, F11 multi-update steps + pretraining schedule + LR schedulers.
 """
 import collections
 import collections.abc
@@ -571,8 +571,60 @@ def f10():
   save('F10_radial', **out)
 
 
+# ----------------------------------------------------------------- F11 ----
+# several updates per step, a discriminator-pretraining schedule and both learning-rate
+# schedulers, through the reference's own AdversarialRunner (epoch_beginning / train_epoch /
+# epoch_finished as train.py:263-276 calls them).  Epoch 1: generator disabled (discriminator
+# pretraining), epochs 2-3: two discriminator updates + one generator update per step.
+
+
+def f11():
+  conf = _gan_conf()
+  conf.discriminator_optimizer = dict(conf.discriminator_optimizer, updates_per_step=2, lr_scheduler='linear',
+                                      end_learning_rate=2e-5, decay_steps=4)
+  conf.generator_optimizer = dict(conf.generator_optimizer, lr_scheduler='multistep', decay_steps=[2],
+                                  decay_factor=0.5)
+  conf.pretrain_discriminator_epochs = 1
+  ref_utils.set_random_seeds(conf.seed)
+  runner = ref_AR.build_runner(conf, '', 'train')
+  vgg_crit = runner.gen_criteria['VGG19'].c
+  _load_vgg_weights(vgg_crit.criterion.vgg, seed=19)
+  with torch.no_grad():
+    runner.gen.scale.fill_(0.25)
+  inj = _InjectedDropout()
+  g = torch.Generator().manual_seed(77)
+  inj.install(runner.disc, g)
+  out = {'G0.' + k: v for k, v in npd(runner.gen.state_dict()).items()}
+  out.update({'D0.' + k: v for k, v in npd(runner.disc.state_dict()).items()})
+  out['conf'] = np.array(['disc updates_per_step=2 lr_scheduler=linear end_learning_rate=2e-5 decay_steps=4; '
+                          'gen lr_scheduler=multistep decay_steps=[2] decay_factor=0.5; '
+                          'pretrain_discriminator_epochs=1'])
+  for epoch in (1, 2, 3):
+    runner.epoch_beginning(epoch)
+    out['ep%d.flags' % epoch] = np.array([int(runner.discriminator_enabled), int(runner.generator_enabled)])
+    out['ep%d.lr' % epoch] = np.array([runner.gen_optimizer.param_groups[0]['lr'],
+                                       runner.disc_optimizer.param_groups[0]['lr']], dtype=np.float64)
+    batches = [O.synth_batch(2, 128, 128, acc=4, seed=300 + 10 * epoch + i) for i in range(2)]
+    n_before = len(inj.used)
+    l, m = runner.train_epoch(_Loader(batches), epoch)
+    runner.epoch_finished(epoch)
+    used = inj.used[n_before:]
+    out['ep%d.num_masks' % epoch] = np.int64(len(used))
+    for j, mk in enumerate(used):
+      out['ep%d.mask%d' % (epoch, j)] = mk.numpy()
+    names = sorted(l.keys())
+    out['ep%d.loss_names' % epoch] = np.array(names)
+    out['ep%d.losses' % epoch] = np.array([l[k].value for k in names], dtype=np.float64)
+    out['ep%d.gen_psnr' % epoch] = np.float64(m['gen_psnr'].value)
+    out.update({'G%d.%s' % (epoch, k): v for k, v in npd(runner.gen.state_dict()).items()
+                if not k.startswith('pretrained_model')})
+    out.update({'D%d.%s' % (epoch, k): v for k, v in npd(runner.disc.state_dict()).items()})
+  out['vgg_seed'] = np.int64(19)
+  save('F11_schedules', **out)
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11']
   for name in which:
     print('==', name)
     globals()[name]()

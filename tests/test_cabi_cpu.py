@@ -141,3 +141,43 @@ def test_image_pool_semantics():
     ra = a.query(x, dec)
     rb = b.query(x, [(u, i) for u, i in dec])
     assert torch.equal(ra, rb), step
+
+
+def test_lr_schedulers_match_torch_closed_forms():
+  """training/lr_schedulers.py (FlatAdam has no torch optimizer to hand to torch's schedulers) against
+  torch.optim.lr_scheduler.MultiStepLR / LambdaLR driven the way the reference drives them
+  (reference training/lr_schedulers.py:26-44: constructed with initial_epoch -1, one step() per epoch)."""
+  import sys
+  import torch
+  sys.path.insert(0, PKG)
+  from training import lr_schedulers as L
+
+  class Opt(object):
+    def __init__(self, lr):
+      self.param_groups = [{'lr': lr}]
+
+  class Conf(dict):
+    __getattr__ = dict.__getitem__
+
+    def get_attr(self, k, default=None):
+      return self.get(k, default)
+
+  for name, conf in (('multistep', Conf(decay_steps=[2, 5], decay_factor=0.3)),
+                     ('linear', Conf(learning_rate=2e-4, end_learning_rate=1e-5, decay_steps=6, start_decay=2)),
+                     ('polynomial', Conf(learning_rate=2e-4, end_learning_rate=0.0, decay_steps=5, decay_power=2.0))):
+    mine = Opt(2e-4)
+    sm = L.get_lr_scheduler(conf, name, mine)
+    p = torch.nn.Parameter(torch.zeros(1))
+    theirs = torch.optim.Adam([p], lr=2e-4)
+    if name == 'multistep':
+      st = torch.optim.lr_scheduler.MultiStepLR(theirs, conf.decay_steps, conf.decay_factor, -1)
+    else:
+      lam = L._get_polynomial_decay(conf.learning_rate, conf.end_learning_rate, conf.decay_steps,
+                                    conf.get_attr('start_decay', 0), 1.0 if name == 'linear' else conf.decay_power)
+      st = torch.optim.lr_scheduler.LambdaLR(theirs, lam, -1)
+    for epoch in range(10):
+      assert abs(mine.param_groups[0]['lr'] - theirs.param_groups[0]['lr']) < 1e-18 + 1e-12 * 2e-4, (name, epoch)
+      assert L.is_pre_epoch_scheduler(sm) and not L.is_post_epoch_scheduler(sm)
+      sm.step()
+      theirs.step()
+      st.step()

@@ -862,3 +862,60 @@ def test_bf16_psnr_where_the_unet_contributes(env, scale):
         (scale, p_hip, p_ref, abs(p_hip - p_ref), p_pre, rel))
   assert abs(p_ref - p_pre) > 0.05, 'the U-Net must actually move the prediction for this test to mean anything'
   assert abs(p_hip - p_ref) < (0.01 if scale < 0.1 else 0.02)
+
+
+def test_f11_multi_update_steps_pretraining_schedule_lr_schedulers_fp32(env):
+  """SURVEY 8f-4 against F11, written by the reference's AdversarialRunner (training/adversarial_runner.py
+  :58-73,195-209,267-305,391-525; training/lr_schedulers.py:26-44): config keys updates_per_step,
+  lr_scheduler (multistep / linear), pretrain_discriminator_epochs; three epochs driven exactly as the
+  reference's train.py:263-276 drives them.  Flags and learning rates exact; losses 1e-4 relative in
+  epoch 1 (first Adam steps amplify fp32 noise afterwards: 2e-3, as in the F7 test); parameters after
+  epoch 1 within 2 lr."""
+  Configuration, set_dtype = env
+  from training import build_runner
+  from csmri_hip import ops
+  f = load('F11_schedules')
+  set_dtype('fp32')
+  conf = gan_conf(Configuration, 'fp32')
+  conf.discriminator_optimizer = dict(conf.discriminator_optimizer, updates_per_step=2, lr_scheduler='linear',
+                                      end_learning_rate=2e-5, decay_steps=4)
+  conf.generator_optimizer = dict(conf.generator_optimizer, lr_scheduler='multistep', decay_steps=[2],
+                                  decay_factor=0.5)
+  conf.pretrain_discriminator_epochs = 1
+  runner = build_runner(conf, 'adversarial', '0', 'train')
+  runner.gen.load_state_dict(sub(f, 'G0.'))
+  runner.disc.load_state_dict(sub(f, 'D0.'))
+  ops.bump_weight_epoch()
+  assert runner._train_step == runner._train_multiple_steps
+  for epoch in (1, 2, 3):
+    runner.epoch_beginning(epoch)
+    assert [int(runner.discriminator_enabled), int(runner.generator_enabled)] == list(f['ep%d.flags' % epoch])
+    lrs = [runner.gen_optimizer.param_groups[0]['lr'], runner.disc_optimizer.param_groups[0]['lr']]
+    assert np.allclose(lrs, f['ep%d.lr' % epoch], rtol=1e-12), (epoch, lrs)
+    batches = [O.synth_batch(2, 128, 128, acc=4, seed=300 + 10 * epoch + i) for i in range(2)]
+    n = int(f['ep%d.num_masks' % epoch])
+    runner.disc.injected_dropout = [T(f['ep%d.mask%d' % (epoch, j)]) for j in range(n)]
+    losses, metrics = runner.train_epoch(Loader(batches), epoch)
+    runner.epoch_finished(epoch)
+    assert not runner.disc.injected_dropout, 'every injected mask must have been consumed, in order'
+    names = [str(s) for s in f['ep%d.loss_names' % epoch]]
+    assert sorted(losses) == names
+    tol = 1e-4 if epoch == 1 else 3e-3
+    for k, v in zip(names, f['ep%d.losses' % epoch]):
+      print('F11 epoch %d %-26s hip %.7f ref %.7f' % (epoch, k, losses[k].value, v))
+      assert abs(losses[k].value - v) < tol * max(1.0, abs(v)), (epoch, k, losses[k].value, v)
+    assert abs(metrics['gen_psnr'].value - float(f['ep%d.gen_psnr' % epoch])) < 2e-3
+    if epoch == 1:
+      sd = runner.disc.state_dict()
+      for k, v in sub(f, 'D1.').items():
+        if 'num_batches' in k:
+          assert int(sd[k]) == int(v), k
+          continue
+        d = (sd[k].cpu().float() - v.float()).abs()
+        assert float(d.max()) < 2 * 2.0 * 1.55e-4 * max(1.0, float(v.abs().max())) + 1e-5, (k, float(d.max()))
+      # the generator is frozen during discriminator pretraining
+      sg = runner.gen.state_dict()
+      for k, v in sub(f, 'G0.').items():
+        if 'running' in k or 'num_batches' in k:
+          continue
+        assert torch.equal(sg[k].cpu().float(), v.float()), k

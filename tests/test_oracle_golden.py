@@ -287,3 +287,54 @@ def test_f10_radial_masks_bit_exact():
                       rng=np.random.RandomState(4321))
     assert tuple(m.shape) == tuple(int(v) for v in f['shape_' + tag])
     assert np.array_equal(np.flatnonzero(m), f['idx_' + tag]), tag
+
+
+# ----------------------------------------------------------------- F11 ----
+
+
+def test_f11_multi_update_steps_schedules_and_lr_schedulers():
+  """the reference's _train_multiple_steps (2 discriminator updates + 1 generator update
+  per step), discriminator pretraining in epoch 1 and both LR schedulers over three epochs."""
+  f = load('F11_schedules')
+  PG, SG = _split_state(sub(f, 'G0.'))
+  PD, SD = _split_state(sub(f, 'D0.'))
+  PG = {k: (v.clone().requires_grad_(True) if not k.startswith('pretrained_model') else v)
+        for k, v in PG.items()}
+  PD = {k: v.clone().requires_grad_(True) for k, v in PD.items()}
+  PV = O.init_vgg(gen=torch.Generator().manual_seed(int(f['vgg_seed'])))
+  gopt = O.make_adam([v for k, v in PG.items() if v.requires_grad], 2e-4, 0.5, 0.999)
+  dopt = O.make_adam(PD.values(), 2e-4, 0.5, 0.999)
+  orig_unet, orig_disc = O.UNET_CONF, O.DISC_CONF
+  O.UNET_CONF, O.DISC_CONF = SMALL_UNET, SMALL_DISC
+  try:
+    _patch_defaults()
+    pool = O.ImagePool(80)
+    for epoch in (1, 2, 3):
+      disc_en, gen_en = O.pretraining_flags(epoch, None, 1)
+      assert [int(disc_en), int(gen_en)] == list(f['ep%d.flags' % epoch])
+      lr_g = O.lr_multistep(2e-4, [2], 0.5, epoch)
+      lr_d = O.lr_polynomial(2e-4, 2e-5, 4, epoch)
+      assert np.allclose([lr_g, lr_d], f['ep%d.lr' % epoch], rtol=1e-12)
+      gopt.param_groups[0]['lr'], dopt.param_groups[0]['lr'] = lr_g, lr_d
+      batches = [O.synth_batch(2, 128, 128, acc=4, seed=300 + 10 * epoch + i) for i in range(2)]
+      n = int(f['ep%d.num_masks' % epoch])
+      masks = [T(f['ep%d.mask%d' % (epoch, j)]) for j in range(n)]
+      dm = [masks[i:i + 3] for i in range(0, n, 3)]
+      losses, out_gen = O.gan_train_multi_step(PG, SG, PD, SD, PV, gopt, dopt, batches, disc_updates=2,
+                                               gen_updates=1, disc_enabled=disc_en, gen_enabled=gen_en,
+                                               pool=pool, dropout_masks=dm)
+      names = [str(s) for s in f['ep%d.loss_names' % epoch]]
+      assert sorted(losses) == names
+      for k, v in zip(names, f['ep%d.losses' % epoch]):
+        assert abs(losses[k] - v) < 5e-5 * max(1.0, abs(v)), (epoch, k, losses[k], v)
+      psnr = O.psnr_batch(out_gen['pred'].detach(), batches[1 if not gen_en else 0]['target'])
+      assert abs(psnr - float(f['ep%d.gen_psnr' % epoch])) < 2e-3
+      for tag, P, S in (('G', PG, SG), ('D', PD, SD)):
+        for k, v in sub(f, '%s%d.' % (tag, epoch)).items():
+          cur = P[k] if k in P else S.get(k)
+          if cur is None:
+            continue
+          assert torch.allclose(cur.detach().float(), v.float(), atol=5e-5, rtol=2e-3), (epoch, tag, k)
+  finally:
+    O.UNET_CONF, O.DISC_CONF = orig_unet, orig_disc
+    _patch_defaults()
