@@ -267,6 +267,7 @@ class PackGroup(object):
 FOLD_WINDOW = True      # reflection dgrads: centre written in place + border-only halo fold
 PROFILE_SHAPES = False  # tools: append the problem shape to gconv labels
 PROFILE = None        # bench.py sets this to a list to collect per-launch HIP event timings
+GRAD_READY_HOOK = None  # data parallelism: called with the ConvLayer once its weight-gradient launch is issued
 LAUNCH_LOG = None     # tests set this to a list: (kind, kernel instance name, splitk) per conv-library launch
 
 
@@ -570,6 +571,8 @@ class ConvAct(torch.autograd.Function):
     g = act_bwd(gy, y, ctx.act_slope) if ctx.act_slope != 1.0 else gy
     if ctx.w_req:
       conv_wgrad(layer, x0, x1, g)
+      if GRAD_READY_HOOK is not None:
+        GRAD_READY_HOOK(layer)
     gx0 = gx1 = None
     if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
       gx = conv_dgrad(layer, g, ctx.in_hw)
@@ -684,6 +687,8 @@ class ConvBnAct(torch.autograd.Function):
              bn.bias.grad.data_ptr() if want_affine else 0, 1, snap.data_ptr(), groups, stream())
     if want_affine:
       conv_wgrad(layer, x0, x1, gy)
+      if GRAD_READY_HOOK is not None:
+        GRAD_READY_HOOK(layer)
     gx0 = gx1 = None
     if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
       gx = conv_dgrad(layer, gy, ctx.in_hw)
@@ -828,6 +833,30 @@ def undersample(img, mask_u8):
   lib.call('csmri_undersample', img.data_ptr(), mask_u8.contiguous().data_ptr(), ks.data_ptr(), inp.data_ptr(),
            b, h, w, stream())
   return ks, inp
+
+
+def fft2(x, inverse=False, ortho=True):
+  """Batched 2-D FFT of interleaved complex fp32 [B,H,W,2] (reference Fft2d / Ifft2d, myfft.py:78-128)."""
+  _need_gpu(x)
+  x = x.contiguous()
+  assert x.dtype == torch.float32 and x.shape[-1] == 2
+  b, h, w, _ = x.shape
+  out = torch.empty_like(x)
+  lib.call('csmri_fft2', x.data_ptr(), out.data_ptr(), b, h, w, int(inverse), int(ortho), stream())
+  return out
+
+
+class Fft2d(torch.autograd.Function):
+  """orthoFFT2 with the adjoint as backward (myfft.py:78-102: grad_x = orthoIFFT2(grad_k))."""
+
+  @staticmethod
+  def forward(ctx, x, inverse=False):
+    ctx.inverse = inverse
+    return fft2(x, inverse, True)
+
+  @staticmethod
+  def backward(ctx, g):
+    return fft2(g.contiguous(), not ctx.inverse, True), None
 
 
 def dc_raw(x, k0, mask_u8, pad_dtype=None):

@@ -1,172 +1,349 @@
-// csmri_dc: k-space data consistency = batched 2-D complex FFT + mask merge +
-// inverse FFT, fp32, interleaved complex (float2) layout.
+// csmri_dc: k-space data consistency = batched 2-D complex FFT + mask merge + inverse FFT, fp32,
+// interleaved complex (float2) layout.
 //
 //   out = orthoIFFT2( (1 - m) * orthoFFT2(x) + k0 )          myfft.py:131-163
 //
-// A 256x256 complex fp32 slice is 512 KiB and does not fit one CU's 160 KiB LDS,
-// so the transform is decomposed into three HBM passes, each of which keeps a
-// tile of 16 independent 1-D transforms in LDS:
-//   pass 1  row FFTs                 (16 rows per workgroup, coalesced 2 KiB rows)
-//   pass 2  per 16-column strip: column FFT -> ortho scale -> (1-m)*k + k0 ->
-//           column inverse FFT; the merged k-space never touches HBM
-//   pass 3  row inverse FFTs + ortho scale (+ optional channel-padded copy that
-//           is the next conv block's input)
-// The passes run in place on `out`, so the traffic is 7 x B*H*W*8 bytes
-// (x, k0 reads; mask bytes; 3 writes + 2 re-reads of the intermediate).
-// 1-D transform: Stockham autosort, radix-4 stages (+ one radix-2 stage for odd
-// log2 N), twiddles from an LDS table built with sincospif at kernel start.
+// A 256x256 complex fp32 slice is 512 KiB and does not fit one CU's 160 KiB LDS, so the transform is three
+// HBM passes (the intermediate stays in L2 / Infinity Cache between them):
+//   pass 1  row FFTs: ONE WAVE PER ROW, the whole 1-D transform in registers -- no LDS, no barrier
+//   pass 2  per strip of 8 columns (64-byte row segments, coalesced): column FFT -> ortho scale ->
+//           (1-m)*k + k0 -> column inverse FFT, one wave per column out of an LDS image of the strip; the
+//           merged k-space never touches HBM
+//   pass 3  row inverse FFTs (wave per row) + ortho scale (+ the channel-padded copy that is the next conv
+//           block's input)
+// The passes run in place on `out`: algorithmic traffic 3 x B*H*W*8 B + mask, moved 7 x B*H*W*8 B.
+//
+// 1-D transform of N = L*R points in one wave (L = 64 lanes, R = N/64 values per lane; N = 32: two
+// transforms per wave on its half-waves): lane l holds points l + L*q.  FORWARD = radix-2 decimation in
+// frequency: the spans >= L pair REGISTERS of a lane, the spans < L pair LANES through wave shuffles
+// (xor 32, 16, .. 1: ds_bpermute / DPP, no LDS memory).  Its output is bit-reversed: lane l then holds the R
+// CONSECUTIVE frequencies R*rev(l) + rev(q), which it stores as one contiguous run -- HBM keeps the natural
+// order and every 64-byte sector is written whole.  INVERSE = decimation in time, which consumes exactly that
+// bit-reversed register arrangement (lane l loads its R consecutive inputs) and ends in natural order, lane-
+// contiguous.  So the pair FFT -> iFFT needs no reordering anywhere, and in pass 2 the merge runs on the
+// registers between the two.  Twiddles: a 512-entry table of exp(-2 pi i k / 512) built at COMPILE time
+// (constexpr, double precision, rounded once), each lane keeps its <= 8 factors in registers.
 #include "common.h"
 
-#define DC_T 16           // independent transforms per tile
-#define DC_TP (DC_T + 1)  // LDS pitch (bank-conflict padding)
-#define DC_THREADS 256
+// ---- compile-time twiddle table ------------------------------------------------------------------------
+struct cf2 { float x, y; };
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double cx_sin_small(double x) {     // |x| <= pi/4: Taylor, error < 1e-17
+  double x2 = x * x, term = x, sum = x;
+  for (int k = 1; k < 12; ++k) { term *= -x2 / ((2 * k) * (2 * k + 1)); sum += term; }
+  return sum;
+}
+constexpr double cx_cos_small(double x) {
+  double x2 = x * x, term = 1.0, sum = 1.0;
+  for (int k = 1; k < 12; ++k) { term *= -x2 / ((2 * k - 1) * (2 * k)); sum += term; }
+  return sum;
+}
+constexpr double cx_cos_turn(int k, int n) {   // cos(2 pi k / n), octant reduction keeps the argument <= pi/4
+  k = ((k % n) + n) % n;
+  if (8 * k <= n) return cx_cos_small(2.0 * kPi * k / n);
+  if (8 * k <= 3 * n) return cx_sin_small(kPi / 2 - 2.0 * kPi * k / n);
+  if (8 * k <= 5 * n) return -cx_cos_small(kPi - 2.0 * kPi * k / n);
+  if (8 * k <= 7 * n) return cx_sin_small(2.0 * kPi * k / n - 3 * kPi / 2);
+  return cx_cos_small(2.0 * kPi - 2.0 * kPi * k / n);
+}
+constexpr double cx_sin_turn(int k, int n) { return cx_cos_turn(4 * k - n, 4 * n); }   // sin(t) = cos(t - pi/2)
+struct TwTable { cf2 v[512]; };
+constexpr TwTable make_tw() {
+  TwTable t{};
+  for (int k = 0; k < 512; ++k) { t.v[k].x = (float)cx_cos_turn(k, 512); t.v[k].y = (float)(-cx_sin_turn(k, 512)); }
+  return t;
+}
+__device__ const TwTable g_tw512 = make_tw();      // exp(-2 pi i k / 512)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {      // a * conj(b)
+  return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float2 tw512(int idx) { const cf2 t = g_tw512.v[idx & 511]; return make_float2(t.x, t.y); }
 
-// In-LDS FFT of DC_T interleaved transforms of length N.  Data layout a[n*DC_TP + t].
-// sign = -1 forward, +1 inverse (unnormalised).  Returns the buffer holding the result.
-__device__ float2* fft_tile(float2* a, float2* b, const float2* tw, int N, int sign, int tid) {
-  int Ns = 1;
-  while (Ns < N) {
-    const int rem = N / Ns;
-    if ((rem & 3) == 0) {
-      const int nb = N >> 2, tstep = N / (Ns * 4);
-      for (int idx = tid; idx < nb * DC_T; idx += DC_THREADS) {
-        const int col = idx % DC_T, j = idx / DC_T;
-        const int k = j & (Ns - 1);
-        float2 v0 = a[j * DC_TP + col];
-        float2 v1 = a[(j + nb) * DC_TP + col];
-        float2 v2 = a[(j + 2 * nb) * DC_TP + col];
-        float2 v3 = a[(j + 3 * nb) * DC_TP + col];
-        if (k) {
-          float2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
-          if (sign > 0) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
-          v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
-        }
-        float2 t0 = make_float2(v0.x + v2.x, v0.y + v2.y);
-        float2 t1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-        float2 t2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-        float2 d = make_float2(v1.x - v3.x, v1.y - v3.y);
-        // (v1 - v3) * (sign * i)
-        float2 t3 = sign < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
-        const int j0 = (j - k) * 4 + k;
-        b[j0 * DC_TP + col] = make_float2(t0.x + t2.x, t0.y + t2.y);
-        b[(j0 + Ns) * DC_TP + col] = make_float2(t1.x + t3.x, t1.y + t3.y);
-        b[(j0 + 2 * Ns) * DC_TP + col] = make_float2(t0.x - t2.x, t0.y - t2.y);
-        b[(j0 + 3 * Ns) * DC_TP + col] = make_float2(t1.x - t3.x, t1.y - t3.y);
-      }
-      Ns *= 4;
-    } else {
-      const int nb = N >> 1, tstep = N / (Ns * 2);
-      for (int idx = tid; idx < nb * DC_T; idx += DC_THREADS) {
-        const int col = idx % DC_T, j = idx / DC_T;
-        const int k = j & (Ns - 1);
-        float2 v0 = a[j * DC_TP + col];
-        float2 v1 = a[(j + nb) * DC_TP + col];
-        if (k) {
-          float2 w1 = tw[k * tstep];
-          if (sign > 0) w1.y = -w1.y;
-          v1 = cmul(v1, w1);
-        }
-        const int j0 = (j - k) * 2 + k;
-        b[j0 * DC_TP + col] = make_float2(v0.x + v1.x, v0.y + v1.y);
-        b[(j0 + Ns) * DC_TP + col] = make_float2(v0.x - v1.x, v0.y - v1.y);
-      }
-      Ns *= 2;
+template <int LOGN> struct FftCfg {
+  static constexpr int N = 1 << LOGN, LOGL = LOGN < 6 ? LOGN : 6, L = 1 << LOGL, R = N / L, LOGR = LOGN - LOGL;
+  static constexpr int TPW = 64 / L;             // transforms per wave
+};
+
+// the lane's twiddle factors: reg[t] for the register-level span N >> t, lane[s] for the lane-level span L >> s
+template <int LOGN> struct LaneTw {
+  float2 reg[FftCfg<LOGN>::LOGR > 0 ? FftCfg<LOGN>::LOGR : 1];
+  float2 lane[FftCfg<LOGN>::LOGL];
+  __device__ __forceinline__ void init(int l) {
+    typedef FftCfg<LOGN> C;
+#pragma unroll
+    for (int t = 0; t < C::LOGR; ++t) reg[t] = tw512((l << t) * (512 / C::N));            // w_{N >> t}^l
+#pragma unroll
+    for (int s = 0; s < C::LOGL; ++s) {
+      const int half = C::L >> (s + 1);
+      lane[s] = tw512((l & (half - 1)) * (256 / (half > 0 ? half : 1)));                     // w_{2 half}^(l mod half)
     }
-    __syncthreads();
-    float2* t = a; a = b; b = t;
   }
-  return a;
-}
+};
 
-__device__ __forceinline__ void build_twiddles(float2* tw, int N, int tid) {
-  for (int i = tid; i < N; i += DC_THREADS) {
-    float s, c;
-    sincospif(2.0f * (float)i / (float)N, &s, &c);
-    tw[i] = make_float2(c, -s);     // exp(-2 pi i k / N)
-  }
+__device__ __forceinline__ int rev_bits(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
+template <int LOGR> __host__ __device__ constexpr int rev_const(int q) {
+  int r = 0;
+  for (int i = 0; i < LOGR; ++i) r |= ((q >> i) & 1) << (LOGR - 1 - i);
+  return r;
 }
+// exp(-2 pi i j / h2) for the register-level stages (compile-time after unrolling)
+__device__ __forceinline__ float2 reg_const_tw(int j, int h2) { return tw512(j * (512 / h2)); }
 
-// passes 1 and 3: FFT along W for DC_T rows per workgroup.
-__global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(
-    const float* src, int src_ps, float2* dst, void* out_pad, int out_pad_dt,
-    int W, int sign, float scale) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float2* a = (float2*)smem;
-  float2* b = a + W * DC_TP;
-  float2* tw = b + W * DC_TP;
-  const int tid = threadIdx.x;
-  const size_t row0 = (size_t)blockIdx.x * DC_T;
-  build_twiddles(tw, W, tid);
-  for (int idx = tid; idx < DC_T * W; idx += DC_THREADS) {
-    const int r = idx / W, n = idx - r * W;
-    a[n * DC_TP + r] = *(const float2*)(src + ((row0 + r) * W + n) * (size_t)src_ps);
+// forward (decimation in frequency), natural input v[q] = x[l + L q] -> bit-reversed output
+template <int LOGN>
+__device__ __forceinline__ void fft_dif(float2 (&v)[FftCfg<LOGN>::R], const LaneTw<LOGN>& tw, int lane) {
+  typedef FftCfg<LOGN> C;
+#pragma unroll
+  for (int t = 0; t < C::LOGR; ++t) {
+    const int h = C::R >> (t + 1);                 // register distance of the pair
+#pragma unroll
+    for (int q = 0; q < C::R; ++q) {
+      if (q & h) continue;
+      const float2 a = v[q], b = v[q + h];
+      v[q] = make_float2(a.x + b.x, a.y + b.y);
+      float2 d = make_float2(a.x - b.x, a.y - b.y);
+      d = cmul(d, tw.reg[t]);
+      const int j = q & (h - 1);
+      if (j) d = cmul(d, reg_const_tw(j, 2 * h));
+      v[q + h] = d;
+    }
   }
-  __syncthreads();
-  float2* res = fft_tile(a, b, tw, W, sign, tid);
-  for (int idx = tid; idx < DC_T * W; idx += DC_THREADS) {
-    const int r = idx / W, n = idx - r * W;
-    float2 v = res[n * DC_TP + r];
-    v.x *= scale; v.y *= scale;
-    const size_t o = (row0 + r) * W + n;
-    dst[o] = v;
-    if (out_pad) {
-      if (out_pad_dt == CSMRI_F32) {
-        f32x4_t lo = (f32x4_t){v.x, v.y, 0.f, 0.f}, z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        f32x4_t* pp = (f32x4_t*)out_pad + o * 2;
-        pp[0] = lo; pp[1] = z;
+#pragma unroll
+  for (int s = 0; s < C::LOGL; ++s) {
+    const int half = C::L >> (s + 1);
+    const bool upper = (lane & half) != 0;
+#pragma unroll
+    for (int q = 0; q < C::R; ++q) {
+      const float px = __shfl_xor(v[q].x, half), py = __shfl_xor(v[q].y, half);
+      if (upper) {
+        const float2 d = make_float2(px - v[q].x, py - v[q].y);
+        v[q] = half > 1 ? cmul(d, tw.lane[s]) : d;
       } else {
-        u32x4_t q = (u32x4_t){(unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16), 0u, 0u, 0u};
-        ((u32x4_t*)out_pad)[o] = q;
+        v[q] = make_float2(v[q].x + px, v[q].y + py);
       }
     }
   }
 }
 
-// pass 2: per strip of DC_T columns: FFT along H, merge, inverse FFT along H.
-__global__ __launch_bounds__(DC_THREADS) void dc_cols_kernel(
-    float2* __restrict__ data, const float2* __restrict__ k0, const uint8_t* __restrict__ mask,
-    int H, int W, float scale, float2* __restrict__ kout, int keep_sampled) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float2* a = (float2*)smem;
-  float2* b = a + H * DC_TP;
-  float2* tw = b + H * DC_TP;
-  const int tid = threadIdx.x;
-  const int strips = W / DC_T;
-  const int img = blockIdx.x / strips, c0 = (blockIdx.x - img * strips) * DC_T;
-  const size_t base = (size_t)img * H * W + c0;
-  build_twiddles(tw, H, tid);
-  for (int idx = tid; idx < DC_T * H; idx += DC_THREADS) {
-    const int h = idx / DC_T, c = idx - h * DC_T;
-    a[h * DC_TP + c] = data[base + (size_t)h * W + c];
+// inverse (decimation in time, conjugated twiddles), bit-reversed input -> natural output v[q] = y[l + L q]
+template <int LOGN>
+__device__ __forceinline__ void fft_dit_inv(float2 (&v)[FftCfg<LOGN>::R], const LaneTw<LOGN>& tw, int lane) {
+  typedef FftCfg<LOGN> C;
+#pragma unroll
+  for (int s = C::LOGL - 1; s >= 0; --s) {
+    const int half = C::L >> (s + 1);
+    const bool upper = (lane & half) != 0;
+#pragma unroll
+    for (int q = 0; q < C::R; ++q) {
+      // both lanes of a pair need conj(w) * b, b = the upper lane's value
+      const float2 wb = half > 1 ? cmulc(v[q], tw.lane[s]) : v[q];
+      const float2 mine = upper ? wb : v[q];
+      const float px = __shfl_xor(mine.x, half), py = __shfl_xor(mine.y, half);
+      v[q] = upper ? make_float2(px - wb.x, py - wb.y) : make_float2(v[q].x + px, v[q].y + py);
+    }
   }
-  __syncthreads();
-  float2* res = fft_tile(a, b, tw, H, -1, tid);
-  for (int idx = tid; idx < DC_T * H; idx += DC_THREADS) {
-    const int h = idx / DC_T, c = idx - h * DC_T;
-    const size_t o = base + (size_t)h * W + c;
-    float2 k = res[h * DC_TP + c];
-    k.x *= scale; k.y *= scale;
-    // (1 - m) * k + k0 with m in {0,1}: bit-exact integer mask test
-    // keep_sampled (forward model, csmri_undersample): m * k instead, and the k-space is an output
-    float2 v = (mask[o] != 0) == (keep_sampled != 0) ? k : make_float2(0.f, 0.f);
-    if (k0) { float2 q = k0[o]; v.x += q.x; v.y += q.y; }
-    if (kout) kout[o] = v;
-    res[h * DC_TP + c] = v;
-  }
-  __syncthreads();
-  float2* other = (res == a) ? b : a;
-  float2* r2 = fft_tile(res, other, tw, H, +1, tid);
-  for (int idx = tid; idx < DC_T * H; idx += DC_THREADS) {
-    const int h = idx / DC_T, c = idx - h * DC_T;
-    data[base + (size_t)h * W + c] = r2[h * DC_TP + c];
+#pragma unroll
+  for (int t = C::LOGR - 1; t >= 0; --t) {
+    const int h = C::R >> (t + 1);
+#pragma unroll
+    for (int q = 0; q < C::R; ++q) {
+      if (q & h) continue;
+      float2 b = cmulc(v[q + h], tw.reg[t]);
+      const int j = q & (h - 1);
+      if (j) b = cmulc(b, reg_const_tw(j, 2 * h));
+      const float2 a = v[q];
+      v[q] = make_float2(a.x + b.x, a.y + b.y);
+      v[q + h] = make_float2(a.x - b.x, a.y - b.y);
+    }
   }
 }
 
-static bool is_pow2_in_range(int n) { return n >= 32 && n <= 512 && (n & (n - 1)) == 0; }
+#define DC_THREADS 256
+#define DC_STRIP 8                   // columns per workgroup in pass 2 (64-byte row segments)
+#define DC_PITCH (DC_STRIP + 1)      // float2 pitch of the LDS strip image (conflict-free column reads)
+
+// passes 1 and 3 (and the row halves of csmri_fft2): 1-D transforms along W, one per wave (two for W = 32).
+//   INV = false: src natural order with pixel stride src_ps floats -> dst natural order (dense)
+//   INV = true : src dense natural order -> dst dense natural order (+ optional channel-padded copy), x scale
+template <int LOGN, bool INV>
+__global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const float* __restrict__ src, int src_ps,
+                                                             float2* __restrict__ dst, void* out_pad, int out_pad_dt,
+                                                             int rows, float scale) {
+  typedef FftCfg<LOGN> C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l = lane & (C::L - 1);
+  int row = (blockIdx.x * (DC_THREADS / 64) + wave) * C::TPW + (lane >> C::LOGL);
+  const bool live = row < rows;                       // shuffles need every lane: dead rows compute on row 0
+  if (!live) row = 0;
+  LaneTw<LOGN> tw;
+  tw.init(l);
+  float2 v[C::R];
+  const size_t base = (size_t)row * C::N;
+  const int kbase = C::R * rev_bits(l, C::LOGL);      // first of the lane's R consecutive frequencies
+  if (!INV) {
+#pragma unroll
+    for (int q = 0; q < C::R; ++q) v[q] = *(const float2*)(src + (base + l + C::L * q) * (size_t)src_ps);
+    fft_dif<LOGN>(v, tw, lane);
+    if (!live) return;
+#pragma unroll
+    for (int q = 0; q < C::R; ++q) {
+      float2 o = v[q];
+      o.x *= scale; o.y *= scale;
+      dst[base + kbase + rev_const<C::LOGR>(q)] = o;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < C::R; ++q) v[q] = *(const float2*)(src + (base + kbase + rev_const<C::LOGR>(q)) * (size_t)src_ps);
+    fft_dit_inv<LOGN>(v, tw, lane);
+    if (!live) return;
+#pragma unroll
+    for (int q = 0; q < C::R; ++q) {
+      float2 o = v[q];
+      o.x *= scale; o.y *= scale;
+      const size_t p = base + l + C::L * q;
+      dst[p] = o;
+      if (out_pad) {
+        if (out_pad_dt == CSMRI_F32) {
+          f32x4_t* pp = (f32x4_t*)out_pad + p * 2;
+          pp[0] = (f32x4_t){o.x, o.y, 0.f, 0.f}; pp[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        } else {
+          ((u32x4_t*)out_pad)[p] = (u32x4_t){(unsigned)f32_to_bf16_bits(o.x) | ((unsigned)f32_to_bf16_bits(o.y) << 16), 0u, 0u, 0u};
+        }
+      }
+    }
+  }
+}
+
+// pass 2: a strip of DC_STRIP columns of one image.
+//   MODE 0  FFT along H -> x scale -> mask merge (+ k0) -> inverse FFT along H   (csmri_dc / csmri_undersample)
+//   MODE 1  FFT along H only (x scale), natural order out                        (csmri_fft2 forward)
+//   MODE 2  inverse FFT along H only (x scale)                                   (csmri_fft2 inverse)
+template <int LOGN, int MODE>
+__global__ __launch_bounds__(DC_THREADS) void dc_cols_kernel(float2* __restrict__ data, const float2* __restrict__ k0,
+                                                             const uint8_t* __restrict__ mask, int W, float scale,
+                                                             float2* __restrict__ kout, int keep_sampled) {
+  typedef FftCfg<LOGN> C;
+  constexpr int H = C::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* A = (float2*)smem;                       // [H][DC_PITCH]
+  float2* K = A + H * DC_PITCH;                    // [H][DC_PITCH]  k0 strip, then the merged k-space (kout)
+  uint8_t* M = (uint8_t*)(K + H * DC_PITCH);       // [H][DC_STRIP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int strips = W / DC_STRIP;
+  const int img = blockIdx.x / strips, c0 = (blockIdx.x - img * strips) * DC_STRIP;
+  const size_t base = (size_t)img * H * W + c0;
+  for (int idx = tid; idx < H * DC_STRIP; idx += DC_THREADS) {
+    const int h = idx / DC_STRIP, c = idx - h * DC_STRIP;
+    const size_t o = base + (size_t)h * W + c;
+    A[h * DC_PITCH + c] = data[o];
+    if (MODE == 0) {
+      if (k0) K[h * DC_PITCH + c] = k0[o];
+      M[h * DC_STRIP + c] = mask[o];
+    }
+  }
+  __syncthreads();
+  const int l = lane & (C::L - 1);
+  LaneTw<LOGN> tw;
+  tw.init(l);
+  const int kbase = C::R * rev_bits(l, C::LOGL);
+  constexpr int COLS_PER_WAVE = DC_STRIP / (DC_THREADS / 64);       // 2
+#pragma unroll 1
+  for (int cc = 0; cc < COLS_PER_WAVE; cc += C::TPW) {
+    const int c = wave * COLS_PER_WAVE + cc + (lane >> C::LOGL);
+    float2 v[C::R];
+    if (MODE != 2) {
+#pragma unroll
+      for (int q = 0; q < C::R; ++q) v[q] = A[(l + C::L * q) * DC_PITCH + c];
+      fft_dif<LOGN>(v, tw, lane);
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int q = 0; q < C::R; ++q) {
+        const int ky = kbase + rev_const<C::LOGR>(q);
+        float2 k = v[q];
+        k.x *= scale; k.y *= scale;
+        // (1 - m) * k + k0 with m in {0,1}: bit-exact integer mask test; keep_sampled (forward model): m * k
+        float2 o = (M[ky * DC_STRIP + c] != 0) == (keep_sampled != 0) ? k : make_float2(0.f, 0.f);
+        if (k0) { const float2 z = K[ky * DC_PITCH + c]; o.x += z.x; o.y += z.y; }
+        if (kout) K[ky * DC_PITCH + c] = o;
+        v[q] = o;
+      }
+    } else if (MODE == 1) {
+#pragma unroll
+      for (int q = 0; q < C::R; ++q)
+        A[(kbase + rev_const<C::LOGR>(q)) * DC_PITCH + c] = make_float2(v[q].x * scale, v[q].y * scale);
+    } else {
+#pragma unroll
+      for (int q = 0; q < C::R; ++q) v[q] = A[(kbase + rev_const<C::LOGR>(q)) * DC_PITCH + c];
+    }
+    if (MODE != 1) {
+      fft_dit_inv<LOGN>(v, tw, lane);
+      const float s2 = MODE == 2 ? scale : 1.f;
+#pragma unroll
+      for (int q = 0; q < C::R; ++q) A[(l + C::L * q) * DC_PITCH + c] = make_float2(v[q].x * s2, v[q].y * s2);
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < H * DC_STRIP; idx += DC_THREADS) {
+    const int h = idx / DC_STRIP, c = idx - h * DC_STRIP;
+    const size_t o = base + (size_t)h * W + c;
+    data[o] = A[h * DC_PITCH + c];
+    if (MODE == 0 && kout) kout[o] = K[h * DC_PITCH + c];
+  }
+}
+
+static int log2_in_range(int n) {
+  for (int s = 5; s <= 9; ++s) if (n == (1 << s)) return s;
+  return -1;
+}
+
+template <int LOGN, bool INV>
+static int launch_rows(const float* src, int src_ps, float2* dst, void* out_pad, int out_pad_dt, int rows,
+                       float scale, hipStream_t st) {
+  constexpr int per_wg = (DC_THREADS / 64) * FftCfg<LOGN>::TPW;
+  hipLaunchKernelGGL((dc_rows_kernel<LOGN, INV>), dim3(cdiv(rows, per_wg)), dim3(DC_THREADS), 0, st,
+                     src, src_ps, dst, out_pad, out_pad_dt, rows, scale);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+static int rows_pass(int logw, bool inv, const float* src, int src_ps, float2* dst, void* out_pad, int out_pad_dt,
+                     int rows, float scale, hipStream_t st) {
+#define ROWS(LW) (inv ? launch_rows<LW, true>(src, src_ps, dst, out_pad, out_pad_dt, rows, scale, st) \
+                      : launch_rows<LW, false>(src, src_ps, dst, out_pad, out_pad_dt, rows, scale, st))
+  switch (logw) {
+    case 5: return ROWS(5); case 6: return ROWS(6); case 7: return ROWS(7); case 8: return ROWS(8); case 9: return ROWS(9);
+  }
+#undef ROWS
+  return CSMRI_E_UNSUPPORTED;
+}
+
+template <int LOGN, int MODE>
+static int launch_cols(float2* data, const float2* k0, const uint8_t* mask, int B, int W, float scale,
+                       float2* kout, int keep, hipStream_t st) {
+  constexpr int H = 1 << LOGN;
+  constexpr int lds = 2 * H * DC_PITCH * (int)sizeof(float2) + H * DC_STRIP;
+  CSMRI_SET_MAX_LDS((dc_cols_kernel<LOGN, MODE>), lds);
+  hipLaunchKernelGGL((dc_cols_kernel<LOGN, MODE>), dim3(B * (W / DC_STRIP)), dim3(DC_THREADS), lds, st,
+                     data, k0, mask, W, scale, kout, keep);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+template <int MODE>
+static int cols_pass(int logh, float2* data, const float2* k0, const uint8_t* mask, int B, int W, float scale,
+                     float2* kout, int keep, hipStream_t st) {
+  switch (logh) {
+    case 5: return launch_cols<5, MODE>(data, k0, mask, B, W, scale, kout, keep, st);
+    case 6: return launch_cols<6, MODE>(data, k0, mask, B, W, scale, kout, keep, st);
+    case 7: return launch_cols<7, MODE>(data, k0, mask, B, W, scale, kout, keep, st);
+    case 8: return launch_cols<8, MODE>(data, k0, mask, B, W, scale, kout, keep, st);
+    case 9: return launch_cols<9, MODE>(data, k0, mask, B, W, scale, kout, keep, st);
+  }
+  return CSMRI_E_UNSUPPORTED;
+}
 
 extern "C" size_t csmri_dc_work_bytes(int B, int H, int W) {
   (void)B; (void)H; (void)W;
@@ -178,25 +355,16 @@ extern "C" int csmri_dc(const float* x, int x_pix_stride, const float* k0, const
                         int W, void* stream) {
   (void)work;
   CSMRI_CHECK_ARG(x && mask && out && B > 0 && x_pix_stride >= 2 && x_pix_stride % 2 == 0);
-  if (!is_pow2_in_range(H) || !is_pow2_in_range(W)) return CSMRI_E_UNSUPPORTED;
+  const int lh = log2_in_range(H), lw = log2_in_range(W);
+  if (lh < 0 || lw < 0) return CSMRI_E_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)k0 | (uintptr_t)out_pad) & 15) return CSMRI_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const float scale = 1.0f / sqrtf((float)H * (float)W);
-  const int lds_rows = (2 * W * DC_TP + W) * (int)sizeof(float2);
-  const int lds_cols = (2 * H * DC_TP + H) * (int)sizeof(float2);
-  CSMRI_SET_MAX_LDS(dc_rows_kernel, lds_rows);
-  CSMRI_SET_MAX_LDS(dc_cols_kernel, lds_cols);
-  const int row_blocks = B * H / DC_T, col_blocks = B * (W / DC_T);
-  hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
-                     x, x_pix_stride, (float2*)out, (void*)nullptr, 0, W, -1, 1.0f);
-  CSMRI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dc_cols_kernel, dim3(col_blocks), dim3(DC_THREADS), lds_cols, st,
-                     (float2*)out, (const float2*)k0, mask, H, W, scale, (float2*)nullptr, 0);
-  CSMRI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
-                     (const float*)out, 2, (float2*)out, out_pad, out_pad_dtype, W, +1, scale);
-  CSMRI_LAUNCH_CHECK();
-  return CSMRI_OK;
+  int rc = rows_pass(lw, false, x, x_pix_stride, (float2*)out, nullptr, 0, B * H, 1.0f, st);
+  if (rc != CSMRI_OK) return rc;
+  rc = cols_pass<0>(lh, (float2*)out, (const float2*)k0, mask, B, W, scale, nullptr, 0, st);
+  if (rc != CSMRI_OK) return rc;
+  return rows_pass(lw, true, out, 2, (float2*)out, out_pad, out_pad_dtype, B * H, scale, st);
 }
 
 // The forward model that produces a training sample from a (complex) image, on the device:
@@ -207,23 +375,31 @@ extern "C" int csmri_dc(const float* x, int x_pix_stride, const float* k0, const
 extern "C" int csmri_undersample(const float* img, const uint8_t* mask, float* kspace, float* inp, int B, int H,
                                  int W, void* stream) {
   CSMRI_CHECK_ARG(img && mask && kspace && inp && B > 0);
-  if (!is_pow2_in_range(H) || !is_pow2_in_range(W)) return CSMRI_E_UNSUPPORTED;
+  const int lh = log2_in_range(H), lw = log2_in_range(W);
+  if (lh < 0 || lw < 0) return CSMRI_E_UNSUPPORTED;
   if (((uintptr_t)img | (uintptr_t)kspace | (uintptr_t)inp) & 15) return CSMRI_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const float scale = 1.0f / sqrtf((float)H * (float)W);
-  const int lds_rows = (2 * W * DC_TP + W) * (int)sizeof(float2);
-  const int lds_cols = (2 * H * DC_TP + H) * (int)sizeof(float2);
-  CSMRI_SET_MAX_LDS(dc_rows_kernel, lds_rows);
-  CSMRI_SET_MAX_LDS(dc_cols_kernel, lds_cols);
-  const int row_blocks = B * H / DC_T, col_blocks = B * (W / DC_T);
-  hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
-                     img, 2, (float2*)inp, (void*)nullptr, 0, W, -1, 1.0f);
-  CSMRI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dc_cols_kernel, dim3(col_blocks), dim3(DC_THREADS), lds_cols, st,
-                     (float2*)inp, (const float2*)nullptr, mask, H, W, scale, (float2*)kspace, 1);
-  CSMRI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dc_rows_kernel, dim3(row_blocks), dim3(DC_THREADS), lds_rows, st,
-                     (const float*)inp, 2, (float2*)inp, (void*)nullptr, 0, W, +1, scale);
-  CSMRI_LAUNCH_CHECK();
-  return CSMRI_OK;
+  int rc = rows_pass(lw, false, img, 2, (float2*)inp, nullptr, 0, B * H, 1.0f, st);
+  if (rc != CSMRI_OK) return rc;
+  rc = cols_pass<0>(lh, (float2*)inp, nullptr, mask, B, W, scale, (float2*)kspace, 1, st);
+  if (rc != CSMRI_OK) return rc;
+  return rows_pass(lw, true, inp, 2, (float2*)inp, nullptr, 0, B * H, scale, st);
+}
+
+// Stand-alone batched 2-D FFT / inverse FFT of interleaved complex fp32 images: the operation behind the
+// reference's Fft2d / Ifft2d Functions (myfft.py:78-128), whose backward passes are the same transforms in
+// the other direction (myfft.py:92-102,119-128).  ortho != 0: both directions scaled by 1/sqrt(HW) (the
+// reference's normalized=True); ortho == 0: forward unscaled, inverse scaled by 1/(HW) (pytorch_fft).
+extern "C" int csmri_fft2(const float* x, float* out, int B, int H, int W, int inverse, int ortho, void* stream) {
+  CSMRI_CHECK_ARG(x && out && B > 0);
+  const int lh = log2_in_range(H), lw = log2_in_range(W);
+  if (lh < 0 || lw < 0) return CSMRI_E_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)out) & 15) return CSMRI_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = ortho ? 1.0f / sqrtf((float)H * (float)W) : (inverse ? 1.0f / ((float)H * (float)W) : 1.0f);
+  int rc = rows_pass(lw, inverse != 0, x, 2, (float2*)out, nullptr, 0, B * H, 1.0f, st);
+  if (rc != CSMRI_OK) return rc;
+  return inverse ? cols_pass<2>(lh, (float2*)out, nullptr, nullptr, B, W, scale, nullptr, 0, st)
+                 : cols_pass<1>(lh, (float2*)out, nullptr, nullptr, B, W, scale, nullptr, 0, st);
 }

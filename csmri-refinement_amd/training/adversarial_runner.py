@@ -133,6 +133,12 @@ class AdversarialRunner(BaseRunner):
       gen_optimizer.pack_groups = lambda: trainable_pack_groups(self.gen)
     if self._group_epochs and disc_optimizer is not None and hasattr(disc_optimizer, 'pack_groups'):
       disc_optimizer.pack_groups = lambda: trainable_pack_groups(self.disc)
+    if dist_utils.world_size() > 1 and gen_optimizer is not None and disc_optimizer is not None:
+      # data parallelism: a sub-bucket of gradients leaves as soon as the backward has issued its last layer
+      def _ready(layer, opts=(disc_optimizer, gen_optimizer)):
+        for o in opts:
+          o.grad_ready(layer)
+      ops.GRAD_READY_HOOK = _ready
     self.train_gen_metric_fns = train_gen_metric_fns or {}
     self.train_disc_metric_fns = train_disc_metric_fns or {}
     self.val_metric_fns = val_metric_fns or {}

@@ -1,13 +1,14 @@
-"""Data parallelism: one process per GPU, gradients exchanged as ONE flat fp32
-bucket per model over RCCL (torch.distributed backend 'nccl' on ROCm).
+"""Data parallelism: one process per GPU, gradients exchanged over RCCL (torch.distributed backend
+'nccl' on ROCm) out of each model's flat fp32 gradient buffer, in sub-buckets, as bf16.
 
 The reference's only parallelism is single-process nn.DataParallel
 (utils/custom_data_parallel.py:6-35, utils/__init__.py:59-68): parameters are
 re-broadcast every forward and gradients reduced to GPU 0.  Here every rank holds
-replicas, each step moves exactly sum(numel) gradient elements once (all-reduce of
-the flat gradient buffer, divided by world size inside the fused Adam kernel), and
-the discriminator bucket is launched asynchronously right after the discriminator
-backward so it overlaps the generator-side forward work.  BatchNorm statistics,
+replicas and each step moves every gradient element once as bf16 (GradBucket: direct
+all-to-all + fp32 accumulation on the owning rank + all-gather; the mean's 1/N is folded into the
+fused Adam kernel).  The discriminator's deep layers (convs.17/22: 90 % of its 27.9 M elements)
+finish first in its backward and their sub-bucket leaves while the shallow layers are still
+being differentiated; the rest overlaps the generator-side forward work.  BatchNorm statistics,
 dropout masks and the image pool stay per rank."""
 import os
 
@@ -56,22 +57,120 @@ def shard_batch(batch, r=None, n=None):
   return out
 
 
+def _backend():
+  return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
 class GradBucket(object):
-  """Asynchronous sum all-reduce of one flat gradient buffer."""
+  """Gradient exchange of one model: its flat fp32 gradient buffer, cut into SUB-BUCKETS (contiguous element
+  ranges, listed in the order the backward finishes them) that are exchanged independently so the first ones
+  travel while the backward still computes the rest.
 
-  def __init__(self, flat_grad):
+  Transport per sub-bucket (``payload``):
+    'bf16'  (default with more than one rank) reduce-scatter + all-gather written out over the DIRECT
+            collectives: cast the range to bf16, all_to_all the N chunks (every pair of GPUs talks over its own
+            xGMI link: all 7 links of an MI355X carry 1/8 of the bytes each, where a ring would push everything
+            over one link per direction), SUM THE N RECEIVED bf16 CHUNKS IN fp32 on the owning rank, round once,
+            all_gather the reduced chunks, widen back into the fp32 buffer.  Half the bytes of an fp32
+            all-reduce, and no rank-count-dependent chain of bf16 roundings: every element is
+            bf16(sum_r bf16(g_r)) with the sum carried in fp32.
+    'fp32'  dist.all_reduce on the range (exact sums; CSMRI_GRAD_PAYLOAD=fp32).
+  All device work of an exchange runs on a communication stream behind an event recorded when start() is
+  called; wait() only makes the caller's stream wait for the exchanges' end events (the host never blocks
+  on the nccl backend).  The 1/N of the mean is returned by wait() and folded into the fused Adam kernel."""
+
+  def __init__(self, flat_grad, splits=None, payload=None):
     self.flat = flat_grad
-    self.work = None
+    n = flat_grad.numel()
+    self.splits = [(0, n)] if not splits else [(int(a), int(b)) for a, b in splits]
+    assert self.splits[0][0] >= 0 and all(a < b for a, b in self.splits)
+    assert sorted(self.splits) == sorted(set(self.splits)) and \
+        sum(b - a for a, b in self.splits) == n and min(a for a, _ in self.splits) == 0 and \
+        max(b for _, b in self.splits) == n, 'sub-buckets must tile the flat buffer'
+    self.payload = payload or os.environ.get('CSMRI_GRAD_PAYLOAD', 'bf16')
+    assert self.payload in ('bf16', 'fp32')
+    self._started = [False] * len(self.splits)
+    self._done = [None] * len(self.splits)        # end-of-exchange events (device tensors) / None
+    self._stage = {}
+    self._stream = None
 
-  def start(self):
-    if world_size() > 1:
-      self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+  # -- one sub-bucket ----------------------------------------------------------------------------------
+  def _buffers(self, i, world):
+    a, b = self.splits[i]
+    per = ((b - a + world - 1) // world + 7) // 8 * 8
+    key = (i, world)
+    if key not in self._stage:
+      dev = self.flat.device
+      self._stage[key] = (torch.zeros(world * per, dtype=torch.bfloat16, device=dev),
+                          torch.empty(world * per, dtype=torch.bfloat16, device=dev),
+                          torch.empty(per, dtype=torch.bfloat16, device=dev))
+    return (per,) + self._stage[key]
+
+  def _exchange(self, i):
+    world = world_size()
+    a, b = self.splits[i]
+    view = self.flat[a:b]
+    host_hop = _backend() == 'gloo' and view.is_cuda     # functional tests: several ranks on one GPU over gloo
+    if self.payload == 'fp32':
+      if host_hop:
+        t = view.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        view.copy_(t)
+      else:
+        dist.all_reduce(view, op=dist.ReduceOp.SUM)
+      return
+    per, send, recv, mine = self._buffers(i, world)
+    send[:b - a].copy_(view)                              # fp32 -> bf16 (RNE); the padded tail stays zero
+    if host_hop:
+      s_h, r_h = send.cpu(), torch.empty(world * per, dtype=torch.bfloat16)
+      dist.all_to_all_single(r_h, s_h)
+      recv.copy_(r_h)
+    else:
+      dist.all_to_all_single(recv, send)
+    mine.copy_(recv.view(world, per).float().sum(0))      # the N contributions to my chunk, summed in fp32
+    if host_hop:
+      g_h = torch.empty(world * per, dtype=torch.bfloat16)
+      dist.all_gather_into_tensor(g_h, mine.cpu())
+      send.copy_(g_h)
+    else:
+      dist.all_gather_into_tensor(send, mine)
+    view.copy_(send[:b - a])                              # bf16 -> fp32
+    send[b - a:].zero_()
+
+  def start(self, i=None):
+    """Begin the exchange of sub-bucket i (all not yet started ones when None).  The gradients of the range
+    must have been ISSUED on the calling stream (or on streams it has joined)."""
+    if world_size() <= 1:
+      return
+    todo = [j for j in range(len(self.splits)) if not self._started[j]] if i is None else [i]
+    for j in todo:
+      if self._started[j]:
+        continue
+      self._started[j] = True
+      if not self.flat.is_cuda:
+        self._exchange(j)
+        continue
+      if self._stream is None:
+        self._stream = torch.cuda.Stream()
+      ready = torch.cuda.Event()
+      ready.record()
+      self._stream.wait_event(ready)
+      with torch.cuda.stream(self._stream):
+        self._exchange(j)
+        done = torch.cuda.Event()
+        done.record(self._stream)
+      self._done[j] = done
 
   def wait(self):
-    """Returns the factor the summed gradient must be scaled by (1/world)."""
-    if self.work is not None:
-      self.work.wait()
-      self.work = None
+    """Make the caller's stream wait for every started exchange; returns the factor the summed gradient
+    must be scaled by (1/world)."""
+    if world_size() > 1:
+      self.start()                                        # anything nobody started early
+      for j, ev in enumerate(self._done):
+        if ev is not None:
+          torch.cuda.current_stream().wait_event(ev)
+        self._done[j] = None
+        self._started[j] = False
     return 1.0 / world_size()
 
 

@@ -37,7 +37,19 @@ class FlatAdam(object):
     self.step_count = 0                       # host mirror of step_dev
     self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
     self._scale = 1.0
-    self.bucket = GradBucket(self.flat_g)
+    # sub-buckets for the gradient exchange, cut at conv weights from the END of the buffer (the backward
+    # finishes the last layers first) whenever a tail of >= 4 M elements has accumulated: the
+    # discriminator becomes [convs.22.. | convs.17.. | the rest], small models stay one bucket
+    cuts, acc = [], 0
+    for i in range(len(self.params) - 1, 0, -1):
+      acc += self.params[i].numel()
+      if acc >= (4 << 20) and self.params[i].dim() == 4 and self.offsets[i] > 0:
+        cuts.append(i)
+        acc = 0
+    bounds = [0] + [self.offsets[i] for i in reversed(cuts)] + [total]
+    splits = list(reversed([(bounds[j], bounds[j + 1]) for j in range(len(bounds) - 1)]))
+    self.bucket = GradBucket(self.flat_g, splits)
+    self._first_param_of_split = {id(self.params[i]): len(cuts) - 1 - k for k, i in enumerate(reversed(cuts))}
     self.param_groups = [{'lr': lr, 'betas': self.betas, 'eps': eps, 'weight_decay': 0,
                           'amsgrad': False, 'params': list(range(len(self.params)))}]
     # callable -> PackGroups holding packed copies of exactly these weights: a step then invalidates
@@ -53,6 +65,23 @@ class FlatAdam(object):
 
   def start_allreduce(self):
     self.bucket.start()
+
+  def grad_ready(self, layer):
+    """ops.GRAD_READY_HOOK target: the weight-gradient launch of `layer` has been issued (on the weight-gradient
+    side stream when one is in use).  When that layer's weight opens a sub-bucket, everything behind it in
+    the buffer is final: start that sub-bucket's exchange now, under the rest of the backward."""
+    j = self._first_param_of_split.get(id(layer.weight))
+    if j is None or torch.cuda.is_current_stream_capturing():
+      return
+    from training.distributed import world_size
+    if world_size() <= 1:
+      return
+    side = ops._WGRAD['stream']
+    if side is not None:
+      with torch.cuda.stream(side):
+        self.bucket.start(j)
+    else:
+      self.bucket.start(j)
 
   def wait_allreduce(self):
     self._scale = self.bucket.wait()

@@ -55,6 +55,9 @@ class Runner(BaseRunner):
     self.loss_weights = self._get_loss_weights(loss_weights or {}, self.criteria)
     self.optimizer = optimizer
     self.lr_scheduler = lr_scheduler
+    if optimizer is not None and dist_utils.world_size() > 1:
+      from csmri_hip import ops
+      ops.GRAD_READY_HOOK = optimizer.grad_ready
     self.train_metric_fns = train_metric_fns or {}
     self.val_metric_fns = val_metric_fns or {}
     self.train_model_input_fn = self._get_model_input_fn(model, train_input_batch_transform)

@@ -211,6 +211,12 @@ int csmri_dc(const float* x, int x_pix_stride, const float* k0, const uint8_t* m
 int csmri_undersample(const float* img, const uint8_t* mask, float* kspace, float* inp, int B,
                       int H, int W, void* stream);
 size_t csmri_dc_work_bytes(int B, int H, int W);
+/* stand-alone batched 2-D FFT / inverse FFT, interleaved complex fp32 [B,H,W,2] -> same (x == out allowed):
+ * the transform behind the reference's Fft2d / Ifft2d autograd Functions (myfft.py:78-128; their backward
+ * passes, :92-102,119-128, are this call with `inverse` flipped).  ortho != 0: 1/sqrt(HW) in both directions
+ * (normalized=True); ortho == 0: forward unscaled, inverse 1/(HW) (pytorch_fft.fft2 / ifft2).
+ * H, W powers of two in [32, 512]. */
+int csmri_fft2(const float* x, float* out, int B, int H, int W, int inverse, int ortho, void* stream);
 
 /* layout converters (H2D boundary: batch dict tensors are NCHW fp32,
  * training/base_runner.py:29-41) */

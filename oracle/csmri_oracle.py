@@ -691,6 +691,65 @@ def gan_train_step(PG, SG, PD, SD, PV, gen_opt, disc_opt, batch, pool=None,
   return losses, metrics, out_gen
 
 
+def data_parallel_gan_step(replicas, PV, shards, dropout_masks=None):
+  """SURVEY 8(e) multi-GPU parity oracle: N model replicas in lock step, each running
+  gan_train_step (the reference's AdversarialRunner step) on ITS shard of the global batch with its own
+  BatchNorm statistics, dropout draws and image pool; at every optimizer.step() the replicas' gradients are
+  first replaced by their mean -- what the gradient all-reduce / N does between the backward and Adam.
+  (The reference itself only has single-process nn.DataParallel, utils/custom_data_parallel.py:26-35,
+  whose replicas likewise keep per-replica BatchNorm batch statistics.)
+
+  replicas: list of dicts with keys PG, SG, PD, SD, gen_opt, disc_opt, pool (one per rank, same initial
+  weights); shards: per-rank batch dicts; dropout_masks: per-rank [3 passes][3 layers] or None.
+  Returns the per-rank (losses, metrics) and the averaged gradients {'G': {...}, 'D': {...}}."""
+  import threading
+  n = len(replicas)
+  bar = threading.Barrier(n)
+  avg = {}
+
+  def wrap(key, tag, names_of):
+    opts = [r[key] for r in replicas]
+    for rank, opt in enumerate(opts):
+      orig = opt.step
+
+      def step(orig=orig, rank=rank, opts=opts, tag=tag):
+        bar.wait()
+        if rank == 0:
+          plist = [[p for g in o.param_groups for p in g['params']] for o in opts]
+          mean = []
+          for group in zip(*plist):
+            m = sum(p.grad for p in group) / n
+            for p in group:
+              p.grad = m.clone()
+            mean.append(m)
+          avg[tag] = {k: m for k, m in zip(names_of(replicas[0]), mean)}
+        bar.wait()
+        orig()
+      opt.step = step
+  wrap('disc_opt', 'D', lambda r: list(r['PD'].keys()))
+  wrap('gen_opt', 'G', lambda r: [k for k, v in r['PG'].items() if v.requires_grad])
+  out, err = [None] * n, []
+
+  def run(rank):
+    try:
+      r = replicas[rank]
+      dm = dropout_masks[rank] if dropout_masks is not None else None
+      l, m, _ = gan_train_step(r['PG'], r['SG'], r['PD'], r['SD'], PV, r['gen_opt'], r['disc_opt'],
+                               shards[rank], pool=r.get('pool'), dropout_masks=dm)
+      out[rank] = (l, m)
+    except BaseException as e:       # a failed replica must not leave the others at the barrier
+      err.append(e)
+      bar.abort()
+  threads = [threading.Thread(target=run, args=(i,)) for i in range(n)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  if err:
+    raise err[0]
+  return out, avg
+
+
 def lr_multistep(base_lr, milestones, gamma, epoch):
   """MultiStepLR as built by training/lr_schedulers.py:26-31 (``multistep``): the value in force while
   the scheduler's epoch counter is ``epoch`` (the runner steps it once per epoch_beginning, so training

@@ -472,3 +472,34 @@ def test_fp32_kernels_exact_next_to_mfma_kernels_in_one_graph(hip):
     for got, want in zip(d, ref):
       assert torch.equal(got, want)
     assert torch.equal(c, ref_conv_out)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 64), (1, 256, 256), (2, 128, 32), (1, 512, 512), (3, 32, 64)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_fft2_standalone_matches_numpy(hip, shape):
+  """csmri_fft2 (the reference's Fft2d / Ifft2d, myfft.py:78-128) against numpy.fft -- the same
+  known-answer relation the reference's own myfft.py __main__ block checks (:186-189,203-207) -- in both
+  normalisations, plus the autograd adjoint (myfft.py:92-102) and the round trip."""
+  ops = hip.ops
+  b, h, w = shape
+  rng = np.random.RandomState(h + w)
+  x = (rng.randn(b, h, w) + 1j * rng.randn(b, h, w)).astype(np.complex64)
+  xd = torch.from_numpy(np.stack((x.real, x.imag), -1)).cuda()
+  for inverse in (False, True):
+    for ortho in (True, False):
+      fn = np.fft.ifft2 if inverse else np.fft.fft2
+      ref = fn(x.astype(np.complex128), norm='ortho' if ortho else None)
+      got = ops.fft2(xd, inverse, ortho).cpu().numpy()
+      got = got[..., 0] + 1j * got[..., 1]
+      err = np.abs(got - ref).max() / np.abs(ref).max()
+      print('fft2 %s inverse=%d ortho=%d rel max err %.2e' % (shape, inverse, ortho, err))
+      assert err < 2e-6, (inverse, ortho, err)
+  back = ops.fft2(ops.fft2(xd, False, True), True, True)
+  assert float((back - xd).abs().max()) < 5e-6 * float(xd.abs().max()) * 4
+  # adjoint: <F x, g> = <x, F^H g>
+  xg = xd.clone().requires_grad_(True)
+  g = torch.randn(xd.shape, generator=torch.Generator().manual_seed(1)).cuda()
+  (ops.Fft2d.apply(xg) * g).sum().backward()
+  gref = np.fft.ifft2((g[..., 0].cpu().numpy() + 1j * g[..., 1].cpu().numpy()).astype(np.complex128), norm='ortho')
+  gg = xg.grad.cpu().numpy()
+  assert np.abs((gg[..., 0] + 1j * gg[..., 1]) - gref).max() < 2e-6 * np.abs(gref).max() + 1e-7
