@@ -57,6 +57,8 @@ def parse():
   p.add_argument('--batch', type=int, default=0)
   p.add_argument('--no-graphs', action='store_true', help='eager launches instead of hipGraph replay')
   p.add_argument('--no-overlap', action='store_true', help='keep the VGG branch on the main stream')
+  p.add_argument('--cpu-all-threads', action='store_true',
+                 help='also time the CPU baseline at os.cpu_count() threads (256 on the GPU box: ~3 min per step)')
   p.add_argument('--device-resident', action='store_true',
                  help='A/B: batches already in HBM (no H2D in the timed region)')
   a = p.parse_args()
@@ -151,9 +153,21 @@ def _split_sd(sd):
   return P, S
 
 
-def cpu_baseline_c3(runner, host_batch, steps=2):
-  """The oracle's GAN step on the host cores: same weights, the SAME batch (all slices), timed at 32 threads
-  (small-batch conv2d stops scaling well before the box's hardware threads) and at os.cpu_count()."""
+def _thread_counts(all_threads):
+  """Thread counts the CPU baseline is timed at.  Small-batch conv2d stops scaling well before the box's
+  hardware threads and then collapses: measured on the GPU box (2 x EPYC 9575F, 256 threads;
+  profiles/r02_bench_n1_a.json) 1.79 slices/s at 32 threads against 0.046 at 256 (174 s per step), so
+  the os.cpu_count() run is opt-in (--cpu-all-threads) and the default adds 64 threads beside 32."""
+  n = os.cpu_count() or 1
+  counts = {min(32, n), min(64, n)}
+  if all_threads:
+    counts.add(n)
+  return sorted(counts)
+
+
+def cpu_baseline_c3(runner, host_batch, steps=2, all_threads=False):
+  """The oracle's GAN step on the host cores: same weights, the SAME batch (all slices), timed per thread
+  count of _thread_counts()."""
   sys.path.insert(0, os.path.join(ROOT, 'oracle'))
   import torch
   import csmri_oracle as O
@@ -161,7 +175,7 @@ def cpu_baseline_c3(runner, host_batch, steps=2):
   PV = {k: v.detach().cpu().clone() for k, v in
         runner.gen_criteria['VGG19'].criterion.vgg.state_dict().items() if k.startswith('blocks')}
   out = {}
-  for threads in sorted(set([min(32, os.cpu_count() or 1), os.cpu_count() or 1])):
+  for threads in _thread_counts(all_threads):
     torch.set_num_threads(threads)
     PG, SG = _split_sd(runner.gen.state_dict())
     PD, SD = _split_sd(runner.disc.state_dict())
@@ -200,13 +214,13 @@ def psnr_probe_c3(runner, host_batch, scale):
   return O.psnr_batch(pred, host_batch['target']), O.psnr_batch(want['pred'], host_batch['target'])
 
 
-def cpu_baseline_c2(runner, host_batch, sample_b=16, steps=3):
+def cpu_baseline_c2(runner, host_batch, sample_b=16, steps=3, all_threads=False):
   sys.path.insert(0, os.path.join(ROOT, 'oracle'))
   import torch
   import csmri_oracle as O
   out, psnr = {}, None
   batch = {k: v[:sample_b].clone() for k, v in host_batch.items()}
-  for threads in sorted(set([min(32, os.cpu_count() or 1), os.cpu_count() or 1])):
+  for threads in _thread_counts(all_threads):
     torch.set_num_threads(threads)
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in runner.model.state_dict().items()}
     opt = O.make_adam(P.values(), 2e-4, 0.9, 0.999)
@@ -406,7 +420,7 @@ def main():
     ref_runner, _ = build_runner(args.config, args.dtype, args.batch)
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     if gan:
-      line['cpu_baseline'] = cpu_baseline_c3(ref_runner, host_batches[0])
+      line['cpu_baseline'] = cpu_baseline_c3(ref_runner, host_batches[0], all_threads=args.cpu_all_threads)
       # the 0.01 dB criterion where the U-Net contributes (scale preset; the reference starts at scale = 0
       # where pred == pretrained, reported beside it)
       for tag, sc in (('', 0.02), ('_scale0p25', 0.25), ('_scale0', 0.0)):
@@ -416,7 +430,7 @@ def main():
       line['psnr_probe'] = ('generator forward (train-mode BatchNorm) on batch 0, initial weights, RefinementWrapper.scale '
                             'preset to 0.02 (headline psnr_delta_db), 0.25 and 0 (the reference\'s initial value)')
     else:
-      base, psnr_cpu = cpu_baseline_c2(ref_runner, host_batches[0])
+      base, psnr_cpu = cpu_baseline_c2(ref_runner, host_batches[0], all_threads=args.cpu_all_threads)
       line['cpu_baseline'] = base
       with torch.no_grad():
         ref_runner.model.train()

@@ -653,11 +653,14 @@ def test_f4_refinement_wrapper_fwd_bwd_fp32_vs_reference_golden(env):
   """F4 (the reference's RefinementWrapper, models/refinement_wrapper.py:169-220, reduced-width U-Net,
   128^2, scale = 0.37): the four outputs (2e-5), the BatchNorm running statistics after the forward,
   and the gradients of every U-Net tensor and of `scale` for fixed upstream gradients on pred and
-  prescaled_refinement.  Gradient bound: direction cos >= 0.9999 and relative L2 <= 1e-2 per tensor
-  -- 13 stacked LeakyReLU/BatchNorm layers on 2 x 128 x 128 positions: the few pre-activations within
-  fp32 rounding of zero take the other LeakyReLU slope under any change of summation order, and each
-  such flip moves an early layer's weight gradient by ~1e-3 of its norm (the late layers, which see
-  few flips downstream of them, agree to ~1e-5)."""
+  prescaled_refinement.
+  Gradient bound.  The reference's OWN fp32 gradients sit 2e-3 .. 1e-2 (relative L2) away from the exact
+  (fp64) values on every tensor upstream of the last BatchNorm layers -- the beta gradient of
+  concat_decode_units.1.decode.0.encode.2 is a sum over 32768 positions that cancels to ~1e-4 of its terms,
+  and everything before it inherits that (measured: the oracle in fp64 vs the fixture).  A second correct
+  fp32 evaluation cannot agree with the first more closely than each agrees with the truth, so the test
+  measures both against the fp64 oracle: per tensor, the HIP error may not exceed twice the reference's
+  own error (or 1e-4), and the direction must agree with the reference to cos >= 0.9999."""
   Configuration, set_dtype = env
   from models import construct_model
   from csmri_hip import ops
@@ -669,7 +672,8 @@ def test_f4_refinement_wrapper_fwd_bwd_fp32_vs_reference_golden(env):
   gen.load_state_dict(sub(f, 'P.'))
   ops.bump_weight_epoch()
   gen.train()
-  batch = {k: v.cuda() for k, v in O.synth_batch(2, 128, 128, acc=4, seed=11).items()}
+  host = O.synth_batch(2, 128, 128, acc=4, seed=11)
+  batch = {k: v.cuda() for k, v in host.items()}
   out = gen(batch['inp'], batch['kspace'], batch['mask'])
   for k in ('pred', 'pretrained', 'prescaled_refinement', 'scaled_refinement'):
     ref = T(f['out.' + k])
@@ -679,15 +683,33 @@ def test_f4_refinement_wrapper_fwd_bwd_fp32_vs_reference_golden(env):
     assert torch.allclose(got, ref, atol=2e-5 * max(1.0, float(ref.abs().max())), rtol=1e-4), k
   ((out['pred'] * T(f['gp']).cuda()).sum() + (out['prescaled_refinement'] * T(f['gu']).cuda()).sum()).backward()
   torch.cuda.synchronize()
+  # the exact gradients: the oracle in float64
+  dt = torch.float64
+  small_unet = dict(O.UNET_CONF, encode_filters=[8, 16, 32], decode_filters=[16, 8])
+  P = {k: v.to(dt) for k, v in sub(f, 'P.').items() if 'running' not in k and 'num_batches' not in k}
+  S = {k: v.to(dt).clone() for k, v in sub(f, 'P.').items() if 'running' in k}
+  P = {k: (v.clone().requires_grad_(True) if not k.startswith('pretrained_model') else v) for k, v in P.items()}
+  hb = {k: v.to(dt) for k, v in host.items()}
+  with torch.no_grad():
+    pre = O.recnet_forward(P, hb['inp'], hb['kspace'], hb['mask'], 3, 3, prefix='pretrained_model.conv_blocks')
+  rs, mn, mx = O.scale_minmax(pre[:, 0:1].contiguous())
+  u = O.unet_forward(P, S, pre, True, conf=small_unet, prefix='learnable_model.')
+  pred = torch.cat((O.unscale_minmax(rs + P['scale'] * u, mn, mx), pre[:, 1:2]), 1)
+  ((pred * T(f['gp']).to(dt)).sum() + (u * T(f['gu']).to(dt)).sum()).backward()
   named = dict(gen.named_parameters())
-  worst = (1.0, 0.0, '')
+  worst = (0.0, 0.0, '')
   for k, g in sub(f, 'grad.').items():
-    cos, err = _cos_err(named[k].grad.cpu().reshape(g.shape), g)
-    print('F4 grad %-66s cos %.7f rel_l2 %.3e' % (k, cos, err))
-    if g.numel() > 1 and cos < worst[0]:
-      worst = (cos, err, k)
-    assert err < 1e-2 and (g.numel() == 1 or cos > 0.9999), (k, cos, err)
-  print('F4 worst gradient: cos %.7f rel_l2 %.3e %s' % worst)
+    exact = P[k].grad.reshape(g.shape)
+    hip = named[k].grad.cpu().reshape(g.shape)
+    _, e_hip = _cos_err(hip, exact)
+    _, e_ref = _cos_err(g, exact)
+    cos, _ = _cos_err(hip, g)
+    print('F4 grad %-66s hip vs fp64 %.3e | reference vs fp64 %.3e | cos(hip, ref) %.7f' % (k, e_hip, e_ref, cos))
+    if e_hip / max(e_ref, 1e-4) > worst[0]:
+      worst = (e_hip / max(e_ref, 1e-4), e_hip, k)
+    assert e_hip <= max(2.0 * e_ref, 1e-4), (k, e_hip, e_ref)
+    assert g.numel() == 1 or cos > 0.9999, (k, cos)
+  print('F4 worst (HIP error) / (reference error): %.2f at %.3e  %s' % worst)
   sd = gen.state_dict()
   for k, v in sub(f, 'S1.').items():
     assert torch.allclose(sd[k].cpu(), v, atol=1e-5, rtol=1e-4), k
