@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcsmri_hip.so')
+# CSMRI_HIP_LIB: diagnostic builds of the SAME library (tools/stamp_*.py: in-kernel phase stamps)
+LIB_PATH = os.environ.get('CSMRI_HIP_LIB') or os.path.join(_HERE, 'libcsmri_hip.so')
 
 F32, BF16 = 0, 1
 BORDER_ZERO, BORDER_REFLECT = 0, 1

@@ -583,6 +583,56 @@ class ConvAct(torch.autograd.Function):
     return gx0, gx1, None, None, None, None, None
 
 
+class ConvActStack(torch.autograd.Function):
+  """A chain of (pad -> conv -> +bias -> LeakyReLU) layers as ONE autograd node (RecNet's ConvBlock,
+  reference models/recnet.py:29-62).  Same kernels as ConvAct per layer; in the backward the activation
+  derivative of layer i is applied in the epilogue of layer i+1's data-gradient kernel (its input IS layer
+  i's activated output, whose sign is the pre-activation's), so no separate act_bwd pass reads and
+  writes the gradient tensor between two layers.
+
+  ``plan``: list of (ConvLayer, slope); ``params``: the layers' weight / bias Parameters (only so that
+  autograd schedules this node; their gradients are accumulated into .grad by the kernels)."""
+
+  @staticmethod
+  def forward(ctx, x, plan, out_dtype_last, *params):
+    saved, cur = [x], x
+    n = len(plan)
+    for i, (layer, slope) in enumerate(plan):
+      cur, _ = conv_forward(layer, cur, None, True, slope, False, out_dtype_last if i == n - 1 else None)
+      saved.append(cur)
+    ctx.plan = plan
+    ctx.w_req = [layer.weight.requires_grad and layer.train_weights for layer, _ in plan]
+    ctx.save_for_backward(*saved)
+    return cur
+
+  @staticmethod
+  def backward(ctx, gy):
+    plan, saved = ctx.plan, ctx.saved_tensors
+    n = len(plan)
+    g = as_nhwc(gy)
+    last_layer, last_slope = plan[-1]
+    if g.dtype != last_layer.dtype:
+      g = g.to(last_layer.dtype)
+    if last_slope != 1.0:
+      g = act_bwd(g, saved[n], last_slope)
+    for i in range(n - 1, -1, -1):
+      layer, _ = plan[i]
+      xin = saved[i]
+      if ctx.w_req[i]:
+        conv_wgrad(layer, xin, None, g)
+        if GRAD_READY_HOOK is not None:
+          GRAD_READY_HOOK(layer)
+      in_hw = (xin.shape[1], xin.shape[2])
+      if i > 0:
+        prev_slope = plan[i - 1][1]
+        g = conv_dgrad(layer, g, in_hw, g_src=xin if prev_slope != 1.0 else None, g_slope=prev_slope)
+      elif ctx.needs_input_grad[0]:
+        g = conv_dgrad(layer, g, in_hw)
+      else:
+        g = None
+    return (g, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
 # ----------------------------------------------------------------------------
 # conv + BatchNorm(train/eval) + LeakyReLU (+ Dropout2d mask)
 # ----------------------------------------------------------------------------

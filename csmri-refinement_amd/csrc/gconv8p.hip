@@ -170,6 +170,16 @@ __global__ __launch_bounds__(512, 2) void gconv8p_kernel(const GParams p) {
   } while (0)
 #define G8P_BAR() __builtin_amdgcn_s_barrier()
 
+#ifdef CSMRI_DBG_STAMPS
+  // diagnostic build: per-wave cycle sums [phase 0..3][segment 0..4] written to p.slab (host passes a buffer):
+  // segment 0 = wait + fragment reads + stage issue, 1 = first barrier, 2 = lgkmcnt wait, 3 = MFMAs, 4 = second barrier
+  unsigned long long ph[4][5] = {}, last_t;
+#define STAMP(P, S) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    ph[P][S] += t_ - last_t; last_t = t_; } while (0)
+#else
+#define STAMP(P, S) do {} while (0)
+#endif
   // ---- prologue: tile 0 complete, X-lo / W-lo of tile 1 ------------------------------------------------
   char* b0 = smem; char* b1 = smem + BUF;
   stage_x(0, b0); stage_w(0, b0); stage_w(1, b0); stage_x(1, b0);
@@ -178,37 +188,49 @@ __global__ __launch_bounds__(512, 2) void gconv8p_kernel(const GParams p) {
   G8P_BAR();
   if (wm == 1) G8P_BAR();                    // second wave of every SIMD: one barrier interval behind
   char* cur = b0; char* nxt = b1;
+#ifdef CSMRI_DBG_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_t) :: "memory");
+#endif
   for (int tt = 0; tt < T; ++tt) {
     // P1
     G8P_VMCNT(6);                            // retires W-hi(t)
     read_x(cur, 0, xf); read_w(cur, 0, wl);
     stage_w(1, nxt);                         // W-hi(t+1)
-    G8P_BAR(); G8P_LGKM0();
+    STAMP(0, 0); G8P_BAR(); STAMP(0, 1); G8P_LGKM0(); STAMP(0, 2);
     G8P_MMA(wl, xf, 0, 0);
-    G8P_BAR();
+    STAMP(0, 3); G8P_BAR(); STAMP(0, 4);
     // P2
     G8P_VMCNT(6);                            // retires X-hi(t)
     read_w(cur, 1, wh);
     stage_x(1, nxt);                         // X-hi(t+1)
-    G8P_BAR(); G8P_LGKM0();
+    STAMP(1, 0); G8P_BAR(); STAMP(1, 1); G8P_LGKM0(); STAMP(1, 2);
     G8P_MMA(wh, xf, 2, 0);
-    G8P_BAR();
+    STAMP(1, 3); G8P_BAR(); STAMP(1, 4);
     // P3
     read_x(cur, 1, xf);
     stage_x(0, cur);                         // X-lo(t+2)
-    G8P_BAR(); G8P_LGKM0();
+    STAMP(2, 0); G8P_BAR(); STAMP(2, 1); G8P_LGKM0(); STAMP(2, 2);
     G8P_MMA(wh, xf, 2, 4);
-    G8P_BAR();
+    STAMP(2, 3); G8P_BAR(); STAMP(2, 4);
     // P4
     G8P_VMCNT(6);                            // retires X-lo(t+1), W-lo(t+1)
     stage_w(0, cur);                         // W-lo(t+2)
-    G8P_BAR();
+    STAMP(3, 0); G8P_BAR(); STAMP(3, 1); STAMP(3, 2);
     G8P_MMA(wl, xf, 0, 4);
-    G8P_BAR();
+    STAMP(3, 3); G8P_BAR(); STAMP(3, 4);
     char* sw = cur; cur = nxt; nxt = sw;
   }
   if (wm == 0) G8P_BAR();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing (zero-page) DMA must not outlive the workgroup's LDS
+#ifdef CSMRI_DBG_STAMPS
+  if (lane == 0 && p.slab && p.splitk == 1) {
+    unsigned long long* dbg = (unsigned long long*)p.slab + ((size_t)blockIdx.x * 8 + wid) * 20;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 5; ++b) dbg[a * 5 + b] = ph[a][b];
+  }
+#endif
 
   // ---- epilogue (gconv_glds256's) ----------------------------------------------------------------------
 #pragma unroll

@@ -721,6 +721,171 @@ __global__ __launch_bounds__(256, 3) void wgrad_glds_kernel(const WParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// wpatch: weight gradient of the stride-1 layers with few channels on large maps (RecNet, the 256^2 /
+// 128^2 U-Net levels: Cin in {32, 64}, Cout <= 64) from an LDS PATCH.  The kernels above gather X once
+// per filter tap and per 256-row tile of the (tap, channel) axis; on these layers (16 taps, two such
+// tiles) that is what the hardware counters showed: 2.8-3x the operand bytes fetched, and at C2's batch
+// of 64, where the tensors exceed the Infinity Cache, all of it comes from HBM.  Here a workgroup owns
+// 16 x 16 output pixels at a time: it stages the (16+KH-1) x (16+KW-1) input patch (border rule,
+// upsampling, concat applied while loading, as in tconv.hip) and the 256 x Cout dY tile ONCE, and every
+// tap reads its shifted window of the patch from LDS with ds_read_b64_tr_b16.  Each input pixel is
+// fetched 1.27-1.4 times (the halo) and dY once.  Workgroups are persistent over tiles (grid.z-style
+// split count = number of workgroups) so the fp32 accumulators leave as ONE slab per workgroup; the
+// slabs go through the same deterministic reduce-scatter as before.
+// Work split: wave w owns taps w, w+WAVES, ...; all (Cin/16) x (Cout/16) fragment pairs of a tap.
+template <int CIN, int COUT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
+  constexpr int CPR = CIN / 8;                      // 16-byte chunks per patch pixel
+  constexpr int CQ = COUT / 8;                      // chunks per dY pixel (COUT = 16 for 8 real channels)
+  constexpr int CF = CIN / 16, NF = COUT / 16;
+  constexpr int MAXT = 16 / WAVES;                  // taps per wave (KH * KW <= 16)
+  constexpr int XROWS = 1024 / (CPR * 16), YROWS = 1024 / (CQ * 16);   // rows per LDS-DMA instruction
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int TPW = 16 + p.KW - 1, TPH = 16 + p.KH - 1, npix = TPH * TPW;
+  const int xinstr = (npix + XROWS - 1) / XROWS;
+  const int IMG_X = xinstr * 1024;                  // dY image follows the patch
+  char* ximg = smem; char* yimg = smem + IMG_X;
+  const int taps = p.KH * p.KW;
+  const int tiles_x = (p.Wo + 15) >> 4, tiles_y = (p.Ho + 15) >> 4, ntiles = p.B * tiles_x * tiles_y;
+  const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3, r16 = lane & 15;
+
+  f32x4_t acc[MAXT][CF][NF];
+#pragma unroll
+  for (int a = 0; a < MAXT; ++a)
+#pragma unroll
+    for (int c = 0; c < CF; ++c)
+#pragma unroll
+      for (int n = 0; n < NF; ++n) acc[a][c][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // lane constants of the staging instructions
+  const int xr = lane / CPR, xslot = lane % CPR;
+  const int yr = lane / CQ, yslot = lane % CQ;
+  const unsigned magic = 0xFFFFFFFFu / (unsigned)TPW + 1u;
+  // lane constants of the fragment reads: K chunk kc = tile rows 2kc, 2kc+1; this lane's pixel k = 8g + tq (+4)
+  const int klo = 8 * g + tq;
+  const int prow = (klo >> 4) * TPW + (klo & 15);   // patch row of pixel k for tap (0,0), tile row 0
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int b = t / (tiles_x * tiles_y);
+    const int rem = t - b * tiles_x * tiles_y;
+    const int y0 = (rem / tiles_x) * 16, x0 = (rem % tiles_x) * 16;
+    // ---- stage the patch and the dY tile ----------------------------------------------------
+    for (int i = wid; i < xinstr; i += WAVES) {
+      const int P = i * XROWS + xr;
+      const int py = (int)__umulhi((unsigned)P, magic), px = P - py * TPW;
+      int u = y0 - p.pt + py, w = x0 - p.pl + px;
+      if (p.border == CSMRI_BORDER_REFLECT) {
+        u = u < 0 ? -u : u; u = min(u, 2 * (Hv - 1) - u);
+        w = w < 0 ? -w : w; w = min(w, 2 * (Wv - 1) - w);
+      }
+      const bool ok = (P < npix) & ((unsigned)u < (unsigned)Hv) & ((unsigned)w < (unsigned)Wv);
+      if (p.ups) { u >>= 1; w >>= 1; }
+      const size_t pix = ((size_t)b * p.Hin + u) * p.Win + w;
+      const int chunk = (img_off<CPR>(P, xslot) >> 4) % CPR;      // source-side swizzle
+      const int c = chunk * 8;
+      const char* src = c < p.c0 ? p.in0 + (pix * p.ps0 + c) * 2 : p.in1 + (pix * p.ps1 + (c - p.c0)) * 2;
+      src = ok ? src : w_zero_page;
+      __builtin_amdgcn_global_load_lds((wgptr_t)src, (wlptr_t)(ximg + i * 1024), 16, 0, 0);
+    }
+    for (int i = wid; i < 256 / YROWS; i += WAVES) {
+      const int k = i * YROWS + yr;                 // tile pixel: row k >> 4, column k & 15
+      const int oy = y0 + (k >> 4), ox = x0 + (k & 15);
+      const int chunk = (img_off<CQ>(k, yslot) >> 4) % CQ;
+      const bool ok = oy < p.Ho && ox < p.Wo && chunk * 8 < p.Cout;
+      const char* src = ok ? p.dy + ((((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dyps + chunk * 8) * 2 : w_zero_page;
+      __builtin_amdgcn_global_load_lds((wgptr_t)src, (wlptr_t)(yimg + i * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- 8 K chunks of 32 pixels x my taps -----------------------------------------------------
+#pragma unroll 1
+    for (int kc = 0; kc < 8; ++kc) {
+      bf16x8_t yf[NF];
+      const int yrlo = kc * 32 + klo, yrhi = yrlo + 4;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int ch = n * 2 + (tp >> 1);
+        yf[n] = tr_frag(yimg, img_off<CQ>(yrlo, ch) + (tp & 1) * 8, img_off<CQ>(yrhi, ch) + (tp & 1) * 8);
+      }
+#pragma unroll
+      for (int a = 0; a < MAXT; ++a) {
+        const int tap = wid + a * WAVES;
+        if (tap >= taps) break;                     // wave-uniform
+        const int ty = tap / p.KW, tx = tap - ty * p.KW;
+        const int rlo = prow + (2 * kc + ty) * TPW + tx, rhi = rlo + 4;
+#pragma unroll
+        for (int c = 0; c < CF; ++c) {
+          const int ch = c * 2 + (tp >> 1);
+          const bf16x8_t xf = tr_frag(ximg, img_off<CPR>(rlo, ch) + (tp & 1) * 8, img_off<CPR>(rhi, ch) + (tp & 1) * 8);
+#pragma unroll
+          for (int n = 0; n < NF; ++n)
+            acc[a][c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[n], acc[a][c][n], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- one slab per workgroup: [Cout][NK], NK index = tap * Cin + ci ------------------------------
+#pragma unroll
+  for (int a = 0; a < MAXT; ++a) {
+    const int tap = wid + a * WAVES;
+    if (tap >= taps) break;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      const int co = n * 16 + r16;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int c = 0; c < CF; ++c) {
+        const int cc = tap * CIN + c * 16 + g * 4;
+        *(f32x4_t*)(p.slab + ((size_t)blockIdx.x * p.Cout + co) * p.NK + cc) = acc[a][c][n];
+      }
+    }
+  }
+}
+
+static int wpatch_cout(const csmri_wgrad_desc* d) { return d->Cout <= 16 ? 16 : d->Cout; }
+static bool wpatch_eligible(const csmri_wgrad_desc* d) {
+  static const char* off = getenv("CSMRI_NO_WPATCH");          // A/B knob
+  if (off || d->dtype != CSMRI_BF16 || d->stride != 1) return false;
+  if (!(d->Cin == 32 || d->Cin == 64)) return false;
+  if (!(d->Cout == 8 || d->Cout == 16 || d->Cout == 32 || d->Cout == 64)) return false;
+  if (d->KH * d->KW > 16 || d->KH < 1 || d->KW < 1) return false;
+  if (d->in1 && (d->c0 % 8)) return false;
+  const long long tiles = (long long)d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16);
+  return tiles >= 512;                                           // large maps only
+}
+static int wpatch_groups(const csmri_wgrad_desc* d) {
+  const long long tiles = (long long)d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16);
+  static const char* env = getenv("CSMRI_WPATCH_BLOCKS");        // tuning knob: persistent workgroups
+  long long g = env ? atoi(env) : 512;
+  if (g > tiles / 4) g = tiles / 4;                              // at least 4 tiles per workgroup
+  return (int)(g < 1 ? 1 : g);
+}
+template <int CIN, int COUT, int WAVES>
+static int launch_wpatch(const WParams& p, hipStream_t st) {
+  const int TPW = 16 + p.KW - 1, TPH = 16 + p.KH - 1;
+  const int xrows = 1024 / (CIN / 8 * 16);
+  const int lds = ((TPH * TPW + xrows - 1) / xrows) * 1024 + 256 * COUT * 2;
+  CSMRI_SET_MAX_LDS((wpatch_kernel<CIN, COUT, WAVES>), lds);
+  hipLaunchKernelGGL((wpatch_kernel<CIN, COUT, WAVES>), dim3(p.splitk), dim3(WAVES * 64), lds, st, p);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+static int wpatch_launch(const WParams& p, const csmri_wgrad_desc* d, hipStream_t st) {
+  const int co = wpatch_cout(d);
+  if (d->Cin == 32) {
+    if (co == 16) return launch_wpatch<32, 16, 4>(p, st);
+    if (co == 32) return launch_wpatch<32, 32, 4>(p, st);
+    return launch_wpatch<32, 64, 4>(p, st);
+  }
+  if (co == 16) return launch_wpatch<64, 16, 4>(p, st);
+  if (co == 32) return launch_wpatch<64, 32, 4>(p, st);
+  return launch_wpatch<64, 64, 8>(p, st);
+}
+
 struct WConfig { int BP, BQ; };
 // geometries the row-aligned LDS-DMA kernel takes (64-pixel K steps aligned with output rows)
 static bool wgrad_row_aligned(const csmri_wgrad_desc* d) {
@@ -743,6 +908,7 @@ static WConfig pick_wconfig(const csmri_wgrad_desc* d) {
 static int wgrad_ps(int dtype) { return dtype == CSMRI_BF16 ? 64 : 16; }
 
 extern "C" int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d) {
+  if (wpatch_eligible(d)) return wpatch_groups(d);
   WConfig c = pick_wconfig(d);
   const long long NK = (long long)d->KH * d->KW * d->Cin;
   const long long tiles = (long long)cdiv(NK, c.BP) * cdiv(d->Cout, c.BQ);
@@ -808,6 +974,10 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
 // template instance csmri_wgrad dispatches to for this problem, spelled as rocprofv3 prints it
 extern "C" int csmri_wgrad_kernel_name(const csmri_wgrad_desc* d, char* buf, int n) {
   CSMRI_CHECK_ARG(d && buf && n > 0);
+  if (wpatch_eligible(d)) {
+    snprintf(buf, n, "wpatch_kernel<%d, %d, %d>", d->Cin, wpatch_cout(d), d->Cin == 64 && wpatch_cout(d) == 64 ? 8 : 4);
+    return CSMRI_OK;
+  }
   WConfig c = pick_wconfig(d);
   const int wp = c.BQ >= 128 || (c.BQ == 64 && c.BP == 128) ? 2 : 4, wq = wp == 2 ? 2 : 1;
   static const char* use_tr = getenv("CSMRI_WGRAD_TR");
@@ -852,7 +1022,9 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   int rc;
 #define WG(DT_, BP_, BQ_, WP_, WQ_) rc = launch_wgrad<DT_, BP_, BQ_, WP_, WQ_>(p, st)
   static const char* use_tr = getenv("CSMRI_WGRAD_TR");       // A/B knob: register-staged variant
-  if (d->dtype == CSMRI_BF16 && !use_tr) {
+  if (wpatch_eligible(d)) {
+    rc = wpatch_launch(p, d, st);
+  } else if (d->dtype == CSMRI_BF16 && !use_tr) {
     if (c.BQ == 128) rc = launch_wgrad_glds<128, 128, 2, 2>(p, st);
     else if (c.BQ == 64 && c.BP == 256) rc = launch_wgrad_glds<256, 64, 4, 1>(p, st);
     else if (c.BQ == 64) rc = launch_wgrad_glds<128, 64, 2, 2>(p, st);

@@ -59,13 +59,10 @@ class ConvBlock(nn.Module):
     """x: NHWC [B,H,W,8] compute dtype.  Returns interleaved complex fp32
     [B,H,W,2] when the block ends in 2 channels (feeds DC), else NHWC."""
     n = self.num_convs
-    for i in range(n):
-      cp = self.layers[str(3 * i + 1)]
-      last = i == n - 1
-      x = ops.ConvAct.apply(x, None, cp.weight, cp.bias, cp.layer,
-                            1.0 if last else self.slope,
-                            torch.float32 if last else None)
-    return x
+    cps = [self.layers[str(3 * i + 1)] for i in range(n)]
+    plan = [(cp.layer, 1.0 if i == n - 1 else self.slope) for i, cp in enumerate(cps)]
+    params = [p for cp in cps for p in (cp.weight, cp.bias)]
+    return ops.ConvActStack.apply(x, plan, torch.float32, *params)
 
 
 class RecNet(nn.Module):

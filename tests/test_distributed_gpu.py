@@ -125,8 +125,7 @@ def _oracle_worker(rank, world, port, q, payload):
   runner.gen.load_state_dict(sub('G0.'))
   runner.disc.load_state_dict(sub('D0.'))
   ops.bump_weight_epoch()
-  full = synth_batch(4, 128, 128, acc=4, seed=11)
-  mine = {k: v.cuda() for k, v in D.shard_batch(full).items()}
+  full = synth_batch(4, 128, 128, acc=4, seed=11)       # the GLOBAL batch: the runner takes this rank's shard
   grads = {}
 
   def snap(opt, model, tag):
@@ -142,7 +141,7 @@ def _oracle_worker(rank, world, port, q, payload):
 
   class Loader(list):
     batch_size = 2
-  losses, metrics = runner.train_epoch(Loader([mine]), 1)
+  losses, metrics = runner.train_epoch(Loader([full]), 1)
   torch.cuda.synchronize()
   vals = {k: float(v.value) for k, v in losses.items()}
   splits = list(runner.disc_optimizer.bucket.splits)
