@@ -18,6 +18,7 @@
 //   P2  reads W-hi         multiplies (lo, hi)   stages X-hi of tile t+1
 //   P3  reads X-hi         multiplies (hi, hi)   stages X-lo of tile t+2   (its region was last read in P1)
 //   P4  reads nothing      multiplies (hi, lo)   stages W-lo of tile t+2   (W-lo fragments stay in registers)
+// (a phase's stage is issued in the middle of its MFMA block: cheapest place for the issue, see G8P_MMA)
 // Hazards (the two wave groups are one barrier interval apart, so "a phase later" is two intervals):
 //   WAR  a region is re-staged at least two phases after its last fragment read;
 //   RAW  a region is read one phase after the phase whose leading s_waitcnt vmcnt(6) retires it in EVERY wave
@@ -159,13 +160,21 @@ __global__ __launch_bounds__(512, 2) void gconv8p_kernel(const GParams p) {
       for (int kc = 0; kc < 2; ++kc)
         q[i][kc] = *(const bf16x8_t*)(buf + TILE_X + g8p_off(wn * 64 + h * 32 + i * 16 + r16, kc * 4 + g));
   };
-#define G8P_MMA(wq, xq, i0, j0)                                                                              \
+// 16 MFMAs of one quadrant; STAGE (the phase's two LDS-DMA instructions + pointer updates) is issued after the
+// first eight: among MFMAs an LDS-DMA issue costs ~60 cycles of the wave, in front of the barrier next to the
+// fragment reads 100-185 (in-kernel stamps: the load sections, not the MFMA sections, set the interval length)
+#define G8P_MMA(wq, xq, i0, j0, STAGE)                                                                       \
   do {                                                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
-    _Pragma("unroll") for (int kc = 0; kc < 2; ++kc)                                                         \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
-      acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[i][kc], xq[j][kc], acc[i0 + i][j0 + j], 0, 0, 0); \
+      acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[i][0], xq[j][0], acc[i0 + i][j0 + j], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    STAGE;                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+      acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[i][1], xq[j][1], acc[i0 + i][j0 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
 #define G8P_BAR() __builtin_amdgcn_s_barrier()
@@ -195,28 +204,24 @@ __global__ __launch_bounds__(512, 2) void gconv8p_kernel(const GParams p) {
     // P1
     G8P_VMCNT(6);                            // retires W-hi(t)
     read_x(cur, 0, xf); read_w(cur, 0, wl);
-    stage_w(1, nxt);                         // W-hi(t+1)
     STAMP(0, 0); G8P_BAR(); STAMP(0, 1); G8P_LGKM0(); STAMP(0, 2);
-    G8P_MMA(wl, xf, 0, 0);
+    G8P_MMA(wl, xf, 0, 0, stage_w(1, nxt));                        // W-hi(t+1)
     STAMP(0, 3); G8P_BAR(); STAMP(0, 4);
     // P2
     G8P_VMCNT(6);                            // retires X-hi(t)
     read_w(cur, 1, wh);
-    stage_x(1, nxt);                         // X-hi(t+1)
     STAMP(1, 0); G8P_BAR(); STAMP(1, 1); G8P_LGKM0(); STAMP(1, 2);
-    G8P_MMA(wh, xf, 2, 0);
+    G8P_MMA(wh, xf, 2, 0, stage_x(1, nxt));                        // X-hi(t+1)
     STAMP(1, 3); G8P_BAR(); STAMP(1, 4);
     // P3
     read_x(cur, 1, xf);
-    stage_x(0, cur);                         // X-lo(t+2)
     STAMP(2, 0); G8P_BAR(); STAMP(2, 1); G8P_LGKM0(); STAMP(2, 2);
-    G8P_MMA(wh, xf, 2, 4);
+    G8P_MMA(wh, xf, 2, 4, stage_x(0, cur));                        // X-lo(t+2)
     STAMP(2, 3); G8P_BAR(); STAMP(2, 4);
     // P4
     G8P_VMCNT(6);                            // retires X-lo(t+1), W-lo(t+1)
-    stage_w(0, cur);                         // W-lo(t+2)
     STAMP(3, 0); G8P_BAR(); STAMP(3, 1); STAMP(3, 2);
-    G8P_MMA(wl, xf, 0, 4);
+    G8P_MMA(wl, xf, 0, 4, stage_w(0, cur));                        // W-lo(t+2)
     STAMP(3, 3); G8P_BAR(); STAMP(3, 4);
     char* sw = cur; cur = nxt; nxt = sw;
   }

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void wgrad_scatter_t_kernel(const float* slab,
 }
 
 // bias gradient: column sums of dY, two deterministic stages
-#define DB_ROWS 256
+#define DB_ROWS 2048     // partial rows of the bias-gradient column sums (one workgroup each)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(int dt, const char* dy, int dyps, long long npix,
                                                              int C, float* partial) {
   // block = pixel range; threads = (channel vector, pixel lane), LDS tree over lanes
@@ -752,6 +752,11 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
   const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
   const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3, r16 = lane & 15;
 
+  // bias gradient = column sums of dY: one more MFMA per dY fragment against a fragment of ones (wave 0)
+  f32x4_t bacc[NF];
+#pragma unroll
+  for (int n = 0; n < NF; ++n) bacc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
   f32x4_t acc[MAXT][CF][NF];
 #pragma unroll
   for (int a = 0; a < MAXT; ++a)
@@ -810,6 +815,10 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
         const int ch = n * 2 + (tp >> 1);
         yf[n] = tr_frag(yimg, img_off<CQ>(yrlo, ch) + (tp & 1) * 8, img_off<CQ>(yrhi, ch) + (tp & 1) * 8);
       }
+      if (wid == 0 && p.nsteps) {                  // p.nsteps != 0: the caller wants the bias gradient
+#pragma unroll
+        for (int n = 0; n < NF; ++n) bacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[n], bacc[n], 0, 0, 0);
+      }
 #pragma unroll
       for (int a = 0; a < MAXT; ++a) {
         const int tap = wid + a * WAVES;
@@ -829,6 +838,12 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
     __syncthreads();
   }
   // ---- one slab per workgroup: [Cout][NK], NK index = tap * Cin + ci ------------------------------
+  if (wid == 0 && p.nsteps && g == 0) {            // row 0 of the ones product: sum over pixels per output channel
+    float* part = p.slab + (size_t)gridDim.x * p.Cout * p.NK + (size_t)blockIdx.x * p.Cout;
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+      if (n * 16 + r16 < p.Cout) part[n * 16 + r16] = bacc[n][0];
+  }
 #pragma unroll
   for (int a = 0; a < MAXT; ++a) {
     const int tap = wid + a * WAVES;
@@ -1022,8 +1037,11 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   int rc;
 #define WG(DT_, BP_, BQ_, WP_, WQ_) rc = launch_wgrad<DT_, BP_, BQ_, WP_, WQ_>(p, st)
   static const char* use_tr = getenv("CSMRI_WGRAD_TR");       // A/B knob: register-staged variant
-  if (wpatch_eligible(d)) {
-    rc = wpatch_launch(p, d, st);
+  const bool patch = wpatch_eligible(d);
+  if (patch) {
+    WParams q = p;
+    q.nsteps = d->db ? 1 : 0;                      // wpatch reuses the field: also produce the bias-gradient partials
+    rc = wpatch_launch(q, d, st);
   } else if (d->dtype == CSMRI_BF16 && !use_tr) {
     if (c.BQ == 128) rc = launch_wgrad_glds<128, 128, 2, 2>(p, st);
     else if (c.BQ == 64 && c.BP == 256) rc = launch_wgrad_glds<256, 64, 4, 1>(p, st);
@@ -1054,7 +1072,13 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
                        d->Cin, d->KH, d->KW, d->Cout_real, d->Cin_real, d->dw, d->accumulate);
   }
   CSMRI_LAUNCH_CHECK();
-  if (d->db) {
+  if (d->db && patch) {
+    // the patch kernel left one partial row per workgroup behind the slabs
+    float* part = d->slab + (size_t)p.splitk * d->Cout * p.NK;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout_real + 31) / 32), dim3(256), 0, st, part, p.splitk,
+                       d->Cout, d->Cout_real, d->db, d->accumulate);
+    CSMRI_LAUNCH_CHECK();
+  } else if (d->db) {
     float* part = d->slab + (size_t)p.splitk * d->Cout * p.NK;
     int rows = cdiv(p.M, 512); if (rows > DB_ROWS) rows = DB_ROWS; if (rows < 1) rows = 1;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows), dim3(256), 0, st, d->dtype, p.dy, p.dyps,
