@@ -351,6 +351,7 @@ static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
   auto lg2 = [](long long v) { int s = 0; while ((1ll << s) < v) ++s; return (1ll << s) == v ? s : -1; };
   p.wo_shift = lg2(d->Wo); p.howo_shift = lg2((long long)d->Ho * d->Wo);
   if (p.wo_shift < 0 || p.howo_shift < 0) p.wo_shift = p.howo_shift = -1;
+  p.tap_inner = 0;
   p.dense_out = !d->out_halo && nclass == 1 && d->out_sy == 1 && d->out_sx == 1 && d->out_oy == 0 && d->out_ox == 0 &&
                 d->Hout_t == d->Ho && d->Wout_t == d->Wo;
   const long long in_px = (long long)d->B * d->Hin * d->Win, out_px = (long long)d->B * d->Hout_t * d->Wout_t;

@@ -28,7 +28,10 @@
 #include "mma_core.h"
 #include "gconv_params.h"
 
-__device__ __attribute__((aligned(16))) char g8p_zero_page[16];
+// rows outside the image / past the last K tile read zeros.  Their pointers advance by 128 B per K tile like
+// every other row's (no per-row increment register); a pointer is recomputed at least every Cin/64 <= 16
+// tiles, so 4 KiB of zeros cover any run
+__device__ __attribute__((aligned(16))) char g8p_zero_page[4096];
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -79,12 +82,42 @@ __global__ __launch_bounds__(512, 2) void gconv8p_kernel(const GParams p) {
     }
   // K position of the next X half-tile to stage, per half (the two halves are staged two phases apart)
   int xk[2], xci[2], xty[2], xtx[2];
-  const char* aptr[2][2]; unsigned ainc[2][2];
-  const char* wptr[2][2]; unsigned winc[2];
+  const char* aptr[2][2];
   int wk[2];
+  // fast tap change (zero border, no upsampling, one source -- every VGG layer): the row's address for tap
+  // (0, 0), channel 0 is fixed; a tap adds a wave-uniform byte offset and re-tests the border.  The general
+  // rule below costs ~150 vector instructions per call, which in this loop lengthens a barrier interval of
+  // all eight waves (in-kernel stamps: the intervals holding it ran 2-3x the others)
+  const bool fast = p.border == CSMRI_BORDER_ZERO && !p.ups && p.in1 == nullptr;
+  // K order.  Default: K tile s = (tap, 64-channel chunk), tap-major, as the weights are packed.  TAP-INNER (fast
+  // path, several taps): s = (chunk, tap) -- consecutive K tiles re-read the SAME input rows shifted by one
+  // pixel, which hit in L2, instead of sweeping the whole receptive field once per tap out of the Infinity
+  // Cache (the counters showed ~3x the input fetched per 3x3 layer, and the stamps the X stages as the long
+  // phases).  The weight K offset follows: (tap * Cin + chunk * 64) elements.
+  const int ntaps = p.TH * p.TW;
+  const bool ti = fast && ntaps > 1 && p.tap_inner;
+  const char* rowptr[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int chunk = slot ^ ((j * 4 + (lrow >> 1)) & 7);
+      const long long pix = (long long)ib[h][j] + (long long)by[h][j] * p.Win + bx[h][j];
+      rowptr[h][j] = p.in0 + (pix * p.ps0 + chunk * 8) * 2;
+    }
   auto x_ptrs = [&](int h) {
     const bool live = xk[h] < s_end;
     const int oy_ = xty[h] * p.dys, ox_ = xtx[h] * p.dxs;
+    if (fast) {
+      const long long delta = ((long long)(oy_ * p.Win + ox_) * p.ps0 + xci[h]) * 2;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool ok = live & (ib[h][j] >= 0) & ((unsigned)(by[h][j] + oy_) < (unsigned)p.Hin) &
+                        ((unsigned)(bx[h][j] + ox_) < (unsigned)p.Win);
+        aptr[h][j] = ok ? rowptr[h][j] + delta : g8p_zero_page;
+      }
+      return;
+    }
     const bool second = xci[h] >= p.c0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -99,43 +132,52 @@ __global__ __launch_bounds__(512, 2) void gconv8p_kernel(const GParams p) {
       const int pix = ib[h][j] + u * p.Win + v;
       const char* g = p.off32 ? src + (unsigned)pix * (unsigned)ps : src + (size_t)pix * ps;
       aptr[h][j] = ok ? g : g8p_zero_page;
-      ainc[h][j] = ok ? 128u : 0u;
     }
   };
+  const char* wrow[2][2]; long long wko[2];      // weight rows at K = 0; byte offset of the next K tile to stage
+  const long long wtap_step = (long long)p.Cin * 2, wwrap = (long long)(ntaps - 1) * p.Cin * 2 - 128;
+  int wtap[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     xk[h] = s_begin;
-    const int k0 = s_begin * 64, tap = k0 / p.Cin;
-    xci[h] = k0 - tap * p.Cin; xty[h] = tap / p.TW; xtx[h] = tap - xty[h] * p.TW;
+    if (ti) { const int ch = s_begin / ntaps, tap = s_begin - ch * ntaps; xci[h] = ch * 64; xty[h] = tap / p.TW; xtx[h] = tap - xty[h] * p.TW; }
+    else { const int k0 = s_begin * 64, tap = k0 / p.Cin; xci[h] = k0 - tap * p.Cin; xty[h] = tap / p.TW; xtx[h] = tap - xty[h] * p.TW; }
     x_ptrs(h);
     wk[h] = s_begin;
+    wtap[h] = ti ? s_begin % ntaps : 0;
+    wko[h] = ti ? ((long long)wtap[h] * p.Cin + (long long)(s_begin / ntaps) * 64) * 2 : (long long)s_begin * 128;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int chunk = slot ^ ((j * 4 + (lrow >> 1)) & 7);
-      wptr[h][j] = p.w + ((size_t)cls * (size_t)p.wcs + (size_t)(n0 + wrow_base + h * 32 + j * 8 + lrow) * p.Kp + chunk * 8) * 2 +
-                   (size_t)s_begin * 128;
+      wrow[h][j] = p.w + ((size_t)cls * (size_t)p.wcs + (size_t)(n0 + wrow_base + h * 32 + j * 8 + lrow) * p.Kp + chunk * 8) * 2;
     }
-    winc[h] = 128u;
-    if (T <= 0) { winc[h] = 0; wptr[h][0] = wptr[h][1] = g8p_zero_page; }
   }
   auto stage_x = [&](int h, char* buf) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       __builtin_amdgcn_global_load_lds((gptr_t)aptr[h][j], (lptr_t)(buf + (xrow_base + h * 64 + j * 8) * 128), 16, 0, 0);
-      aptr[h][j] += ainc[h][j];
+      aptr[h][j] += 128;
     }
     ++xk[h];
+    if (ti) {
+      if (++xtx[h] == p.TW) { xtx[h] = 0; if (++xty[h] == p.TH) { xty[h] = 0; xci[h] += 64; } }
+      x_ptrs(h);
+      return;
+    }
     xci[h] += 64;
     if (xci[h] == p.Cin) { xci[h] = 0; if (++xtx[h] == p.TW) { xtx[h] = 0; ++xty[h]; } x_ptrs(h); }
     else if (xci[h] == p.c0 || xk[h] == s_end) x_ptrs(h);       // second concat source / past the end: zero page
   };
   auto stage_w = [&](int h, char* buf) {
+    const bool live = wk[h] < s_end;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)wptr[h][j], (lptr_t)(buf + TILE_X + (wrow_base + h * 32 + j * 8) * 128), 16, 0, 0);
-      wptr[h][j] += winc[h];
+      const char* src = live ? wrow[h][j] + wko[h] : g8p_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + TILE_X + (wrow_base + h * 32 + j * 8) * 128), 16, 0, 0);
     }
-    if (++wk[h] == s_end) { winc[h] = 0; wptr[h][0] = wptr[h][1] = g8p_zero_page; }
+    ++wk[h];
+    if (ti) { if (++wtap[h] == ntaps) { wtap[h] = 0; wko[h] -= wwrap; } else wko[h] += wtap_step; }
+    else wko[h] += 128;
   };
 
   // ---- fragments -------------------------------------------------------------------------------------
@@ -283,9 +325,15 @@ static long long g8p_tiles(const csmri_gconv_desc* d) {
   return (long long)cdiv((long long)d->B * d->Ho * d->Wo, 256) * (d->Cout / 256) * nclass;
 }
 
+// EXPERIMENTAL, off by default (CSMRI_8P=1 enables it; tools/check_8p.py, tools/stamp_8p.py).  Measured on
+// MI355X (round 2): 870-920 TFLOP/s on VGG conv3_2 at batch 16 against 940-950 for
+// gconv_glds256 and slower than the 128-row kernels wherever K has to be split -- the barrier intervals that
+// carry an X stage run 2-3x the others wherever the stage is issued, because a CU takes in rows that miss L2
+// at 23-34 GB/s (MI355X_MICROARCH.md, gather table) and a 256 x 256 x 64 tile needs 64 KiB per microsecond.
 int gconv8p_eligible(const csmri_gconv_desc* d) {
+  static const char* on = getenv("CSMRI_8P");                  // opt-in
   static const char* off = getenv("CSMRI_NO_8P");              // A/B knob
-  if (off) return 0;
+  if (!on || atoi(on) == 0 || off) return 0;
   if (!gconv_glds_eligible(d)) return 0;
   if (d->Cout % 256 || d->stats_partial) return 0;
   static const char* mint = getenv("CSMRI_8P_MIN_TILES");        // A/B knob
@@ -316,6 +364,8 @@ int gconv8p_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st)
   const long long w_elems = (long long)d->Cout * d->TH * d->TW * d->Cin * p.nclass;
   const long long x_elems = (long long)d->B * d->Hin * d->Win * d->Cin;
   p.nt_major = w_elems > x_elems;
+  static const char* ti_env = getenv("CSMRI_8P_TAP_INNER");      // A/B knob
+  p.tap_inner = ti_env ? atoi(ti_env) : 0;      // measured slower than the tap-major order (755 vs 870 TFLOP/s)
   constexpr int lds = 2 * (256 + 256) * 128;
   CSMRI_SET_MAX_LDS(gconv8p_kernel, lds);
   dim3 grid(p.mtiles * p.ntiles, 1, p.nclass * p.splitk);

@@ -18,6 +18,7 @@ struct GParams {
   int wo_shift, howo_shift;   // log2(Wo), log2(Ho*Wo) when both are powers of two, else -1: m -> (b,oy,ox) by shifts
   int dense_out;              // output position index == m (no window / stride / offset / classes): no division at all
   int off32;                  // every input / output byte offset fits 32 bits
+  int tap_inner;              // gconv8p: K order (64-channel chunk, tap) instead of (tap, chunk)
 };
 
 // where output position (b, ty, tx) of the tensor goes: window -> dense `out`, else halo buffer

@@ -78,7 +78,7 @@ if __name__ == '__main__':
     dump(sys.argv[2], sys.argv[3:])
   else:
     names = [a for a in sys.argv[1:] if a in CASES] or list(CASES)
-    env = dict(os.environ)
+    env = dict(os.environ, CSMRI_8P='1')
     subprocess.check_call([sys.executable, __file__, 'dump', '/tmp/g8p_a.pt'] + names, env=env)
     env['CSMRI_NO_8P'] = '1'
     subprocess.check_call([sys.executable, __file__, 'dump', '/tmp/g8p_b.pt'] + names, env=env)

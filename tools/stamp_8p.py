@@ -3,6 +3,7 @@ library: make -C csmri-refinement_amd/csrc stamps; loaded through CSMRI_HIP_LIB)
 usage: python tools/stamp_8p.py [cin cout H B]   (3x3 zero-pad conv, split-K off)"""
 import os, sys, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('CSMRI_8P', '1')
 os.environ.setdefault('CSMRI_HIP_LIB', os.path.join(ROOT, 'csmri-refinement_amd', 'csmri_hip', 'libcsmri_hip_stamps.so'))
 sys.path.insert(0, os.path.join(ROOT, 'csmri-refinement_amd'))
 import torch
