@@ -162,7 +162,8 @@ __device__ __forceinline__ void fft_dit_inv(float2 (&v)[FftCfg<LOGN>::R], const 
   }
 }
 
-#define DC_THREADS 256
+#define DC_THREADS 256               // row passes: 4 waves = 4 rows per workgroup
+#define DC_CTHREADS 512              // column pass: 8 waves = one column of the strip each
 #define DC_STRIP 8                   // columns per workgroup in pass 2 (64-byte row segments)
 #define DC_PITCH (DC_STRIP + 1)      // float2 pitch of the LDS strip image (conflict-free column reads)
 
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const float* __rest
 //   MODE 1  FFT along H only (x scale), natural order out                        (csmri_fft2 forward)
 //   MODE 2  inverse FFT along H only (x scale)                                   (csmri_fft2 inverse)
 template <int LOGN, int MODE>
-__global__ __launch_bounds__(DC_THREADS) void dc_cols_kernel(float2* __restrict__ data, const float2* __restrict__ k0,
+__global__ __launch_bounds__(DC_CTHREADS) void dc_cols_kernel(float2* __restrict__ data, const float2* __restrict__ k0,
                                                              const uint8_t* __restrict__ mask, int W, float scale,
                                                              float2* __restrict__ kout, int keep_sampled) {
   typedef FftCfg<LOGN> C;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_cols_kernel(float2* __restrict_
   const int strips = W / DC_STRIP;
   const int img = blockIdx.x / strips, c0 = (blockIdx.x - img * strips) * DC_STRIP;
   const size_t base = (size_t)img * H * W + c0;
-  for (int idx = tid; idx < H * DC_STRIP; idx += DC_THREADS) {
+  for (int idx = tid; idx < H * DC_STRIP; idx += DC_CTHREADS) {
     const int h = idx / DC_STRIP, c = idx - h * DC_STRIP;
     const size_t o = base + (size_t)h * W + c;
     A[h * DC_PITCH + c] = data[o];
@@ -250,10 +251,11 @@ __global__ __launch_bounds__(DC_THREADS) void dc_cols_kernel(float2* __restrict_
   LaneTw<LOGN> tw;
   tw.init(l);
   const int kbase = C::R * rev_bits(l, C::LOGL);
-  constexpr int COLS_PER_WAVE = DC_STRIP / (DC_THREADS / 64);       // 2
-#pragma unroll 1
-  for (int cc = 0; cc < COLS_PER_WAVE; cc += C::TPW) {
-    const int c = wave * COLS_PER_WAVE + cc + (lane >> C::LOGL);
+  constexpr int COLS_PER_WAVE = DC_STRIP / (DC_CTHREADS / 64);      // 1 (H = 32: two columns per wave on its half-waves, 4 waves idle)
+  static_assert(COLS_PER_WAVE == 1, "one column per wave");
+  const bool has_col = wave * C::TPW < DC_STRIP;        // wave-uniform
+  if (has_col) {
+    const int c = wave * C::TPW + (lane >> C::LOGL);
     float2 v[C::R];
     if (MODE != 2) {
 #pragma unroll
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_cols_kernel(float2* __restrict_
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < H * DC_STRIP; idx += DC_THREADS) {
+  for (int idx = tid; idx < H * DC_STRIP; idx += DC_CTHREADS) {
     const int h = idx / DC_STRIP, c = idx - h * DC_STRIP;
     const size_t o = base + (size_t)h * W + c;
     data[o] = A[h * DC_PITCH + c];
@@ -327,7 +329,7 @@ static int launch_cols(float2* data, const float2* k0, const uint8_t* mask, int 
   constexpr int H = 1 << LOGN;
   constexpr int lds = 2 * H * DC_PITCH * (int)sizeof(float2) + H * DC_STRIP;
   CSMRI_SET_MAX_LDS((dc_cols_kernel<LOGN, MODE>), lds);
-  hipLaunchKernelGGL((dc_cols_kernel<LOGN, MODE>), dim3(B * (W / DC_STRIP)), dim3(DC_THREADS), lds, st,
+  hipLaunchKernelGGL((dc_cols_kernel<LOGN, MODE>), dim3(B * (W / DC_STRIP)), dim3(DC_CTHREADS), lds, st,
                      data, k0, mask, W, scale, kout, keep);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;

@@ -69,8 +69,9 @@ def main(argv=None):
     print(runner)
   start_epoch = 1
   if args.resume:
-    _, epoch, _ = restore_checkpoint(args.resume, runner)
-    start_epoch = epoch + 1
+    state = restore_checkpoint(args.resume, runner, args.cuda)
+    # the reference stores the NEXT epoch in periodic checkpoints (train.py:295: save(..., epoch + 1, ...))
+    start_epoch = state.get('start_epoch', 1)
   if args.dry:
     return 0
   size = conf.get_attr('image_size', default=512 // conf.get_attr('downscale', default=1))

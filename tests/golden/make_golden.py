@@ -10,7 +10,8 @@ the reference's source is stored -- only data.
 
 Fixtures: F1 synthetic batch + mask rows, F2 DC fwd/adjoint,
 F3 RecNet fwd/loss/grads/Adam steps, F4 RefinementWrapper, F5 discriminator,
-F6 VGG loss, F7 full GAN train steps, F8 PSNR, F9 SSIM, F10 radial masks, F11 multi-update steps + pretraining schedule + LR schedulers.
+F6 VGG loss, F7 full GAN train steps, F8 PSNR, F9 SSIM, F10 radial masks, F11 multi-update steps + pretraining schedule + LR schedulers, F12 weight initialisation digests,
+F13 a checkpoint written by the reference's save_checkpoint + what the reference computes after it.
 """
 import collections
 import collections.abc
@@ -623,8 +624,92 @@ def f11():
   save('F11_schedules', **out)
 
 
+# ----------------------------------------------------------------- F12 ----
+# the reference's weight initialisation (models/weight_inits.py:5-114 with the per-model
+# weight_init_params: recnet.py:54-59, unet.py:253-259, discriminators.py:189-209) under fixed torch seeds, at the
+# FULL widths of configs/2-refinement.json and for the 1-recnet.json RecNet.  torch's CPU generator gives the
+# same stream on every machine for one torch version, so a construction that draws in the same order with the
+# same initialisers reproduces the tensors bit for bit: the fixture stores per tensor its shape, first 8
+# values, float64 sum, sum of squares and an order-sensitive checksum (dot with cos(0.37 i)).
+
+
+def _digest(t):
+  a = t.detach().double().reshape(-1).numpy()
+  i = np.arange(a.size, dtype=np.float64)
+  return np.array([a.sum(), (a * a).sum(), (a * np.cos(0.37 * i)).sum(), a.min(), a.max()], dtype=np.float64)
+
+
+def f12():
+  out = {}
+  conf = _gan_conf(small=False)
+  ref_utils.set_random_seeds(7)
+  gc = Configuration.from_dict(conf.generator_model, conf)
+  gen = construct_model(gc, gc.name, cuda='')
+  ref_utils.set_random_seeds(8)
+  dc = Configuration.from_dict(conf.discriminator_model, conf)
+  disc = construct_model(dc, dc.name, cuda='')
+  rconf = Configuration.from_json(os.path.join(REF, 'configs/1-recnet.json'))
+  ref_utils.set_random_seeds(9)
+  rc = Configuration.from_dict(rconf.model, rconf)
+  rec = construct_model(rc, rc.name, cuda='')
+  for tag, model in (('G', gen), ('D', disc), ('R', rec)):
+    for k, v in model.state_dict().items():
+      if 'num_batches' in k:
+        continue
+      out['%s.%s.digest' % (tag, k)] = _digest(v)
+      out['%s.%s.head' % (tag, k)] = v.detach().reshape(-1)[:8].numpy().copy()
+      out['%s.%s.shape' % (tag, k)] = np.array(v.shape, dtype=np.int64)
+  out['seeds'] = np.array([7, 8, 9])
+  save('F12_weight_init', **out)
+
+
+# ----------------------------------------------------------------- F13 ----
+# a checkpoint written by the reference's OWN save_checkpoint (utils/checkpoints.py:9-16) from its
+# AdversarialRunner after one training step (so the Adam states are populated), and what the reference then
+# does with it: the generator's eval-mode prediction on a batch and the losses of the NEXT training step.
+
+
+def f13():
+  import utils.checkpoints as ref_ck
+  conf = _gan_conf()
+  ref_utils.set_random_seeds(conf.seed)
+  runner = ref_AR.build_runner(conf, '', 'train')
+  vgg_crit = runner.gen_criteria['VGG19'].c
+  _load_vgg_weights(vgg_crit.criterion.vgg, seed=19)
+  with torch.no_grad():
+    runner.gen.scale.fill_(0.25)
+  inj = _InjectedDropout()
+  g = torch.Generator().manual_seed(55)
+  inj.install(runner.disc, g)
+  out = {}
+  batch0 = O.synth_batch(2, 128, 128, acc=4, seed=900)
+  runner.train_epoch(_Loader([batch0]), 1)
+  for j, mk in enumerate(inj.used):
+    out['step0.mask%d' % j] = mk.numpy()
+  path = os.path.join(HERE, 'F13_reference_checkpoint.pth')
+  conf._src_file = None                      # the pickled Configuration must not point into the reference tree
+  ref_ck.save_checkpoint(path, conf, runner, 4, {'psnr': 31.5})
+  print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024.0))
+  runner._set_test()
+  with torch.no_grad():
+    vb = O.synth_batch(2, 128, 128, acc=4, seed=901)
+    pred = runner.gen(vb['inp'], vb['kspace'], vb['mask'])['pred']
+  out['eval_pred'] = pred.numpy()
+  n0 = len(inj.used)
+  batch1 = O.synth_batch(2, 128, 128, acc=4, seed=902)
+  l, m = runner.train_epoch(_Loader([batch1]), 2)
+  for j, mk in enumerate(inj.used[n0:]):
+    out['step1.mask%d' % j] = mk.numpy()
+  names = sorted(l.keys())
+  out['loss_names'] = np.array(names)
+  out['step1.losses'] = np.array([l[k].value for k in names], dtype=np.float64)
+  out['step1.gen_psnr'] = np.float64(m['gen_psnr'].value)
+  out.update({'G2.' + k: v for k, v in npd(runner.gen.state_dict()).items() if not k.startswith('pretrained_model')})
+  save('F13_checkpoint_expected', **out)
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13']
   for name in which:
     print('==', name)
     globals()[name]()

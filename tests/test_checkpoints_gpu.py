@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import csmri_oracle as O
-from conftest import PKG
+from conftest import PKG, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -71,8 +71,8 @@ def test_adversarial_checkpoint_resume_is_exact(tmp_path):
   ck = torch.load(path, map_location='cpu', weights_only=False)
   assert sorted(ck['runner']) == ['disc_optimizer', 'discriminator', 'gen_optimizer', 'generator']
   b = build_runner(c2, 'adversarial', '0', 'train')
-  conf, epoch, best = restore_checkpoint(path, b)
-  assert epoch == 1 and best == {'psnr': 1.0}
+  state = restore_checkpoint(path, b)
+  assert state['start_epoch'] == 1 and state['best_val_metrics'] == {'psnr': 1.0}
   g = torch.Generator().manual_seed(4)
   chans = [f for _, bn, drop, f in a.disc._layers if bn is not None and drop]
   masks = [(torch.rand(2, c, generator=g) < 0.5).float() * 2.0 for _ in range(3) for c in chans]
@@ -90,3 +90,55 @@ def test_adversarial_checkpoint_resume_is_exact(tmp_path):
   for (n, p), (_, q) in zip(list(a.gen.state_dict().items()) + list(a.disc.state_dict().items()),
                             list(b.gen.state_dict().items()) + list(b.disc.state_dict().items())):
     assert torch.equal(p.cpu(), q.cpu()), n
+
+
+@pytest.mark.gpu
+def test_resume_from_a_checkpoint_written_by_the_reference(tmp_path):
+  """SURVEY 8f-1 against fixtures F13: restore_checkpoint of a file the reference's own save_checkpoint wrote
+  (weights, BatchNorm statistics, both Adam states, epoch, best metrics), then what the reference computed
+  after saving: the generator's eval-mode prediction (2e-5) and the losses / parameters of the NEXT training
+  step (fp32 compute; 1e-4 relative -- the restored exp_avg / exp_avg_sq / step enter this update)."""
+  import numpy as np
+  import csmri_hip  # noqa: F401
+  from csmri_hip import ops
+  from utils.config import Configuration
+  from utils.checkpoints import restore_checkpoint
+  from models.utils import set_default_compute_dtype
+  from training import build_runner
+  set_default_compute_dtype('fp32')
+  golden = os.path.join(ROOT, 'tests', 'golden')
+  f = np.load(os.path.join(golden, 'F13_checkpoint_expected.npz'))
+  conf = Configuration.from_json(os.path.join(PKG, 'configs', '2-refinement.json'))
+  conf.batch_size = 2
+  conf.vgg_loss = {'seed': 19}
+  g, d = conf.generator_model, conf.discriminator_model
+  for m in (g['pretrained_model'], g['learnable_model'], d):
+    m['compute_dtype'] = 'fp32'
+  g['pretrained_model']['num_filters'] = 8
+  g['learnable_model']['encode_filters'] = [8, 16, 32]
+  g['learnable_model']['decode_filters'] = [16, 8]
+  d['num_filters_per_layer'] = [8, 16, 32, 64, 64, 64]
+  runner = build_runner(conf, 'adversarial', '0', 'train')
+  state = restore_checkpoint(os.path.join(golden, 'F13_reference_checkpoint.pth'), runner, '0')
+  assert state['start_epoch'] == 4 and state['best_val_metrics'] == {'psnr': 31.5}
+  assert runner.gen_optimizer.step_count == 1 and runner.disc_optimizer.step_count == 1
+  runner._set_test()
+  vb = O.synth_batch(2, 128, 128, acc=4, seed=901)
+  with torch.no_grad():
+    pred = runner.gen(vb['inp'].cuda(), vb['kspace'].cuda(), vb['mask'].cuda())['pred'].float().cpu()
+  ref = torch.from_numpy(f['eval_pred'])
+  assert float((pred - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+  runner.disc.injected_dropout = [torch.from_numpy(f['step1.mask%d' % j]) for j in range(9)]
+  losses, metrics = runner.train_epoch(Loader([O.synth_batch(2, 128, 128, acc=4, seed=902)]), 2)
+  for k, v in zip([str(s) for s in f['loss_names']], f['step1.losses']):
+    assert abs(losses[k].value - v) < 1e-4 * max(1.0, abs(v)), (k, losses[k].value, v)
+  assert abs(metrics['gen_psnr'].value - float(f['step1.gen_psnr'])) < 1e-3
+  sd = runner.gen.state_dict()
+  for k in f.files:
+    if not k.startswith('G2.') or 'num_batches' in k or 'running' in k:
+      continue
+    v = torch.from_numpy(f[k]).float()
+    dd = (sd[k[3:]].cpu().float() - v).abs()
+    # second Adam step: every parameter moved by ~lr; agreement to a small fraction of that
+    assert float((dd > 2e-5 * max(1.0, float(v.abs().max()))).float().mean()) < 0.02, k
+    assert float(dd.max()) < 4.1e-4 * max(1.0, float(v.abs().max())), (k, float(dd.max()))

@@ -941,3 +941,61 @@ def test_f11_multi_update_steps_pretraining_schedule_lr_schedulers_fp32(env):
         if 'running' in k or 'num_batches' in k:
           continue
         assert torch.equal(sg[k].cpu().float(), v.float()), k
+
+
+def test_image_pool_swaps_with_injected_decisions_match_oracle(env):
+  """the history pool of generated images (reference utils/image_pool.py:29-60 through
+  training/adversarial_training.py:33-40) on the device-side gather/scatter plan, over six steps with the
+  pool decisions injected on both sides: two filling steps (pool of 4, batch 2), then swaps -- both images
+  drawn, the same slot drawn twice in one batch (the second draw returns the image the first one stored), a
+  mixed step, no draw.  Learning rates are 0 on both sides, so nothing but the batch, the injected dropout
+  masks and the POOL CONTENTS moves the discriminator's losses: every step must match the oracle to fp32
+  rounding (2e-5)."""
+  Configuration, set_dtype = env
+  from training import build_runner
+  from csmri_hip import ops
+  f = load('F7_gan_step')
+  set_dtype('fp32')
+  conf = gan_conf(Configuration, 'fp32')
+  conf.discriminator_model['image_pool_size'] = 4
+  conf.generator_optimizer = dict(conf.generator_optimizer, learning_rate=0.0)
+  conf.discriminator_optimizer = dict(conf.discriminator_optimizer, learning_rate=0.0)
+  runner = build_runner(conf, 'adversarial', '0', 'train')
+  runner.gen.load_state_dict(sub(f, 'G0.'))
+  runner.disc.load_state_dict(sub(f, 'D0.'))
+  ops.bump_weight_epoch()
+  PG, SG = _split_sd(runner.gen.state_dict())
+  PD, SD = _split_sd(runner.disc.state_dict())
+  PG = {k: (v.requires_grad_(True) if not k.startswith('pretrained_model') else v) for k, v in PG.items()}
+  PD = {k: v.requires_grad_(True) for k, v in PD.items()}
+  PV = O.init_vgg(gen=torch.Generator().manual_seed(19))
+  gopt = O.make_adam([v for v in PG.values() if v.requires_grad], 0.0, 0.5, 0.999)
+  dopt = O.make_adam(PD.values(), 0.0, 0.5, 0.999)
+  pool = O.ImagePool(4)
+  decisions = [None, None, [(True, 1), (True, 3)], [(True, 2), (True, 2)], [(False, -1), (True, 0)],
+               [(False, -1), (False, -1)]]
+  g = torch.Generator().manual_seed(77)
+  small_unet = dict(O.UNET_CONF, encode_filters=[8, 16, 32], decode_filters=[16, 8])
+  small_disc = dict(O.DISC_CONF, filters=[8, 16, 32, 64, 64, 64])
+  u_def, d_def = O.unet_forward.__defaults__, O.disc_forward.__defaults__
+  O.unet_forward.__defaults__ = tuple(small_unet if isinstance(x, dict) else x for x in u_def)
+  O.disc_forward.__defaults__ = tuple(small_disc if isinstance(x, dict) else x for x in d_def)
+  try:
+    for step, dec in enumerate(decisions):
+      batch = O.synth_batch(2, 128, 128, acc=4, seed=700 + step)
+      masks = [(torch.rand(2, 64, 1, 1, generator=g) < 0.5).float() * 2.0 for _ in range(9)]
+      runner.disc.injected_dropout = [m.clone() for m in masks]
+      runner.pool_decisions = dec
+      losses, _ = runner.train_epoch(Loader([batch]), 1)
+      ref, _, _ = O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=pool,
+                                   dropout_masks=[masks[0:3], masks[3:6], masks[6:9]], pool_decisions=dec)
+      for k in ('disc_loss_gan', 'gen_loss_gan', 'gen_loss_FeatureMatching'):
+        got = losses[k].value
+        print('pool step %d %-26s hip %.7f oracle %.7f' % (step, k, got, ref[k]))
+        assert abs(got - ref[k]) < 2e-5 * max(1.0, abs(ref[k])), (step, k, got, ref[k])
+  finally:
+    O.unet_forward.__defaults__, O.disc_forward.__defaults__ = u_def, d_def
+  # the device pool holds exactly what the oracle's list holds
+  buf = runner.disc_input_fn.image_pool.buffer[:4, ..., 0].float().cpu()
+  want = torch.cat(pool.images, 0)[:, 0]
+  assert float((buf - want).abs().max()) < 2e-6
