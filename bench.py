@@ -9,6 +9,8 @@ N>1 is launched by the driver as torch.distributed.run with one rank per GPU (RC
   8 slices/GPU of 256x256 synthetic undersampled k-space: generator forward (frozen 3-block RecNet with
   3 data-consistency layers + U-Net), three discriminator forwards, two VGG19 forwards, discriminator
   backward + Adam, generator backward (through D and VGG) + Adam, gradient all-reduce.  Weak scaling.
+--config c5 (BASELINE config 5's data format; bf16, NOT the fp8 variant): the c3 step at 512x512 with
+  golden-angle radial undersampling (70 spokes), 2 slices/GPU.
 --config c2 (BASELINE config C2): one Runner._train_step of RecNet(5 blocks, 3 convs, 32 filters) with
   MSE loss on 64 slices/GPU of 256x256: 5 conv blocks + 5 data-consistency layers forward, their
   adjoints backward, Adam.
@@ -39,7 +41,9 @@ PEAK_HBM_GBS = 8000.0                           # HBM3E spec (same table; ~6.3 T
 GAN_GFLOP_PER_SLICE = 299.2   # algorithmic conv FLOPs of one 256^2 GAN step
 C2_GFLOP_PER_SLICE = 20.31    # RecNet 5/3/32 MSE step at 256^2
 SIZE = 256
-DEFAULT_BATCH = {'c3': 8, 'c2': 64}
+DEFAULT_BATCH = {'c3': 8, 'c2': 64, 'c5': 2}
+C5_GFLOP_PER_SLICE = 1196.8   # the GAN step at 512^2
+C5_SPOKES = 70                # ~8x undersampling needs ~70 radial spokes at 512^2
 N_HOST_BATCHES = 8
 
 
@@ -48,7 +52,7 @@ def parse():
   p.add_argument('--gpus', type=int, default=1)
   p.add_argument('--steps', type=int, default=250)
   p.add_argument('--warmup', type=int, default=10)
-  p.add_argument('--config', default='c3', choices=['c3', 'c2'])
+  p.add_argument('--config', default='c3', choices=['c3', 'c2', 'c5'])
   p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--no-roofline', action='store_true')
@@ -74,7 +78,7 @@ def build_runner(config, dtype, batch):
   from training import build_runner as _build
   import utils
   set_default_compute_dtype(dtype)
-  if config == 'c3':
+  if config in ('c3', 'c5'):
     conf = Configuration.from_json(os.path.join(PKG, 'configs', '2-refinement.json'))
     kind = 'adversarial'
   else:
@@ -318,10 +322,15 @@ def main():
   torch.cuda.set_device(local if torch.cuda.device_count() > local else 0)
   assert ws == max(1, args.gpus) or ws == 1, (ws, args.gpus)
 
-  from data.synthetic import synth_batch
+  from data.synthetic import synth_batch, synth_batch_radial
   runner, conf = build_runner(args.config, args.dtype, args.batch)
-  host_batches = [synth_batch(args.batch, SIZE, SIZE, acc=4, seed=conf.seed + 97 * rank + 100000 * i)
-                  for i in range(N_HOST_BATCHES)]
+  size = 512 if args.config == 'c5' else SIZE
+  if args.config == 'c5':
+    host_batches = [synth_batch_radial(args.batch, size, size, spokes=C5_SPOKES, seed=conf.seed + 97 * rank + 100000 * i)
+                    for i in range(N_HOST_BATCHES)]
+  else:
+    host_batches = [synth_batch(args.batch, size, size, acc=4, seed=conf.seed + 97 * rank + 100000 * i)
+                    for i in range(N_HOST_BATCHES)]
   dev = torch.device('cuda', torch.cuda.current_device())
 
   def loader_factory(n):
@@ -335,7 +344,7 @@ def main():
       return None
   runner._request_data = request
 
-  gan = args.config == 'c3'
+  gan = args.config in ('c3', 'c5')
   if gan:
     runner.overlap_streams = not args.no_overlap
     runner.prefetch_pretrained = not (args.no_prefetch or args.no_overlap)
@@ -378,11 +387,16 @@ def main():
     return
   slices = ws * args.batch * args.steps
   value = slices / dt
-  gf = GAN_GFLOP_PER_SLICE if gan else C2_GFLOP_PER_SLICE
+  gf = C5_GFLOP_PER_SLICE if args.config == 'c5' else (GAN_GFLOP_PER_SLICE if gan else C2_GFLOP_PER_SLICE)
   if gan:
     workload = ('C3/C4 2-refinement GAN step: frozen RecNet(3,3,32)+3 DC, UNET, CNNDiscriminator, '
                 'VGG19 loss, Adam x2; 256x256, 4x Cartesian, %d slices/GPU' % args.batch)
     metric = 'train slices/sec, 256x256 GAN refinement step'
+    if args.config == 'c5':
+      workload = ('C5 data format: the 2-refinement GAN step at 512x512, golden-angle radial undersampling '
+                  '(%d spokes), %d slices/GPU, bf16 convolutions + fp32 FFT (the fp8 variant is not built)'
+                  % (C5_SPOKES, args.batch))
+      metric = 'train slices/sec, 512x512 radial GAN refinement step'
     mode = 'eager' if args.no_graphs else ('hipGraph replay (one graph per step)' if ws == 1 else
                                            'hipGraph replay (4 segments, collectives eager)')
   else:
@@ -402,7 +416,7 @@ def main():
       'prefetch': 'frozen RecNet forward of batch t+1 on a side stream during step t' if prefetch_on else None,
       'launch_mode': mode,
       'config': {'workload': workload, 'per_gpu_batch': args.batch, 'global_batch': ws * args.batch,
-                 'parallelism': 'dp%d' % ws, 'image': [SIZE, SIZE]},
+                 'parallelism': 'dp%d' % ws, 'image': [size, size]},
       'algorithmic_tflops': round(value * gf / 1e3, 2),
       'final_losses': {k: round(v.value, 5) for k, v in losses.items()},
   }

@@ -31,6 +31,47 @@ def cartesian_mask(shape, acc, sample_n=8, rng=None):
   return np.fft.ifftshift(mask, axes=(-1, -2))
 
 
+def radial_mask(shape, n_lines, rng=None, golden_angle=True, rand=True, centred=False):
+  """Radial undersampling (BASELINE config 5; reference compressed_sensing.py:568-647 as the training
+  transform calls it, myImageTransformations.py:63-70: ``acceleration_factor`` is the NUMBER OF SPOKES).
+  Every spoke is a line through the k-space centre gridded to the nearest Cartesian sample; golden-angle
+  spokes continue across the slices of a batch from one random start angle, uniform spokes get a random
+  offset per slice.  Returns an integer (N, nx, nx) 0/1 mask, ifftshift-ed unless ``centred``."""
+  rng = np.random if rng is None else rng
+  n, nx, ny = shape
+  assert nx == ny, 'square slices only'
+  start = np.pi * rng.random() if rand else 0.0
+  if golden_angle:
+    step = np.pi / ((1.0 + np.sqrt(5.0)) / 2.0)
+    angles = start + step * np.arange(n_lines * n)
+  else:
+    angles = np.tile(np.arange(0, np.pi, np.pi / n_lines), n)
+    angles = angles + np.repeat(rng.random(n) * np.pi / n_lines, n_lines)
+  radius = np.arange(-nx / 2, nx / 2, 1.0)
+  # 1-based nearest sample of every (radius, spoke), wrapped into [1, nx]
+  col = np.round(np.outer(radius, np.cos(angles)) + 0.5) + nx / 2
+  row = np.round(np.outer(radius, np.sin(angles)) + 0.5) + ny / 2
+  col = np.where(col > nx, col - nx, col); col = np.where(col < 1, col + nx, col)
+  row = np.where(row > ny, row - ny, row); row = np.where(row < 1, row + ny, row)
+  mask = np.zeros((n, nx, ny), dtype=int)
+  slice_of = np.repeat(np.arange(n), n_lines * nx)
+  mask[slice_of, col.T.reshape(-1).astype(int) - 1, row.T.reshape(-1).astype(int) - 1] = 1
+  return mask if centred else np.fft.ifftshift(mask, axes=(-2, -1))
+
+
+def synth_batch_radial(b, h, w, spokes=70, seed=0):
+  """A batch as synth_batch() with golden-angle radial masks (one random start angle per batch)."""
+  m = radial_mask((b, h, w), spokes, rng=np.random.RandomState(seed + 7919))
+  parts = []
+  for i in range(b):
+    img = phantom(h, w, seed + 1000 + i)
+    k_u = m[i] * np.fft.fft2(img.astype(np.complex128), norm='ortho')
+    x_u = np.fft.ifft2(k_u, norm='ortho')
+    parts.append((_pack(x_u), _pack(k_u), _pack(m[i] * (1 + 1j)), _pack(img.astype(np.complex128))))
+  return {k: torch.from_numpy(np.stack([p[j] for p in parts]))
+          for j, k in enumerate(('inp', 'kspace', 'mask', 'target'))}
+
+
 def phantom(h, w, seed):
   """Seeded smooth random field plus a few ellipses, strictly positive, max 1."""
   rs = np.random.RandomState(seed)

@@ -280,3 +280,22 @@ def test_reference_written_checkpoint_loads_and_checkpoint_helpers(tmp_path):
   CK.prune_checkpoints(run, num_checkpoints_to_retain=1)
   assert sorted(f for f in os.listdir(run) if f.endswith('.pth')) == [names[-1]]
   assert os.path.exists(os.path.join(run, 'config_x.json'))
+
+
+def test_product_radial_mask_equals_the_reference_sample_for_sample():
+  """data.synthetic.radial_mask (the product's own generator for BASELINE config 5 batches) against F10,
+  written by the reference's radial_sampling (compressed_sensing.py:568-647): identical sample indices for
+  golden-angle and uniform spokes at 64^2, 128^2 and 512^2."""
+  import sys
+  import numpy as np
+  sys.path.insert(0, PKG)
+  from data.synthetic import radial_mask, synth_batch_radial
+  f = np.load(os.path.join(ROOT, 'tests', 'golden', 'F10_radial.npz'))
+  for tag in ('g512', 'u128', 'g64'):
+    n, nx, lines, golden = (int(v) for v in f['args_' + tag])
+    m = radial_mask((n, nx, nx), lines, rng=np.random.RandomState(4321), golden_angle=bool(golden))
+    assert np.array_equal(np.flatnonzero(m), f['idx_' + tag]), tag
+  b = synth_batch_radial(2, 64, 64, spokes=12, seed=3)
+  assert b['mask'].shape == (2, 2, 64, 64) and set(np.unique(b['mask'].numpy())) == {0.0, 1.0}
+  k = b['kspace'].numpy()
+  assert float(np.abs(k[b['mask'].numpy() == 0]).max()) == 0.0

@@ -999,3 +999,35 @@ def test_image_pool_swaps_with_injected_decisions_match_oracle(env):
   buf = runner.disc_input_fn.image_pool.buffer[:4, ..., 0].float().cpu()
   want = torch.cat(pool.images, 0)[:, 0]
   assert float((buf - want).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_config5_512_radial_full_width_step_vs_oracle(env, dtype):
+  """BASELINE config 5's data format and resolution through the whole step: 512 x 512 slices, golden-angle
+  radial undersampling with 70 spokes (the mask is NOT constant along W: per-element uint8 path of the DC
+  kernels), full-width networks, 2 slices, one AdversarialRunner step against the fp32 CPU oracle.  The
+  discriminator's logits are 13 x 13 here (reference discriminators.py:211-234 at 512^2).
+  fp32 compute: losses 1e-4, PSNR 1e-3 dB; bf16 compute: losses 2 %, PSNR 0.02 dB (scale = 0.25, see the
+  256^2 tests for why).  (The fp8 convolution variant of config 5 is not built.)"""
+  Configuration, set_dtype = env
+  from data.synthetic import synth_batch_radial
+  runner, conf = _full_width_runner(Configuration, set_dtype, dtype, batch_size=2)
+  batch = synth_batch_radial(2, 512, 512, spokes=70, seed=5)
+  assert float(batch['mask'][0, 0].std(dim=1).max()) > 0      # rows of the mask differ along W
+  g = torch.Generator().manual_seed(10)
+  chans = [f for _, bn, drop, f in runner.disc._layers if bn is not None and drop]
+  masks = [(torch.rand(2, c, 1, 1, generator=g) < 0.5).float() * 2.0 for _ in range(3) for c in chans]
+  PG, SG = _split_sd(runner.gen.state_dict())
+  PD, SD = _split_sd(runner.disc.state_dict())
+  PV = {k: v.detach().cpu().clone() for k, v in
+        runner.gen_criteria['VGG19'].criterion.vgg.state_dict().items() if k.startswith('blocks')}
+  hip = _hip_step(runner, batch, masks)
+  ref = _oracle_step(PG, SG, PD, SD, PV, batch, masks)
+  tol = 1e-4 if dtype == 'fp32' else 2e-2
+  for k in sorted(ref[0]):
+    rel = abs(hip[0][k] - ref[0][k]) / max(1e-12, abs(ref[0][k]))
+    print('config5 %s %-26s hip %.6e oracle %.6e rel %.3e' % (dtype, k, hip[0][k], ref[0][k], rel))
+    assert rel < tol, (k, hip[0][k], ref[0][k])
+  dpsnr = abs(hip[1]['gen_psnr'].value - ref[1]['gen_psnr'])
+  print('config5 %s gen_psnr hip %.5f oracle %.5f' % (dtype, hip[1]['gen_psnr'].value, ref[1]['gen_psnr']))
+  assert dpsnr < (1e-3 if dtype == 'fp32' else 0.02)
