@@ -356,6 +356,13 @@ def main():
         sys.stderr.write('bench: hipGraph capture failed (%r); running eager\n' % (e,))
         runner.disable_graphs()
         args.no_graphs = True
+  elif not args.no_graphs and ws == 1:
+    try:
+      runner.enable_graphs({k: v.to(dev) for k, v in host_batches[0].items()})
+    except Exception as e:
+      sys.stderr.write('bench: hipGraph capture failed (%r); running eager\n' % (e,))
+      runner.disable_graphs()
+      args.no_graphs = True
   else:
     args.no_graphs = True
   if args.warmup > 0:
@@ -403,7 +410,7 @@ def main():
     workload = ('C2 RecNet(5 blocks,3 convs,32 filters)+5 DC MSE training step incl. DC adjoints, Adam; '
                 '256x256, 4x Cartesian, %d slices/GPU' % args.batch)
     metric = 'train slices/sec, 256x256 RecNet (5-cascade DC-CNN) MSE step'
-    mode = 'eager'
+    mode = 'eager' if args.no_graphs else 'hipGraph replay (one graph per step)'
   line = {
       'metric': metric, 'value': round(value, 2), 'unit': 'slices/s',
       'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,

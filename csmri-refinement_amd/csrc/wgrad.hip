@@ -738,8 +738,11 @@ template <int CIN, int COUT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
   constexpr int CPR = CIN / 8;                      // 16-byte chunks per patch pixel
   constexpr int CQ = COUT / 8;                      // chunks per dY pixel (COUT = 16 for 8 real channels)
-  constexpr int CF = CIN / 16, NF = COUT / 16;
-  constexpr int MAXT = 16 / WAVES;                  // taps per wave (KH * KW <= 16)
+  // CIN = 8 (the 2-channel first layers, padded to 8): a 16-wide fragment of the (tap, channel) axis is a PAIR
+  // of taps x 8 channels; the work unit of a wave is such a pair instead of a tap
+  constexpr int CF = CIN >= 16 ? CIN / 16 : 1, NF = COUT / 16;
+  constexpr int UNITS = CIN >= 16 ? 16 : 8;         // taps, or tap pairs (KH * KW <= 16)
+  constexpr int MAXT = UNITS / WAVES;               // units per wave
   constexpr int XROWS = 1024 / (CPR * 16), YROWS = 1024 / (CQ * 16);   // rows per LDS-DMA instruction
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -821,17 +824,32 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
       }
 #pragma unroll
       for (int a = 0; a < MAXT; ++a) {
-        const int tap = wid + a * WAVES;
-        if (tap >= taps) break;                     // wave-uniform
-        const int ty = tap / p.KW, tx = tap - ty * p.KW;
-        const int rlo = prow + (2 * kc + ty) * TPW + tx, rhi = rlo + 4;
+        const int unit = wid + a * WAVES;
+        if constexpr (CIN >= 16) {
+          const int tap = unit;
+          if (tap >= taps) break;                     // wave-uniform
+          const int ty = tap / p.KW, tx = tap - ty * p.KW;
+          const int rlo = prow + (2 * kc + ty) * TPW + tx, rhi = rlo + 4;
 #pragma unroll
-        for (int c = 0; c < CF; ++c) {
-          const int ch = c * 2 + (tp >> 1);
-          const bf16x8_t xf = tr_frag(ximg, img_off<CPR>(rlo, ch) + (tp & 1) * 8, img_off<CPR>(rhi, ch) + (tp & 1) * 8);
+          for (int c = 0; c < CF; ++c) {
+            const int ch = c * 2 + (tp >> 1);
+            const bf16x8_t xf = tr_frag(ximg, img_off<CPR>(rlo, ch) + (tp & 1) * 8, img_off<CPR>(rhi, ch) + (tp & 1) * 8);
+#pragma unroll
+            for (int n = 0; n < NF; ++n)
+              acc[a][c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[n], acc[a][c][n], 0, 0, 0);
+          }
+        } else {
+          if (2 * unit >= taps) break;                // wave-uniform
+          // lanes tp = 0,1 address the first tap of the pair, tp = 2,3 the second (the last pair of an odd
+          // tap count repeats the first tap; its half of the result is never written)
+          int tap = 2 * unit + (tp >> 1);
+          if (tap >= taps) tap = 2 * unit;
+          const int ty = tap / p.KW, tx = tap - ty * p.KW;
+          const int rlo = prow + (2 * kc + ty) * TPW + tx, rhi = rlo + 4;
+          const bf16x8_t xf = tr_frag(ximg, rlo * 16 + (tp & 1) * 8, rhi * 16 + (tp & 1) * 8);
 #pragma unroll
           for (int n = 0; n < NF; ++n)
-            acc[a][c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[n], acc[a][c][n], 0, 0, 0);
+            acc[a][0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[n], acc[a][0][n], 0, 0, 0);
         }
       }
     }
@@ -846,16 +864,22 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
   }
 #pragma unroll
   for (int a = 0; a < MAXT; ++a) {
-    const int tap = wid + a * WAVES;
-    if (tap >= taps) break;
+    const int unit = wid + a * WAVES;
+    if ((CIN >= 16 ? unit : 2 * unit) >= taps) break;
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
       const int co = n * 16 + r16;
       if (co >= p.Cout) continue;
+      if constexpr (CIN >= 16) {
 #pragma unroll
-      for (int c = 0; c < CF; ++c) {
-        const int cc = tap * CIN + c * 16 + g * 4;
-        *(f32x4_t*)(p.slab + ((size_t)blockIdx.x * p.Cout + co) * p.NK + cc) = acc[a][c][n];
+        for (int c = 0; c < CF; ++c) {
+          const int cc = unit * CIN + c * 16 + g * 4;
+          *(f32x4_t*)(p.slab + ((size_t)blockIdx.x * p.Cout + co) * p.NK + cc) = acc[a][c][n];
+        }
+      } else {
+        const int tap = 2 * unit + (g >> 1);            // fragment rows 0-7: first tap, 8-15: second
+        if (tap < taps)
+          *(f32x4_t*)(p.slab + ((size_t)blockIdx.x * p.Cout + co) * p.NK + tap * 8 + (g & 1) * 4) = acc[a][0][n];
       }
     }
   }
@@ -865,7 +889,7 @@ static int wpatch_cout(const csmri_wgrad_desc* d) { return d->Cout <= 16 ? 16 : 
 static bool wpatch_eligible(const csmri_wgrad_desc* d) {
   static const char* off = getenv("CSMRI_NO_WPATCH");          // A/B knob
   if (off || d->dtype != CSMRI_BF16 || d->stride != 1) return false;
-  if (!(d->Cin == 32 || d->Cin == 64)) return false;
+  if (!(d->Cin == 8 || d->Cin == 32 || d->Cin == 64)) return false;
   if (!(d->Cout == 8 || d->Cout == 16 || d->Cout == 32 || d->Cout == 64)) return false;
   if (d->KH * d->KW > 16 || d->KH < 1 || d->KW < 1) return false;
   if (d->in1 && (d->c0 % 8)) return false;
@@ -891,6 +915,11 @@ static int launch_wpatch(const WParams& p, hipStream_t st) {
 }
 static int wpatch_launch(const WParams& p, const csmri_wgrad_desc* d, hipStream_t st) {
   const int co = wpatch_cout(d);
+  if (d->Cin == 8) {
+    if (co == 16) return launch_wpatch<8, 16, 4>(p, st);
+    if (co == 32) return launch_wpatch<8, 32, 4>(p, st);
+    return launch_wpatch<8, 64, 4>(p, st);
+  }
   if (d->Cin == 32) {
     if (co == 16) return launch_wpatch<32, 16, 4>(p, st);
     if (co == 32) return launch_wpatch<32, 32, 4>(p, st);

@@ -96,22 +96,65 @@ class Runner(BaseRunner):
   def predict(self, batch):
     return self.model(*self.train_model_input_fn(batch, use_batch_transform=False))
 
+  def _step_body(self, batch):
+    """zero_grad -> forward -> criteria -> weighted sum -> backward; returns (loss tensors, total, out)."""
+    self.optimizer.zero_grad()
+    out = self.model(*self.train_model_input_fn(batch))
+    names, losses = [], []
+    for name, criterion in self.criteria.items():
+      names.append(name)
+      losses.append(criterion(out, batch))
+    total = torch.sum(torch.stack(losses) * self.loss_weights)
+    total.backward()
+    from csmri_hip import ops
+    ops.join_wgrad_stream()
+    return names, [l.detach() for l in losses], total.detach(), out
+
+  def enable_graphs(self, example_batch, warmup=2):
+    """Capture the whole step (reference training/runner.py:154-178) as ONE hipGraph for this batch shape and
+    replay it per step: the RecNet step is ~150 short launches and eager issue leaves the GPU idle between
+    them.  Single process only (with data parallelism the gradient exchange sits between backward and Adam)."""
+    assert dist_utils.world_size() == 1, 'graph mode of the standard runner is single-GPU'
+    static = {k: v.detach().clone() for k, v in example_batch.items()}
+    self._set_train()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(warmup):
+        self._step_body(static)
+        self.optimizer.step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
+      names, losses, total, out = self._step_body(static)
+      self.optimizer.step()
+    self.optimizer.step_count -= 1                   # the capture pass executed nothing
+    self._graph = {'graph': g, 'static': static, 'names': names, 'losses': losses, 'total': total, 'out': out}
+    return self
+
+  def disable_graphs(self):
+    self._graph = None
+
   def _train_step(self, loader):
     batch = self._request_data(loader)
     if batch is None:
       return 0, None, None
-    self.optimizer.zero_grad()
-    out = self.model(*self.train_model_input_fn(batch))
-    losses, loss_metrics = [], {}
-    for name, criterion in self.criteria.items():
-      loss = criterion(out, batch)
-      losses.append(loss)
-      loss_metrics['loss_' + name] = get_loss_metric(loss.detach())
-    total = torch.sum(torch.stack(losses) * self.loss_weights)
-    total.backward()
-    self.optimizer.start_allreduce()
-    self.optimizer.step()
-    loss_metrics['loss'] = get_loss_metric(total.detach())
+    G = getattr(self, '_graph', None)
+    if G is not None:
+      torch._foreach_copy_(list(G['static'].values()), [batch[k] for k in G['static']])
+      G['graph'].replay()
+      self.optimizer.step_count += 1
+      names, losses, total, out, batch = G['names'], [l.clone() for l in G['losses']], G['total'].clone(), G['out'], G['static']
+    else:
+      names, losses, total, out = self._step_body(batch)
+      self.optimizer.start_allreduce()
+      self.optimizer.step()
+    loss_metrics = {'loss_' + n: get_loss_metric(l) for n, l in zip(names, losses)}
+    loss_metrics['loss'] = get_loss_metric(total)
     return 1, loss_metrics, (batch, out)
 
   def _val_step(self, loader, compute_metrics=True):

@@ -1031,3 +1031,29 @@ def test_config5_512_radial_full_width_step_vs_oracle(env, dtype):
   dpsnr = abs(hip[1]['gen_psnr'].value - ref[1]['gen_psnr'])
   print('config5 %s gen_psnr hip %.5f oracle %.5f' % (dtype, hip[1]['gen_psnr'].value, ref[1]['gen_psnr']))
   assert dpsnr < (1e-3 if dtype == 'fp32' else 0.02)
+
+
+def test_recnet_runner_graph_replay_equals_eager(env):
+  """Runner.enable_graphs (the RecNet MSE step as one hipGraph) replays exactly the eager kernel sequence:
+  losses and parameters after 3 steps are bit-identical to the eager run (bf16 compute, 128^2, 3 blocks)."""
+  Configuration, set_dtype = env
+  from training import build_runner
+  set_dtype('bf16')
+
+  def make():
+    conf = recnet_conf(Configuration, 3, 'bf16')
+    torch.manual_seed(5)
+    return build_runner(conf, 'standard', '0', 'train')
+  batches = [{k: v.cuda() for k, v in O.synth_batch(2, 128, 128, acc=4, seed=80 + i).items()} for i in range(3)]
+  a, b = make(), make()
+  a._set_train()
+  for _ in range(2):                       # the capture's warm-up steps, eagerly
+    a._step_body(batches[0])
+    a.optimizer.step()
+  la, _ = a.train_epoch(Loader(batches), 1)
+  b.enable_graphs(batches[0], warmup=2)
+  lb, _ = b.train_epoch(Loader(batches), 1)
+  assert {k: v.value for k, v in la.items()} == {k: v.value for k, v in lb.items()}
+  for (k, p), (_, q) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+    assert torch.equal(p, q), k
+  assert a.optimizer.step_count == b.optimizer.step_count == 5
