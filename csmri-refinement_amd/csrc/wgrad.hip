@@ -754,6 +754,7 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
   const int tiles_x = (p.Wo + 15) >> 4, tiles_y = (p.Ho + 15) >> 4, ntiles = p.B * tiles_x * tiles_y;
   const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
   const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3, r16 = lane & 15;
+  const int qoff = blockIdx.y * COUT;               // this workgroup's slice of the output channels (grid.y > 1: Cin = 128)
 
   // bias gradient = column sums of dY: one more MFMA per dY fragment against a fragment of ones (wave 0)
   f32x4_t bacc[NF];
@@ -802,8 +803,8 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
       const int k = i * YROWS + yr;                 // tile pixel: row k >> 4, column k & 15
       const int oy = y0 + (k >> 4), ox = x0 + (k & 15);
       const int chunk = (img_off<CQ>(k, yslot) >> 4) % CQ;
-      const bool ok = oy < p.Ho && ox < p.Wo && chunk * 8 < p.Cout;
-      const char* src = ok ? p.dy + ((((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dyps + chunk * 8) * 2 : w_zero_page;
+      const bool ok = oy < p.Ho && ox < p.Wo && qoff + chunk * 8 < p.Cout;
+      const char* src = ok ? p.dy + ((((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dyps + qoff + chunk * 8) * 2 : w_zero_page;
       __builtin_amdgcn_global_load_lds((wgptr_t)src, (wlptr_t)(yimg + i * 1024), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
     float* part = p.slab + (size_t)gridDim.x * p.Cout * p.NK + (size_t)blockIdx.x * p.Cout;
 #pragma unroll
     for (int n = 0; n < NF; ++n)
-      if (n * 16 + r16 < p.Cout) part[n * 16 + r16] = bacc[n][0];
+      if (qoff + n * 16 + r16 < p.Cout) part[qoff + n * 16 + r16] = bacc[n][0];
   }
 #pragma unroll
   for (int a = 0; a < MAXT; ++a) {
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
     if ((CIN >= 16 ? unit : 2 * unit) >= taps) break;
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
-      const int co = n * 16 + r16;
+      const int co = qoff + n * 16 + r16;
       if (co >= p.Cout) continue;
       if constexpr (CIN >= 16) {
 #pragma unroll
@@ -889,7 +890,7 @@ static int wpatch_cout(const csmri_wgrad_desc* d) { return d->Cout <= 16 ? 16 : 
 static bool wpatch_eligible(const csmri_wgrad_desc* d) {
   static const char* off = getenv("CSMRI_NO_WPATCH");          // A/B knob
   if (off || d->dtype != CSMRI_BF16 || d->stride != 1) return false;
-  if (!(d->Cin == 8 || d->Cin == 32 || d->Cin == 64)) return false;
+  if (!(d->Cin == 8 || d->Cin == 32 || d->Cin == 64 || (d->Cin == 128 && d->Cout == 64))) return false;
   if (!(d->Cout == 8 || d->Cout == 16 || d->Cout == 32 || d->Cout == 64)) return false;
   if (d->KH * d->KW > 16 || d->KH < 1 || d->KW < 1) return false;
   if (d->in1 && (d->c0 % 8)) return false;
@@ -901,15 +902,21 @@ static int wpatch_groups(const csmri_wgrad_desc* d) {
   static const char* env = getenv("CSMRI_WPATCH_BLOCKS");        // tuning knob: persistent workgroups
   long long g = env ? atoi(env) : 512;
   if (g > tiles / 4) g = tiles / 4;                              // at least 4 tiles per workgroup
+  // every workgroup leaves a slab of Cout x NK floats: keep the slab traffic below the operands' own bytes
+  const long long slab = (long long)d->Cout * d->KH * d->KW * d->Cin * 4;
+  const long long operands = ((long long)d->B * d->Hin * d->Win * d->Cin + (long long)d->B * d->Ho * d->Wo * d->Cout) * 2;
+  if (!env && g * slab > operands) g = operands / slab;
+  if (g < 128) g = 128;
+  if (g > tiles) g = tiles;
   return (int)(g < 1 ? 1 : g);
 }
 template <int CIN, int COUT, int WAVES>
-static int launch_wpatch(const WParams& p, hipStream_t st) {
+static int launch_wpatch(const WParams& p, hipStream_t st, int qtiles = 1) {
   const int TPW = 16 + p.KW - 1, TPH = 16 + p.KH - 1;
   const int xrows = 1024 / (CIN / 8 * 16);
   const int lds = ((TPH * TPW + xrows - 1) / xrows) * 1024 + 256 * COUT * 2;
   CSMRI_SET_MAX_LDS((wpatch_kernel<CIN, COUT, WAVES>), lds);
-  hipLaunchKernelGGL((wpatch_kernel<CIN, COUT, WAVES>), dim3(p.splitk), dim3(WAVES * 64), lds, st, p);
+  hipLaunchKernelGGL((wpatch_kernel<CIN, COUT, WAVES>), dim3(p.splitk, qtiles), dim3(WAVES * 64), lds, st, p);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
@@ -925,6 +932,7 @@ static int wpatch_launch(const WParams& p, const csmri_wgrad_desc* d, hipStream_
     if (co == 32) return launch_wpatch<32, 32, 4>(p, st);
     return launch_wpatch<32, 64, 4>(p, st);
   }
+  if (d->Cin == 128) return launch_wpatch<128, 32, 8>(p, st, 2);     // two workgroups per tile, 32 output channels each
   if (co == 16) return launch_wpatch<64, 16, 4>(p, st);
   if (co == 32) return launch_wpatch<64, 32, 4>(p, st);
   return launch_wpatch<64, 64, 8>(p, st);
@@ -1019,7 +1027,8 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
 extern "C" int csmri_wgrad_kernel_name(const csmri_wgrad_desc* d, char* buf, int n) {
   CSMRI_CHECK_ARG(d && buf && n > 0);
   if (wpatch_eligible(d)) {
-    snprintf(buf, n, "wpatch_kernel<%d, %d, %d>", d->Cin, wpatch_cout(d), d->Cin == 64 && wpatch_cout(d) == 64 ? 8 : 4);
+    snprintf(buf, n, "wpatch_kernel<%d, %d, %d>", d->Cin, d->Cin == 128 ? 32 : wpatch_cout(d),
+             d->Cin == 128 ? 8 : (d->Cin == 64 && wpatch_cout(d) == 64 ? 8 : 4));
     return CSMRI_OK;
   }
   WConfig c = pick_wconfig(d);
