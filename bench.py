@@ -248,7 +248,7 @@ def cpu_baseline_c2(runner, host_batch, sample_b=16, steps=3, all_threads=False)
                     'steps after 1 warm-up, per thread count' % (sample_b, steps)}, psnr
 
 
-def roofline(runner, loader_factory, dtype, steps=2):
+def roofline(runner, loader_factory, dtype, steps=2, config='c3'):
   """Instrumented eager steps on ONE stream: HIP events (torch's current stream = the stream the library
   launches on) around every conv-library launch and every HBM-bound entry point."""
   import torch
@@ -289,7 +289,7 @@ def roofline(runner, loader_factory, dtype, steps=2):
   traffic, traffic_src = None, None
   for tname in ('r02_pmc_bench_traffic.json', 'r01_pmc_bench_traffic.json'):
     tpath = os.path.join(ROOT, 'profiles', tname)
-    if traffic is None and os.path.exists(tpath):
+    if config == 'c3' and dtype == 'bf16' and traffic is None and os.path.exists(tpath):   # the PMC passes ran this workload
       for name, rec in json.load(open(tpath)).items():
         if dom in name:
           traffic = round(rec['fetch_bytes_per_launch'] + rec['write_bytes_per_launch'])
@@ -394,7 +394,7 @@ def main():
   prefetch_on = bool(getattr(runner, 'prefetch_pretrained', False))
   rl_out = None
   if not args.no_roofline:
-    rl_out = roofline(runner, loader_factory, args.dtype)
+    rl_out = roofline(runner, loader_factory, args.dtype, config=args.config)
   if ws > 1:
     torch.distributed.barrier()
   if rank != 0:
