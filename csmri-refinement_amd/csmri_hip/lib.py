@@ -47,6 +47,7 @@ class GConvDesc(C.Structure):
       ('splitk', i32), ('slab', vp), ('flags', i32),
       ('out_halo', vp), ('halo_pix_stride', i32), ('win_y0', i32), ('win_x0', i32), ('win_h', i32),
       ('win_w', i32),
+      ('in_dequant', vp), ('w_dequant', vp),
   ]
 
 
@@ -90,6 +91,8 @@ _SIGS = {
     'csmri_pack_weight': (i32, [i32, i32, vp, i32, i32, i32, i32, vp, C.POINTER(i32),
                                 C.POINTER(i64), C.POINTER(i32), vp]),
     'csmri_pack_weight_multi': (i32, [vp, i32, vp]),
+    'csmri_absmax': (i32, [i32, vp, i64, vp, vp]),
+    'csmri_quantize_fp8': (i32, [i32, vp, vp, i64, vp, vp, vp]),
     'csmri_wgrad': (i32, [C.POINTER(WGradDesc), vp]),
     'csmri_wgrad_slab_bytes': (sz, [C.POINTER(WGradDesc)]),
     'csmri_wgrad_suggest_splitk': (i32, [C.POINTER(WGradDesc)]),

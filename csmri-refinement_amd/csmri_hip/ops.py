@@ -14,6 +14,8 @@ import torch
 from . import lib
 from .lib import F32, BF16, BORDER_ZERO, BORDER_REFLECT
 
+FP8 = 2               # CSMRI_FP8: OCP e4m3fn operands of the fp8 convolution variant
+
 _EPOCH = [0]          # bumped whenever trainable weights change (optimizer step / load)
 
 
@@ -153,6 +155,8 @@ class ConvLayer(object):
     self._packs = {}
     self._bias_pad = None
     self.train_weights = True               # False: skip wgrad (e.g. D during the G backward)
+    self.fp8 = False                        # True: forward products on fp8 operands where the shape allows
+    self._pack8 = None
 
   # -- packs ---------------------------------------------------------------
   def _pack(self, mode):
@@ -176,6 +180,39 @@ class ConvLayer(object):
              buf.data_ptr(), C.byref(kp), C.byref(cs), C.byref(tw), stream())
     self._packs[key] = (epoch, buf, kp.value, cs.value, tw.value)
     return buf, kp.value, cs.value, tw.value
+
+  def fp8_ok(self, x0, x1):
+    """The fp8 variant's shape rules (include/csmri_hip.h, csmri_gconv_desc.in_dequant)."""
+    if not self.fp8 or self.dtype != torch.bfloat16 or self.cin_p % 128 or self.cout_p % 64:
+      return False
+    if not x0.is_contiguous() or (x1 is not None and (not x1.is_contiguous() or x0.shape[3] % 16)):
+      return False
+    return True
+
+  def _pack_fp8(self):
+    """Forward pack in fp8: the fp32 forward pack quantised with one power-of-two scale."""
+    epoch = _weight_epoch(self)
+    ent = self._pack8
+    if ent is not None and ent[0] == epoch and ent[1].device == self.weight.device:
+      return ent[1], ent[2], ent[3]
+    dev = self.weight.device
+    nbytes = lib.raw('csmri_pack_weight_bytes')(0, F32, self.cout, self.cin, self.kh, self.kw)
+    tmp = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    kp, cs, tw = C.c_int(0), C.c_longlong(0), C.c_int(0)
+    w = self.weight.detach()
+    assert w.is_contiguous() and w.dtype == torch.float32
+    lib.call('csmri_pack_weight', 0, F32, w.data_ptr(), self.cout, self.cin, self.kh, self.kw,
+             tmp.data_ptr(), C.byref(kp), C.byref(cs), C.byref(tw), stream())
+    if ent is not None and ent[1].device == dev:
+      q, scales = ent[1], ent[3]
+    else:
+      q = torch.empty(tmp.numel(), dtype=torch.uint8, device=dev)
+      scales = torch.empty(3, dtype=torch.float32, device=dev)   # amax, scale, 1/scale
+    lib.call('csmri_absmax', F32, tmp.data_ptr(), tmp.numel(), scales.data_ptr(), stream())
+    lib.call('csmri_quantize_fp8', F32, tmp.data_ptr(), q.data_ptr(), tmp.numel(), scales.data_ptr(),
+             scales.data_ptr() + 4, stream())
+    self._pack8 = (epoch, q, kp.value, scales)
+    return q, kp.value, scales
 
   def bias_padded(self):
     if self.bias is None:
@@ -296,6 +333,29 @@ class _Timed(object):
     return False
 
 
+def absmax(x):
+  """max |x| of a contiguous fp32 / bf16 tensor as a device scalar [1] (csmri_absmax)."""
+  _need_gpu(x)
+  assert x.is_contiguous()
+  out = torch.empty(1, dtype=torch.float32, device=x.device)
+  lib.call('csmri_absmax', dt_of(x), x.data_ptr(), x.numel(), out.data_ptr(), stream())
+  return out
+
+
+def quantize_fp8(x, amax=None):
+  """(q, scales): q = e4m3fn(x * scale) as uint8 of x's shape, scales = device [scale, 1/scale] with the
+  power-of-two scale 2^(7 - floor(log2 amax)) (csmri_quantize_fp8; amax defaults to max |x|)."""
+  _need_gpu(x)
+  assert x.is_contiguous() and x.numel() % 16 == 0
+  if amax is None:
+    amax = absmax(x)
+  q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+  scales = torch.empty(2, dtype=torch.float32, device=x.device)
+  lib.call('csmri_quantize_fp8', dt_of(x), x.data_ptr(), q.data_ptr(), x.numel(), amax.data_ptr(),
+           scales.data_ptr(), stream())
+  return q, scales
+
+
 def _gconv_run(d, want_stats, flops=0.0):
   splitk = lib.raw('csmri_gconv_suggest_splitk')(C.byref(d))
   if want_stats:
@@ -352,13 +412,31 @@ def conv_forward(layer, x0, x1=None, use_bias=True, act_slope=1.0, want_stats=Fa
   ho, wo = layer.out_hw(h, w)
   odt = out_dtype or layer.dtype
   y = torch.empty(b, ho, wo, layer.cout_p, dtype=odt, device=x0.device)
-  wp, kp, _, tw = layer._pack(0)
   pl, pr, pt, pb = layer.pads
   d = lib.GConvDesc()
-  d.dtype, d.out_dtype = dt_of(x0), dt_of(y)
-  d.in0, d.in0_pix_stride = x0.data_ptr(), x0.stride(2)
-  if x1 is not None:
-    d.in1, d.in1_pix_stride, d.c0 = x1.data_ptr(), x1.stride(2), c0
+  keep8 = None
+  if layer.fp8_ok(x0, x1):
+    # fp8 variant: both operands rounded to e4m3fn with per-tensor power-of-two scales (a concatenated
+    # input shares one scale: the larger of the two maxima); accumulate / epilogue / output unchanged
+    wp, kp, wsc = layer._pack_fp8()
+    tw = layer.kw
+    amax = absmax(x0)
+    if x1 is not None:
+      amax = torch.maximum(amax, absmax(x1))
+    q0, xsc = quantize_fp8(x0, amax)
+    q1 = quantize_fp8(x1, amax)[0] if x1 is not None else None
+    keep8 = (q0, q1, xsc, wsc)
+    d.dtype, d.out_dtype = FP8, dt_of(y)
+    d.in0, d.in0_pix_stride = q0.data_ptr(), q0.stride(2)
+    if q1 is not None:
+      d.in1, d.in1_pix_stride, d.c0 = q1.data_ptr(), q1.stride(2), c0
+    d.in_dequant, d.w_dequant = xsc.data_ptr() + 4, wsc.data_ptr() + 8
+  else:
+    wp, kp, _, tw = layer._pack(0)
+    d.dtype, d.out_dtype = dt_of(x0), dt_of(y)
+    d.in0, d.in0_pix_stride = x0.data_ptr(), x0.stride(2)
+    if x1 is not None:
+      d.in1, d.in1_pix_stride, d.c0 = x1.data_ptr(), x1.stride(2), c0
   d.B, d.Hin, d.Win, d.Cin = b, h, w, cin
   d.upsample, d.border = int(layer.upsample), layer.border
   d.TH, d.TW, d.in_s = layer.kh, tw, layer.stride     # tw >= kw: zero taps pad few-channel filters

@@ -278,9 +278,10 @@ extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   if (gconv_glds256_eligible(d)) return gconv_glds256_splitk(d);
   GConfig c = pick_config(d);
   if (gconv_glds_eligible(d)) { c.BM = 128; c.BN = gconv_glds_bn(d); }
+  if (d->dtype == CSMRI_FP8) { c.BM = 128; c.BN = gconv_fp8_bn(d); c.KC = 1; }
   int nclass = d->nclass > 0 ? d->nclass : 1;
   long long tiles = (long long)cdiv(desc_M(d), c.BM) * cdiv(d->Cout, c.BN) * nclass;
-  int bke = (d->dtype == CSMRI_BF16 ? 32 : 16) * c.KC;
+  int bke = d->dtype == CSMRI_FP8 ? 128 : (d->dtype == CSMRI_BF16 ? 32 : 16) * c.KC;
   int nsteps = cdiv((long long)d->TH * d->TW * d->Cin, bke);
   // measured (tools/bench_conv.py, main + reduce; bench.py): from ~224 tiles on the two-buffer kernel without
   // split-K beats 2-3 slices + reduce (36 vs 44 us on a 256-tile layer, +2 % on the step); ~192-tile problems want
@@ -309,7 +310,8 @@ static int launch_gconv(const GParams& p, hipStream_t st) {
 
 static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
   CSMRI_CHECK_ARG(d && d->in0 && d->w && d->out);
-  CSMRI_CHECK_ARG(d->dtype == CSMRI_F32 || d->dtype == CSMRI_BF16);
+  CSMRI_CHECK_ARG(d->dtype == CSMRI_F32 || d->dtype == CSMRI_BF16 || d->dtype == CSMRI_FP8);
+  if (d->dtype == CSMRI_FP8 && !gconv_fp8_eligible(d)) return CSMRI_E_UNSUPPORTED;
   CSMRI_CHECK_ARG(d->out_dtype == CSMRI_F32 || d->out_dtype == CSMRI_BF16);
   CSMRI_CHECK_ARG(d->Cin > 0 && d->Cin % 8 == 0 && d->Cout > 0 && d->Cout % 8 == 0);
   CSMRI_CHECK_ARG(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Ho > 0 && d->Wo > 0);
@@ -343,7 +345,7 @@ static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
     if ((uintptr_t)d->out_halo & 15) return CSMRI_E_ALIGN;
   }
   p.M = desc_M(d);
-  const int bke = (d->dtype == CSMRI_BF16 ? 32 : 16) * c.KC;
+  const int bke = d->dtype == CSMRI_FP8 ? 128 : (d->dtype == CSMRI_BF16 ? 32 : 16) * c.KC;
   p.nsteps = cdiv((long long)d->TH * d->TW * d->Cin, bke);
   CSMRI_CHECK_ARG((long long)p.nsteps * bke <= d->Kp);
   p.steps_per_split = cdiv(p.nsteps, splitk);
@@ -352,6 +354,7 @@ static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
   p.wo_shift = lg2(d->Wo); p.howo_shift = lg2((long long)d->Ho * d->Wo);
   if (p.wo_shift < 0 || p.howo_shift < 0) p.wo_shift = p.howo_shift = -1;
   p.tap_inner = 0;
+  p.dq0 = d->dtype == CSMRI_FP8 ? d->in_dequant : nullptr; p.dq1 = d->dtype == CSMRI_FP8 ? d->w_dequant : nullptr;
   p.dense_out = !d->out_halo && nclass == 1 && d->out_sy == 1 && d->out_sx == 1 && d->out_oy == 0 && d->out_ox == 0 &&
                 d->Hout_t == d->Ho && d->Wout_t == d->Wo;
   const long long in_px = (long long)d->B * d->Hin * d->Win, out_px = (long long)d->B * d->Hout_t * d->Wout_t;
@@ -373,6 +376,7 @@ static int launch_reduce(const GParams& p, hipStream_t st) {
 // template instance csmri_gconv dispatches to for this problem, spelled as rocprofv3 prints it
 extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n) {
   CSMRI_CHECK_ARG(d && buf && n > 0);
+  if (d->dtype == CSMRI_FP8) { gconv_fp8_kernel_name(d, buf, n); return CSMRI_OK; }
   if (pconv_eligible(d)) { snprintf(buf, n, "pconv_kernel<8>"); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (gconv8p_eligible(d)) { snprintf(buf, n, "gconv8p_kernel"); return CSMRI_OK; }
@@ -399,6 +403,12 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
   int rc = build_params(d, p, c);
   if (rc != CSMRI_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == CSMRI_FP8) {
+    rc = gconv_fp8_launch(p, d, st);
+    if (rc != CSMRI_OK) return rc;
+    if (p.splitk > 1 && !(d->flags & CSMRI_GCONV_DEFER_REDUCE)) return launch_reduce(p, st);
+    return CSMRI_OK;
+  }
   if (pconv_eligible(d)) return pconv_launch(p, d, st);
   if (tconv_eligible(d)) return tconv_launch(p, d, st);
   if (gconv_glds_eligible(d)) {

@@ -19,6 +19,7 @@ struct GParams {
   int dense_out;              // output position index == m (no window / stride / offset / classes): no division at all
   int off32;                  // every input / output byte offset fits 32 bits
   int tap_inner;              // gconv8p: K order (64-channel chunk, tap) instead of (tap, chunk)
+  const float* dq0; const float* dq1;   // fp8 operands: device scalars whose product dequantises the accumulators
 };
 
 // where output position (b, ty, tx) of the tensor goes: window -> dense `out`, else halo buffer
@@ -68,3 +69,9 @@ int gconv_glds256_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_
 int gconv8p_eligible(const csmri_gconv_desc* d);
 int gconv8p_splitk(const csmri_gconv_desc* d);
 int gconv8p_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
+
+// gconv_fp8.hip
+int gconv_fp8_eligible(const csmri_gconv_desc* d);
+int gconv_fp8_bn(const csmri_gconv_desc* d);
+int gconv_fp8_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
+void gconv_fp8_kernel_name(const csmri_gconv_desc* d, char* buf, int n);

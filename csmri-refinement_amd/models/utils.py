@@ -12,13 +12,29 @@ import torch.nn as nn
 import csmri_hip
 from csmri_hip import ops
 
+# 'fp8' (BASELINE config 5): bf16 activations / backward, forward products of the trainable convolutions on
+# e4m3fn operands wherever the shape allows (ops.ConvLayer.fp8_ok); everything else exactly the bf16 path
 COMPUTE_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32,
-                  'bfloat16': torch.bfloat16, 'float32': torch.float32}
+                  'bfloat16': torch.bfloat16, 'float32': torch.float32, 'fp8': torch.bfloat16}
 _DEFAULT_DTYPE = [torch.bfloat16]
+_FP8_FORWARD = [False]
 
 
 def set_default_compute_dtype(name_or_dtype):
   _DEFAULT_DTYPE[0] = COMPUTE_DTYPES.get(name_or_dtype, name_or_dtype)
+  _FP8_FORWARD[0] = name_or_dtype == 'fp8'
+
+
+def set_fp8_forward(module, on=True):
+  """Switch the fp8 forward variant of every trainable convolution under ``module``."""
+  n = 0
+  for m in module.modules():
+    if isinstance(m, ConvParams):
+      m.fp8 = bool(on)
+      if m.layer is not None and not m.layer.frozen:
+        m.layer.fp8 = bool(on)
+        n += 1
+  return n
 
 
 def default_compute_dtype():
@@ -65,6 +81,7 @@ class ConvParams(nn.Module):
     self.layer = ops.ConvLayer(self.weight, self.bias, stride, pads, border, dtype,
                                upsample=upsample, frozen=frozen)
     self._layer_args = (stride, pads, border, dtype, upsample, frozen)
+    self.layer.fp8 = bool(getattr(self, 'fp8', _FP8_FORWARD[0])) and not frozen
     return self.layer
 
   def _apply(self, fn, *a, **k):

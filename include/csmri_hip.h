@@ -35,6 +35,7 @@ extern "C" {
 
 #define CSMRI_F32 0
 #define CSMRI_BF16 1
+#define CSMRI_FP8 2   /* OCP e4m3fn, per-tensor power-of-two scale: operand type of the fp8 csmri_gconv variant only */
 
 #define CSMRI_OK 0
 #define CSMRI_E_ARG (-1)
@@ -72,7 +73,7 @@ int csmri_shutdown(void);
  *   weights w + z*w_class_stride and output offset (z>>1, z&1)).
  * ---------------------------------------------------------------------- */
 typedef struct csmri_gconv_desc {
-  int dtype;                 /* CSMRI_F32 / CSMRI_BF16: type of in, w */
+  int dtype;                 /* CSMRI_F32 / CSMRI_BF16 / CSMRI_FP8: type of in, w */
   int out_dtype;             /* type of out */
   /* input: channels [0,c0) from in0, [c0,Cin) from in1 (in1 may be NULL) */
   const void* in0; const void* in1;
@@ -105,6 +106,10 @@ typedef struct csmri_gconv_desc {
    * (g_src is indexed the same way); all other positions go, without actgrad, to `out_halo`
    * ([B, Hout_t, Wout_t] extents, only those positions are touched).  NULL: no window. */
   void* out_halo; int halo_pix_stride; int win_y0, win_x0, win_h, win_w;
+  /* dtype == CSMRI_FP8: device scalars (csmri_quantize_fp8's scales[1] of the input and of the packed
+   * weights) whose product multiplies the fp32 accumulators before the epilogue; NULL = 1.  The fp8
+   * variant needs Cin % 128 == 0, c0 % 16 == 0, Cout % 64 == 0, pixel strides % 16 == 0. */
+  const float* in_dequant; const float* w_dequant;
 } csmri_gconv_desc;
 #define CSMRI_GCONV_DEFER_REDUCE 1
 
@@ -140,6 +145,20 @@ typedef struct csmri_pack_item {
   int mode, dtype, Cout, Cin, KH, KW;
 } csmri_pack_item;
 int csmri_pack_weight_multi(const csmri_pack_item* items_dev, int n, void* stream);
+
+/* ------------------------------------------------------------------------
+ * fp8 operand preparation (BASELINE.json config 5: "fp8 MFMA convs").  The reference has no fp8 path;
+ * the variant computes the same nn.Conv2d (models/unet.py:40-52, models/discriminators.py,
+ * models/vgg.py) on operands rounded to OCP e4m3fn with one power-of-two scale per tensor:
+ *   e = floor(log2(amax)), scale = 2^(7-e), q = e4m3_rne(x * scale)   (|x*scale| < 256, never saturates)
+ * csmri_absmax: amax[0] = max |x| over n contiguous elements (device scalar, NaNs skipped).
+ * csmri_quantize_fp8: q[i] = e4m3(x[i] * scale); scales[0] = scale, scales[1] = 1/scale (device,
+ * may be NULL).  n % 16 == 0.  Weights: pack with csmri_pack_weight(mode, CSMRI_F32, ...) and quantise
+ * the packed buffer (same [rows][Kp] indexing).
+ * ---------------------------------------------------------------------- */
+int csmri_absmax(int dtype, const void* x, long long n, float* amax, void* stream);
+int csmri_quantize_fp8(int dtype, const void* x, void* q, long long n, const float* amax, float* scales,
+                       void* stream);
 
 /* ------------------------------------------------------------------------
  * Weight gradient of a convolution (nn.Conv2d backward w.r.t. weight):

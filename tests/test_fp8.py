@@ -1,0 +1,220 @@
+"""The fp8 convolution variant (BASELINE.json config 5 "fp8 MFMA convs"; VERDICT row ns-1).
+
+The reference has no fp8 path (its convolutions are fp32 nn.Conv2d: models/unet.py:40-52,
+models/discriminators.py:137-172), so the oracle for this variant is the reference convolution applied to
+operands rounded the way csrc/fp8.hip rounds them -- oracle/csmri_lowprec.py restates that rounding
+(e4m3fn, ties to even, one power-of-two scale per tensor) and is itself pinned here to torch's
+float8_e4m3fn conversion on the CPU.
+
+Stated tolerances:
+  * quantised bytes and scales: bit-exact (byte work);
+  * exact-integer operands: the fp8 convolution equals the integer convolution exactly (pins the
+    operand lane map of v_mfma_scale_f32_16x16x128_f8f6f4 and the K order of the LDS tiles);
+  * random operands, fp32 output: relative L2 <= 5e-5 against the oracle convolution on the same
+    fp8-rounded operands (measured 1.2e-5..1.6e-5: the block-scaled MFMA sums its 128 products in a wider
+    fixed-point tree and rounds once per instruction, not as 128 IEEE fp32 additions); bf16 output: <= 3e-3;
+  * against the un-quantised fp32 convolution the variant's own error is the format's: relative L2
+    2.5e-2..4.5e-2 for Gaussian operands (asserted < 6e-2) -- that is what "fp8" costs, not a kernel property."""
+import math
+import zlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import csmri_oracle as O
+import csmri_lowprec as L
+
+
+def rel_l2(a, b):
+  return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU: the restated rounding against torch's own e4m3fn conversion
+# ---------------------------------------------------------------------------------------------------
+def test_e4m3_restatement_matches_torch_float8():
+  g = torch.Generator().manual_seed(0)
+  x = torch.cat([torch.randn(100000, generator=g) * s for s in (1e-3, 0.1, 1.0, 30.0, 200.0)])
+  edge = torch.tensor([0.0, -0.0, 448.0, -448.0, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 2.5 * 2.0 ** -9, 2.0 ** -6,
+                       0.0175, 17.0, 18.0, 19.0, 463.9, 1000.0])
+  x = torch.cat([x, edge])
+  ref = x.clamp(-448, 448).to(torch.float8_e4m3fn)
+  got = L.e4m3_round(x)
+  assert torch.equal(got, ref.to(torch.float32))
+  assert torch.equal(L.e4m3_bits(got), ref.view(torch.uint8))
+
+
+def test_fp8_scale_rule():
+  # scale = 2^(7 - floor(log2 amax)): scaled maximum in [128, 256)
+  for amax in (1.0, 0.99999, 3.7, 1e-3, 447.0, 1e4, 2.0 ** -20):
+    s = L.fp8_scale(amax)
+    assert 128.0 <= amax * s < 256.0 and math.log2(s) == int(math.log2(s))
+  assert L.fp8_scale(0.0) == 1.0
+
+
+def test_fp8_emulated_conv_backward_is_the_16bit_path():
+  """emulate(fp8=True): forward on fp8 operands, gradients as the bf16 emulation computes them."""
+  g = torch.Generator().manual_seed(1)
+  x = torch.randn(2, 128, 8, 8, generator=g).bfloat16().float().requires_grad_(True)
+  w = (torch.randn(64, 128, 3, 3, generator=g) * 0.05).requires_grad_(True)
+  gy = torch.randn(2, 64, 8, 8, generator=g)
+  with L.emulate('bf16', fp8=True):
+    y8 = O.F.conv2d(x, w, None, padding=1)
+    y8.backward(gy)
+  gx8, gw8 = x.grad.clone(), w.grad.clone()
+  x.grad = w.grad = None
+  with L.emulate('bf16'):
+    y16 = O.F.conv2d(x, w, None, padding=1)
+    y16.backward(gy)
+  assert 1e-2 < rel_l2(y8, y16) < 6e-2            # the forward differs by the fp8 rounding ...
+  assert rel_l2(gx8, x.grad) < 1e-6 and rel_l2(gw8, w.grad) < 5e-3   # ... the backward does not (bf16 rounding of dW only)
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def hip():
+  import csmri_hip
+  assert torch.cuda.is_available()
+  return csmri_hip
+
+
+def to_dev_nhwc(x, dtype=torch.bfloat16):
+  return x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+
+
+def from_dev_nhwc(t, c):
+  return t.float().cpu()[..., :c].permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_quantize_fp8_bit_exact(hip, dtype):
+  ops = hip.ops
+  g = torch.Generator().manual_seed(5)
+  for scale, n in ((1.0, 1 << 20), (1e-4, 4096), (300.0, 65536), (0.0, 1024), (7.3e5, 16 * 999)):
+    x = (torch.randn(n, generator=g) * scale).to(dtype)
+    if scale:
+      x[::97] = 0
+      x[5] = -x.abs().max() * 1.0          # the maximum is negative
+    xd = x.cuda()
+    amax = ops.absmax(xd)
+    q, sc = ops.quantize_fp8(xd)
+    torch.cuda.synchronize()
+    ref, s = L.quantize_fp8(x.float())
+    assert float(amax.cpu()) == float(x.float().abs().max())
+    assert sc.cpu().tolist() == [s, 1.0 / s], (sc.cpu().tolist(), s)
+    assert torch.equal(q.cpu(), L.e4m3_bits(ref)), (scale, n)
+
+
+# name, cin, cout, k, stride, border, upsample, H, W, B, c0
+CONV_CASES = [
+    ('vgg2_2', 128, 128, 3, 1, 'zero', False, 32, 32, 4, None),
+    ('vgg3_2', 256, 256, 3, 1, 'zero', False, 16, 24, 3, None),
+    ('unet_e2b', 128, 128, 4, 1, 'reflection', False, 32, 32, 2, None),
+    ('unet_up', 128, 64, 4, 1, 'reflection', True, 16, 16, 2, None),
+    ('unet_cat64', 128, 64, 4, 1, 'reflection', False, 32, 32, 2, 64),
+    ('unet_cat128', 256, 128, 4, 1, 'reflection', False, 16, 16, 2, 128),
+    ('unet_cat_uneven', 256, 64, 3, 1, 'zero', False, 16, 16, 2, 80),
+    ('disc3', 128, 256, 4, 2, 'reflection', False, 32, 32, 4, None),
+    ('disc5_splitk', 512, 1024, 4, 2, 'reflection', False, 8, 8, 2, None),
+    ('disc6_tail', 1024, 1024, 4, 1, 'reflection', False, 5, 7, 3, None),
+    ('big_m', 128, 64, 3, 1, 'zero', False, 128, 128, 4, None),
+]
+
+
+def _layer(ops, name, cin, cout, k, stride, border, up, gen):
+  wt = torch.randn(cout, cin, k, k, generator=gen) / math.sqrt(cin * k * k)
+  bias = torch.randn(cout, generator=gen) * 0.1
+  pads, mode = O.same_padding(k, stride), border
+  layer = ops.ConvLayer(torch.nn.Parameter(wt.clone().cuda()), torch.nn.Parameter(bias.clone().cuda()), stride, pads, mode,
+                        torch.bfloat16, upsample=up)
+  layer.fp8 = True
+  return layer, wt, bias, pads, mode
+
+
+@pytest.mark.gpu
+def test_fp8_conv_exact_on_integer_operands(hip):
+  """Integers up to 8 are exact in e4m3 and every partial sum is exact in fp32: the fp8 convolution must
+  equal the integer convolution bit for bit, for every lane / K position (asymmetric operands)."""
+  ops = hip.ops
+  g = torch.Generator().manual_seed(2)
+  for cin, cout, k, stride, c0 in ((128, 128, 3, 1, None), (256, 64, 4, 2, None), (256, 128, 3, 1, 64)):
+    x = torch.randint(-8, 9, (2, cin, 12, 20), generator=g).float()
+    wt = torch.randint(-8, 9, (cout, cin, k, k), generator=g).float()
+    pads = O.same_padding(k, stride)
+    layer = ops.ConvLayer(torch.nn.Parameter(wt.clone().cuda()), None, stride, pads, 'reflection', torch.bfloat16)
+    layer.fp8 = True
+    x0, x1 = (to_dev_nhwc(x), None) if c0 is None else (to_dev_nhwc(x[:, :c0]), to_dev_nhwc(x[:, c0:]))
+    log = ops.LAUNCH_LOG = []
+    try:
+      y, _ = ops.conv_forward(layer, x0, x1, False, 1.0, False, torch.float32)
+    finally:
+      ops.LAUNCH_LOG = None
+    assert log[-1][1].startswith('gconv_fp8_kernel'), log
+    ref = F.conv2d(O.pad2d(x, pads, 'reflection'), wt, None, stride=stride)
+    assert torch.equal(from_dev_nhwc(y, cout), ref), (cin, cout, k, stride, c0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_fp8_conv_vs_oracle_on_rounded_operands(hip, case):
+  ops = hip.ops
+  name, cin, cout, k, stride, border, up, h, w, b, c0 = case
+  g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+  layer, wt, bias, pads, mode = _layer(ops, name, cin, cout, k, stride, border, up, g)
+  x = (torch.randn(b, cin, h, w, generator=g) * 1.7).bfloat16().float()
+  x0, x1 = (to_dev_nhwc(x), None) if c0 is None else (to_dev_nhwc(x[:, :c0]), to_dev_nhwc(x[:, c0:]))
+  # oracle: the reference convolution on the fp8-rounded operands
+  xq, sx = L.quantize_fp8(x)
+  wq, sw = L.quantize_fp8(wt)
+  prep = (lambda t: F.interpolate(t, scale_factor=2, mode='nearest')) if up else (lambda t: t)
+  ref8 = F.conv2d(O.pad2d(prep(xq), pads, mode), wq, None, stride=stride) / (sx * sw) + bias.view(1, -1, 1, 1)
+  ref8 = F.leaky_relu(ref8, 0.2)
+  ref32 = F.leaky_relu(F.conv2d(O.pad2d(prep(x), pads, mode), wt, bias, stride=stride), 0.2)
+  log = ops.LAUNCH_LOG = []
+  try:
+    y32, _ = ops.conv_forward(layer, x0, x1, True, 0.2, False, torch.float32)
+    y16, stats = ops.conv_forward(layer, x0, x1, True, 1.0, True, None)
+    torch.cuda.synchronize()
+  finally:
+    ops.LAUNCH_LOG = None
+  assert all(e[1].startswith('gconv_fp8_kernel') for e in log), log
+  e32 = rel_l2(from_dev_nhwc(y32, cout), ref8)
+  fmt = rel_l2(ref8, ref32)
+  print('%-16s fp8 conv vs oracle(fp8 operands) %.2e | format error vs fp32 conv %.2e | %s sk%d' %
+        (name, e32, fmt, log[0][1], log[0][2]))
+  assert e32 < 5e-5, (name, e32)
+  assert fmt < 6e-2, (name, fmt)
+  # bf16 output + BatchNorm partial sums from the epilogue (no activation on this call)
+  pre8 = F.conv2d(O.pad2d(prep(xq), pads, mode), wq, None, stride=stride) / (sx * sw) + bias.view(1, -1, 1, 1)
+  assert rel_l2(from_dev_nhwc(y16, cout), pre8) < 3e-3
+  s1, s2 = stats.cpu().double().reshape(2, layer.cout_p, -1).sum(-1)     # partial sums are [2][C][rows]
+  assert torch.allclose(s1[:cout], pre8.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+  assert torch.allclose(s2[:cout], (pre8.double() ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.gpu
+def test_fp8_layer_backward_is_the_bf16_path(hip):
+  """ConvLayer.fp8 only changes the forward product: dgrad / wgrad launches and results are those of the
+  bf16 layer (the ConvAct autograd node saves the bf16 input)."""
+  ops = hip.ops
+  g = torch.Generator().manual_seed(9)
+  outs = []
+  for fp8 in (False, True):
+    gen = torch.Generator().manual_seed(11)
+    layer, wt, bias, pads, mode = _layer(ops, 'l', 128, 128, 3, 1, 'zero', False, gen)
+    layer.fp8 = fp8
+    x = to_dev_nhwc(torch.randn(2, 128, 16, 16, generator=gen)).requires_grad_(True)
+    gy = to_dev_nhwc(torch.randn(2, 128, 16, 16, generator=gen))
+    y = ops.ConvAct.apply(x, None, layer.weight, layer.bias, layer, 1.0, None)
+    y.backward(gy)
+    ops.join_wgrad_stream()
+    torch.cuda.synchronize()
+    outs.append((y.detach().float().cpu(), x.grad.float().cpu(), layer.weight.grad.cpu().clone()))
+  (y16, gx16, gw16), (y8, gx8, gw8) = outs
+  assert 5e-3 < rel_l2(y8, y16) < 6e-2
+  # no activation on this layer, so nothing of the forward's output enters the backward: identical launches
+  assert torch.equal(gx8, gx16) and torch.equal(gw8, gw16)

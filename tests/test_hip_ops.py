@@ -474,6 +474,76 @@ def test_fp32_kernels_exact_next_to_mfma_kernels_in_one_graph(hip):
     assert torch.equal(c, ref_conv_out)
 
 
+def test_torch_elementwise_kernels_exact_next_to_mfma_kernels_in_one_graph(hip):
+  """Same hazard as the test above, for the kernels this library does not build: the wheel's own
+  elementwise / reduction / cat kernels (the criteria algebra, the image pool and the optimizer glue
+  use them inside the captured step) run on a second branch of one hipGraph next to a chain of MFMA
+  convolutions and must stay bit-identical to their serial results."""
+  ops = hip.ops
+  g = torch.Generator().manual_seed(1)
+  b, size = 8, 256
+  wt = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+  layer = ops.ConvLayer(torch.nn.Parameter(wt.cuda()), None, 1, (1, 1, 1, 1), 'zero', torch.bfloat16)
+  act = torch.randn(b, size, size, 64, generator=g).bfloat16().cuda()
+  xf = [torch.randn(b * size * size * 8, generator=g).cuda() for _ in range(3)]
+  xb = [t.bfloat16() for t in xf]
+
+  def torch_chain():
+    outs = []
+    t = xf[0]
+    for i in range(6):
+      t = t + xf[1 + i % 2]
+      outs.append(t)
+    u = xb[0]
+    for i in range(6):
+      u = u + xb[1 + i % 2]
+      outs.append(u)
+    v = xf[0]
+    for i in range(4):
+      v = v * 1.0001 + xf[1]
+      outs.append(v)
+    outs.append(torch.stack([t.sum() for t in xf]))
+    outs.append(torch.cat([xb[0][:4096], xb[1][:4096]]) * 0.5)
+    return outs
+
+  def conv_chain():
+    t = act
+    for _ in range(10):
+      t, _ = ops.conv_forward(layer, t, use_bias=False, act_slope=0.2)
+    return t
+
+  with torch.no_grad():
+    ref = [t.clone() for t in torch_chain()]
+    ref_conv_out = conv_chain().clone()
+  s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+  def both():
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur)
+    s2.wait_stream(cur)
+    with torch.no_grad():
+      with torch.cuda.stream(s2):
+        c = conv_chain()
+      with torch.cuda.stream(s1):
+        a = torch_chain()
+    cur.wait_stream(s1)
+    cur.wait_stream(s2)
+    return a, c
+
+  for _ in range(2):
+    both()
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+    a, c = both()
+  for _ in range(10):
+    graph.replay()
+    torch.cuda.synchronize()
+    for i, (got, want) in enumerate(zip(a, ref)):
+      assert torch.equal(got, want), i
+    assert torch.equal(c, ref_conv_out)
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 64), (1, 256, 256), (2, 128, 32), (1, 512, 512), (3, 32, 64)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_fft2_standalone_matches_numpy(hip, shape):

@@ -760,7 +760,7 @@ def _oracle_step(PG0, SG0, PD0, SD0, PV, batch, masks, emulate=None):
       orig()
     opt.step = step
   dm = [masks[0:3], masks[3:6], masks[6:9]]
-  with LP.emulate(emulate):
+  with (LP.emulate(**emulate) if isinstance(emulate, dict) else LP.emulate(emulate)):
     losses, metrics, _ = O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=O.ImagePool(80),
                                           dropout_masks=dm)
   return losses, metrics, grads
@@ -1008,7 +1008,7 @@ def test_config5_512_radial_full_width_step_vs_oracle(env, dtype):
   kernels), full-width networks, 2 slices, one AdversarialRunner step against the fp32 CPU oracle.  The
   discriminator's logits are 13 x 13 here (reference discriminators.py:211-234 at 512^2).
   fp32 compute: losses 1e-4, PSNR 1e-3 dB; bf16 compute: losses 2 %, PSNR 0.02 dB (scale = 0.25, see the
-  256^2 tests for why).  (The fp8 convolution variant of config 5 is not built.)"""
+  256^2 tests for why).  The fp8 variant of config 5: test_config5_512_radial_fp8_forward_step below."""
   Configuration, set_dtype = env
   from data.synthetic import synth_batch_radial
   runner, conf = _full_width_runner(Configuration, set_dtype, dtype, batch_size=2)
@@ -1031,6 +1031,54 @@ def test_config5_512_radial_full_width_step_vs_oracle(env, dtype):
   dpsnr = abs(hip[1]['gen_psnr'].value - ref[1]['gen_psnr'])
   print('config5 %s gen_psnr hip %.5f oracle %.5f' % (dtype, hip[1]['gen_psnr'].value, ref[1]['gen_psnr']))
   assert dpsnr < (1e-3 if dtype == 'fp32' else 0.02)
+
+
+def test_config5_512_radial_fp8_forward_step(env):
+  """BASELINE config 5 with its fp8 convolutions: the step of the test above with compute_dtype 'fp8' -- the
+  forward products of every trainable convolution whose shape the fp8 variant accepts (U-Net 128-channel
+  level, discriminator layers 3-6: input channels % 128, output channels % 64) run on e4m3fn operands with
+  per-tensor power-of-two scales, backward and everything else as bf16 (tests/test_fp8.py pins the kernel).
+  Oracle: the CPU oracle with the same operand rounding emulated (oracle/csmri_lowprec.emulate(fp8=True)).
+  Stated tolerance: every loss within 5 % of that emulation (the HIP step evaluates D on [fake; real] as one
+  pass, so its per-tensor maxima -- hence occasionally its scales -- are taken over both halves, the
+  oracle's per call), PSNR within 0.05 dB; the distance to the plain fp32 oracle is printed next to the
+  emulation's own distance (the cost of the format, not of the kernels)."""
+  Configuration, set_dtype = env
+  from data.synthetic import synth_batch_radial
+  from models.utils import set_fp8_forward
+  import csmri_hip
+  runner, conf = _full_width_runner(Configuration, set_dtype, 'bf16', batch_size=2)
+  assert set_fp8_forward(runner.gen) > 0 and set_fp8_forward(runner.disc) > 0
+  batch = synth_batch_radial(2, 512, 512, spokes=70, seed=5)
+  g = torch.Generator().manual_seed(10)
+  chans = [f for _, bn, drop, f in runner.disc._layers if bn is not None and drop]
+  masks = [(torch.rand(2, c, 1, 1, generator=g) < 0.5).float() * 2.0 for _ in range(3) for c in chans]
+  PG, SG = _split_sd(runner.gen.state_dict())
+  PD, SD = _split_sd(runner.disc.state_dict())
+  PV = {k: v.detach().cpu().clone() for k, v in
+        runner.gen_criteria['VGG19'].criterion.vgg.state_dict().items() if k.startswith('blocks')}
+  log = csmri_hip.ops.LAUNCH_LOG = []
+  try:
+    hip = _hip_step(runner, batch, masks)
+  finally:
+    csmri_hip.ops.LAUNCH_LOG = None
+  n8 = sum(1 for e in log if e[1].startswith('gconv_fp8_kernel'))
+  print('config5 fp8: %d fp8 convolution launches in the step' % n8)
+  assert n8 >= 2 * 4 + 3          # D layers 3-6 in the grouped D-phase pass and the generator-phase pass, three U-Net layers
+  ref8 = _oracle_step(PG, SG, PD, SD, PV, batch, masks, emulate={'mode': 'bf16', 'fp8': True})
+  ref = _oracle_step(PG, SG, PD, SD, PV, batch, masks)
+  for k in sorted(ref[0]):
+    rel8 = abs(hip[0][k] - ref8[0][k]) / max(1e-12, abs(ref8[0][k]))
+    rel = abs(hip[0][k] - ref[0][k]) / max(1e-12, abs(ref[0][k]))
+    fmt = abs(ref8[0][k] - ref[0][k]) / max(1e-12, abs(ref[0][k]))
+    print('config5 fp8 %-26s hip %.6e | emulated %.6e (rel %.3e) | fp32 oracle %.6e (hip rel %.3e, emulation rel %.3e)'
+          % (k, hip[0][k], ref8[0][k], rel8, ref[0][k], rel, fmt))
+    assert rel8 < 5e-2, (k, hip[0][k], ref8[0][k])
+  d8 = abs(hip[1]['gen_psnr'].value - ref8[1]['gen_psnr'])
+  d32 = abs(hip[1]['gen_psnr'].value - ref[1]['gen_psnr'])
+  print('config5 fp8 gen_psnr hip %.5f emulated %.5f fp32 %.5f' % (hip[1]['gen_psnr'].value, ref8[1]['gen_psnr'],
+                                                                  ref[1]['gen_psnr']))
+  assert d8 < 0.05 and d32 < 0.1
 
 
 def test_recnet_runner_graph_replay_equals_eager(env):
