@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: train slices/s of the 256x256 GAN-refinement step (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W [--config c3|c2] [--dtype bf16|fp32]
+  python bench.py --gpus N --steps K --warmup W [--config c3|c2|c5] [--dtype bf16|fp32|fp8]
 
 N>1 is launched by the driver as torch.distributed.run with one rank per GPU (RCCL).
 
@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, 'csmri-refinement_amd')
 sys.path.insert(0, PKG)
 
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA, MI355X_MICROARCH.md chip table
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'fp8': 5000.0}   # dense MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0                           # HBM3E spec (same table; ~6.3 TB/s achievable)
 GAN_GFLOP_PER_SLICE = 299.2   # algorithmic conv FLOPs of one 256^2 GAN step
 C2_GFLOP_PER_SLICE = 20.31    # RecNet 5/3/32 MSE step at 256^2
@@ -53,7 +53,7 @@ def parse():
   p.add_argument('--steps', type=int, default=250)
   p.add_argument('--warmup', type=int, default=10)
   p.add_argument('--config', default='c3', choices=['c3', 'c2', 'c5'])
-  p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+  p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp8'])
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--no-roofline', action='store_true')
   p.add_argument('--no-prefetch', action='store_true',
@@ -283,7 +283,8 @@ def roofline(runner, loader_factory, dtype, steps=2, config='c3'):
   dom = max(flop_kernels, key=lambda k: flop_kernels[k][2])
   n, fl, sec = agg[dom]
   achieved = fl / sec / 1e12
-  peak = PEAK_TFLOPS[dtype]
+  # --dtype fp8 only moves the eligible forward products to fp8: price the dominant kernel by what it multiplies
+  peak = PEAK_TFLOPS['fp8' if 'fp8' in dom else ('bf16' if dtype == 'fp8' else dtype)]
   # HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very
   # command (tools/pmc_bench.sh; FETCH_SIZE doubled per the gfx950 correction), committed under profiles/
   traffic, traffic_src = None, None

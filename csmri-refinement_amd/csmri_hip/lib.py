@@ -104,6 +104,8 @@ _SIGS = {
     'csmri_undersample': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     'csmri_dc_work_bytes': (sz, [i32, i32, i32]),
     'csmri_fft2': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'csmri_fft2_bf16': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'csmri_dc_bf16': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     'csmri_nchw_to_nhwc': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),
     'csmri_nhwc_to_nchw': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'csmri_mask_to_u8': (i32, [vp, i32, i32, i32, vp, vp]),

@@ -964,13 +964,15 @@ def undersample(img, mask_u8):
 
 
 def fft2(x, inverse=False, ortho=True):
-  """Batched 2-D FFT of interleaved complex fp32 [B,H,W,2] (reference Fft2d / Ifft2d, myfft.py:78-128)."""
+  """Batched 2-D FFT of interleaved complex [B,H,W,2] (reference Fft2d / Ifft2d, myfft.py:78-128): fp32, or
+  bf16 storage with fp32 arithmetic (csmri_fft2_bf16)."""
   _need_gpu(x)
   x = x.contiguous()
-  assert x.dtype == torch.float32 and x.shape[-1] == 2
+  assert x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] == 2
   b, h, w, _ = x.shape
   out = torch.empty_like(x)
-  lib.call('csmri_fft2', x.data_ptr(), out.data_ptr(), b, h, w, int(inverse), int(ortho), stream())
+  lib.call('csmri_fft2' if x.dtype == torch.float32 else 'csmri_fft2_bf16', x.data_ptr(), out.data_ptr(), b, h, w,
+           int(inverse), int(ortho), stream())
   return out
 
 
@@ -993,14 +995,18 @@ def dc_raw(x, k0, mask_u8, pad_dtype=None):
   fp32, channel-padded copy [B,H,W,8] of pad_dtype or None)."""
   _need_gpu(x)
   x = as_nhwc(x)
-  assert x.dtype == torch.float32 and x.shape[3] >= 2
+  assert x.dtype in (torch.float32, torch.bfloat16) and x.shape[3] >= 2
   b, h, w, _ = x.shape
-  out = torch.empty(b, h, w, 2, dtype=torch.float32, device=x.device)
+  out = torch.empty(b, h, w, 2, dtype=x.dtype, device=x.device)
   out_pad = None
   if pad_dtype is not None:
     out_pad = torch.empty(b, h, w, 8, dtype=pad_dtype, device=x.device)
-  lib.call('csmri_dc', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
-           ptr(out_pad), dt_of(out_pad) if out_pad is not None else 0, 0, b, h, w, stream())
+  if x.dtype == torch.bfloat16:       # bf16 image storage (k0 stays fp32): the "bf16 cFFT" of config 5
+    lib.call('csmri_dc_bf16', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
+             ptr(out_pad), dt_of(out_pad) if out_pad is not None else 0, b, h, w, stream())
+  else:
+    lib.call('csmri_dc', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
+             ptr(out_pad), dt_of(out_pad) if out_pad is not None else 0, 0, b, h, w, stream())
   return out, out_pad
 
 
@@ -1014,7 +1020,7 @@ class DataConsistency(torch.autograd.Function):
   def forward(ctx, x, k0, mask_u8, pad_dtype):
     out, out_pad = dc_raw(x, k0, mask_u8, pad_dtype)
     ctx.save_for_backward(mask_u8)
-    ctx.cx = x.shape[3]
+    ctx.cx, ctx.xdt = x.shape[3], x.dtype
     if out_pad is None:
       return out
     ctx.mark_non_differentiable(out_pad)
@@ -1024,9 +1030,9 @@ class DataConsistency(torch.autograd.Function):
   def backward(ctx, g, *unused):
     mask_u8, = ctx.saved_tensors
     g = as_nhwc(g)
-    if g.dtype != torch.float32:
-      g = copy_channels(g, 2, torch.float32)
-    gx, gpad = dc_raw(g, None, mask_u8, torch.float32 if ctx.cx == 8 else None)
+    if g.dtype != ctx.xdt:
+      g = copy_channels(g, 2, ctx.xdt)
+    gx, gpad = dc_raw(g, None, mask_u8, ctx.xdt if ctx.cx == 8 else None)
     return (gpad if ctx.cx == 8 else gx), None, None, None
 
 

@@ -162,6 +162,19 @@ __device__ __forceinline__ void fft_dit_inv(float2 (&v)[FftCfg<LOGN>::R], const 
   }
 }
 
+// Complex element storage of the image-side buffers: interleaved fp32 (float2) or interleaved bf16 (4 bytes per
+// complex value -- the "bf16 cFFT" of BASELINE config 5: arithmetic stays fp32 in registers / LDS, only the HBM
+// images and the intermediate between the passes are rounded; k-space data k0 / kout stays fp32).
+template <int IO> __device__ __forceinline__ float2 ldc(const void* p, size_t scalar_idx) {
+  if (IO == CSMRI_F32) return *(const float2*)((const float*)p + scalar_idx);
+  const unsigned u = *(const unsigned*)((const unsigned short*)p + scalar_idx);
+  return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+}
+template <int IO> __device__ __forceinline__ void stc(void* p, size_t complex_idx, float2 v) {
+  if (IO == CSMRI_F32) ((float2*)p)[complex_idx] = v;
+  else ((unsigned*)p)[complex_idx] = (unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16);
+}
+
 #define DC_THREADS 256               // row passes: 4 waves = 4 rows per workgroup
 #define DC_CTHREADS 512              // column pass: 8 waves = one column of the strip each
 #define DC_STRIP 8                   // columns per workgroup in pass 2 (64-byte row segments)
@@ -170,9 +183,9 @@ __device__ __forceinline__ void fft_dit_inv(float2 (&v)[FftCfg<LOGN>::R], const 
 // passes 1 and 3 (and the row halves of csmri_fft2): 1-D transforms along W, one per wave (two for W = 32).
 //   INV = false: src natural order with pixel stride src_ps floats -> dst natural order (dense)
 //   INV = true : src dense natural order -> dst dense natural order (+ optional channel-padded copy), x scale
-template <int LOGN, bool INV>
-__global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const float* __restrict__ src, int src_ps,
-                                                             float2* __restrict__ dst, void* out_pad, int out_pad_dt,
+template <int LOGN, bool INV, int IO>
+__global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const void* __restrict__ src, int src_ps,
+                                                             void* __restrict__ dst, void* out_pad, int out_pad_dt,
                                                              int rows, float scale) {
   typedef FftCfg<LOGN> C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -187,18 +200,18 @@ __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const float* __rest
   const int kbase = C::R * rev_bits(l, C::LOGL);      // first of the lane's R consecutive frequencies
   if (!INV) {
 #pragma unroll
-    for (int q = 0; q < C::R; ++q) v[q] = *(const float2*)(src + (base + l + C::L * q) * (size_t)src_ps);
+    for (int q = 0; q < C::R; ++q) v[q] = ldc<IO>(src, (base + l + C::L * q) * (size_t)src_ps);
     fft_dif<LOGN>(v, tw, lane);
     if (!live) return;
 #pragma unroll
     for (int q = 0; q < C::R; ++q) {
       float2 o = v[q];
       o.x *= scale; o.y *= scale;
-      dst[base + kbase + rev_const<C::LOGR>(q)] = o;
+      stc<IO>(dst, base + kbase + rev_const<C::LOGR>(q), o);
     }
   } else {
 #pragma unroll
-    for (int q = 0; q < C::R; ++q) v[q] = *(const float2*)(src + (base + kbase + rev_const<C::LOGR>(q)) * (size_t)src_ps);
+    for (int q = 0; q < C::R; ++q) v[q] = ldc<IO>(src, (base + kbase + rev_const<C::LOGR>(q)) * (size_t)src_ps);
     fft_dit_inv<LOGN>(v, tw, lane);
     if (!live) return;
 #pragma unroll
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const float* __rest
       float2 o = v[q];
       o.x *= scale; o.y *= scale;
       const size_t p = base + l + C::L * q;
-      dst[p] = o;
+      stc<IO>(dst, p, o);
       if (out_pad) {
         if (out_pad_dt == CSMRI_F32) {
           f32x4_t* pp = (f32x4_t*)out_pad + p * 2;
@@ -223,8 +236,8 @@ __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const float* __rest
 //   MODE 0  FFT along H -> x scale -> mask merge (+ k0) -> inverse FFT along H   (csmri_dc / csmri_undersample)
 //   MODE 1  FFT along H only (x scale), natural order out                        (csmri_fft2 forward)
 //   MODE 2  inverse FFT along H only (x scale)                                   (csmri_fft2 inverse)
-template <int LOGN, int MODE>
-__global__ __launch_bounds__(DC_CTHREADS) void dc_cols_kernel(float2* __restrict__ data, const float2* __restrict__ k0,
+template <int LOGN, int MODE, int IO>
+__global__ __launch_bounds__(DC_CTHREADS) void dc_cols_kernel(void* __restrict__ data, const float2* __restrict__ k0,
                                                              const uint8_t* __restrict__ mask, int W, float scale,
                                                              float2* __restrict__ kout, int keep_sampled) {
   typedef FftCfg<LOGN> C;
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(DC_CTHREADS) void dc_cols_kernel(float2* __restrict
   for (int idx = tid; idx < H * DC_STRIP; idx += DC_CTHREADS) {
     const int h = idx / DC_STRIP, c = idx - h * DC_STRIP;
     const size_t o = base + (size_t)h * W + c;
-    A[h * DC_PITCH + c] = data[o];
+    A[h * DC_PITCH + c] = ldc<IO>(data, 2 * o);
     if (MODE == 0) {
       if (k0) K[h * DC_PITCH + c] = k0[o];
       M[h * DC_STRIP + c] = mask[o];
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(DC_CTHREADS) void dc_cols_kernel(float2* __restrict
   for (int idx = tid; idx < H * DC_STRIP; idx += DC_CTHREADS) {
     const int h = idx / DC_STRIP, c = idx - h * DC_STRIP;
     const size_t o = base + (size_t)h * W + c;
-    data[o] = A[h * DC_PITCH + c];
+    stc<IO>(data, o, A[h * DC_PITCH + c]);
     if (MODE == 0 && kout) kout[o] = K[h * DC_PITCH + c];
   }
 }
@@ -303,19 +316,20 @@ static int log2_in_range(int n) {
   return -1;
 }
 
-template <int LOGN, bool INV>
-static int launch_rows(const float* src, int src_ps, float2* dst, void* out_pad, int out_pad_dt, int rows,
+template <int LOGN, bool INV, int IO>
+static int launch_rows(const void* src, int src_ps, void* dst, void* out_pad, int out_pad_dt, int rows,
                        float scale, hipStream_t st) {
   constexpr int per_wg = (DC_THREADS / 64) * FftCfg<LOGN>::TPW;
-  hipLaunchKernelGGL((dc_rows_kernel<LOGN, INV>), dim3(cdiv(rows, per_wg)), dim3(DC_THREADS), 0, st,
+  hipLaunchKernelGGL((dc_rows_kernel<LOGN, INV, IO>), dim3(cdiv(rows, per_wg)), dim3(DC_THREADS), 0, st,
                      src, src_ps, dst, out_pad, out_pad_dt, rows, scale);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
-static int rows_pass(int logw, bool inv, const float* src, int src_ps, float2* dst, void* out_pad, int out_pad_dt,
+template <int IO>
+static int rows_pass(int logw, bool inv, const void* src, int src_ps, void* dst, void* out_pad, int out_pad_dt,
                      int rows, float scale, hipStream_t st) {
-#define ROWS(LW) (inv ? launch_rows<LW, true>(src, src_ps, dst, out_pad, out_pad_dt, rows, scale, st) \
-                      : launch_rows<LW, false>(src, src_ps, dst, out_pad, out_pad_dt, rows, scale, st))
+#define ROWS(LW) (inv ? launch_rows<LW, true, IO>(src, src_ps, dst, out_pad, out_pad_dt, rows, scale, st) \
+                      : launch_rows<LW, false, IO>(src, src_ps, dst, out_pad, out_pad_dt, rows, scale, st))
   switch (logw) {
     case 5: return ROWS(5); case 6: return ROWS(6); case 7: return ROWS(7); case 8: return ROWS(8); case 9: return ROWS(9);
   }
@@ -323,26 +337,26 @@ static int rows_pass(int logw, bool inv, const float* src, int src_ps, float2* d
   return CSMRI_E_UNSUPPORTED;
 }
 
-template <int LOGN, int MODE>
-static int launch_cols(float2* data, const float2* k0, const uint8_t* mask, int B, int W, float scale,
+template <int LOGN, int MODE, int IO>
+static int launch_cols(void* data, const float2* k0, const uint8_t* mask, int B, int W, float scale,
                        float2* kout, int keep, hipStream_t st) {
   constexpr int H = 1 << LOGN;
   constexpr int lds = 2 * H * DC_PITCH * (int)sizeof(float2) + H * DC_STRIP;
-  CSMRI_SET_MAX_LDS((dc_cols_kernel<LOGN, MODE>), lds);
-  hipLaunchKernelGGL((dc_cols_kernel<LOGN, MODE>), dim3(B * (W / DC_STRIP)), dim3(DC_CTHREADS), lds, st,
+  CSMRI_SET_MAX_LDS((dc_cols_kernel<LOGN, MODE, IO>), lds);
+  hipLaunchKernelGGL((dc_cols_kernel<LOGN, MODE, IO>), dim3(B * (W / DC_STRIP)), dim3(DC_CTHREADS), lds, st,
                      data, k0, mask, W, scale, kout, keep);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
-template <int MODE>
-static int cols_pass(int logh, float2* data, const float2* k0, const uint8_t* mask, int B, int W, float scale,
+template <int MODE, int IO>
+static int cols_pass(int logh, void* data, const float2* k0, const uint8_t* mask, int B, int W, float scale,
                      float2* kout, int keep, hipStream_t st) {
   switch (logh) {
-    case 5: return launch_cols<5, MODE>(data, k0, mask, B, W, scale, kout, keep, st);
-    case 6: return launch_cols<6, MODE>(data, k0, mask, B, W, scale, kout, keep, st);
-    case 7: return launch_cols<7, MODE>(data, k0, mask, B, W, scale, kout, keep, st);
-    case 8: return launch_cols<8, MODE>(data, k0, mask, B, W, scale, kout, keep, st);
-    case 9: return launch_cols<9, MODE>(data, k0, mask, B, W, scale, kout, keep, st);
+    case 5: return launch_cols<5, MODE, IO>(data, k0, mask, B, W, scale, kout, keep, st);
+    case 6: return launch_cols<6, MODE, IO>(data, k0, mask, B, W, scale, kout, keep, st);
+    case 7: return launch_cols<7, MODE, IO>(data, k0, mask, B, W, scale, kout, keep, st);
+    case 8: return launch_cols<8, MODE, IO>(data, k0, mask, B, W, scale, kout, keep, st);
+    case 9: return launch_cols<9, MODE, IO>(data, k0, mask, B, W, scale, kout, keep, st);
   }
   return CSMRI_E_UNSUPPORTED;
 }
@@ -352,21 +366,30 @@ extern "C" size_t csmri_dc_work_bytes(int B, int H, int W) {
   return 0;  // the three passes run in place on `out`
 }
 
-extern "C" int csmri_dc(const float* x, int x_pix_stride, const float* k0, const uint8_t* mask,
-                        float* out, void* out_pad, int out_pad_dtype, float* work, int B, int H,
-                        int W, void* stream) {
-  (void)work;
+template <int IO>
+static int dc_passes(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, void* out, void* out_pad,
+                     int out_pad_dtype, int B, int H, int W, hipStream_t st) {
   CSMRI_CHECK_ARG(x && mask && out && B > 0 && x_pix_stride >= 2 && x_pix_stride % 2 == 0);
   const int lh = log2_in_range(H), lw = log2_in_range(W);
   if (lh < 0 || lw < 0) return CSMRI_E_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)k0 | (uintptr_t)out_pad) & 15) return CSMRI_E_ALIGN;
-  hipStream_t st = (hipStream_t)stream;
   const float scale = 1.0f / sqrtf((float)H * (float)W);
-  int rc = rows_pass(lw, false, x, x_pix_stride, (float2*)out, nullptr, 0, B * H, 1.0f, st);
+  int rc = rows_pass<IO>(lw, false, x, x_pix_stride, out, nullptr, 0, B * H, 1.0f, st);
   if (rc != CSMRI_OK) return rc;
-  rc = cols_pass<0>(lh, (float2*)out, (const float2*)k0, mask, B, W, scale, nullptr, 0, st);
+  rc = cols_pass<0, IO>(lh, out, (const float2*)k0, mask, B, W, scale, nullptr, 0, st);
   if (rc != CSMRI_OK) return rc;
-  return rows_pass(lw, true, out, 2, (float2*)out, out_pad, out_pad_dtype, B * H, scale, st);
+  return rows_pass<IO>(lw, true, out, 2, out, out_pad, out_pad_dtype, B * H, scale, st);
+}
+extern "C" int csmri_dc(const float* x, int x_pix_stride, const float* k0, const uint8_t* mask,
+                        float* out, void* out_pad, int out_pad_dtype, float* work, int B, int H,
+                        int W, void* stream) {
+  (void)work;
+  return dc_passes<CSMRI_F32>(x, x_pix_stride, k0, mask, out, out_pad, out_pad_dtype, B, H, W, (hipStream_t)stream);
+}
+// bf16 image storage ("bf16 cFFT"): x, out and the intermediate between the passes are interleaved bf16
+extern "C" int csmri_dc_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, void* out,
+                             void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream) {
+  return dc_passes<CSMRI_BF16>(x, x_pix_stride, k0, mask, out, out_pad, out_pad_dtype, B, H, W, (hipStream_t)stream);
 }
 
 // The forward model that produces a training sample from a (complex) image, on the device:
@@ -382,26 +405,32 @@ extern "C" int csmri_undersample(const float* img, const uint8_t* mask, float* k
   if (((uintptr_t)img | (uintptr_t)kspace | (uintptr_t)inp) & 15) return CSMRI_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const float scale = 1.0f / sqrtf((float)H * (float)W);
-  int rc = rows_pass(lw, false, img, 2, (float2*)inp, nullptr, 0, B * H, 1.0f, st);
+  int rc = rows_pass<CSMRI_F32>(lw, false, img, 2, inp, nullptr, 0, B * H, 1.0f, st);
   if (rc != CSMRI_OK) return rc;
-  rc = cols_pass<0>(lh, (float2*)inp, nullptr, mask, B, W, scale, (float2*)kspace, 1, st);
+  rc = cols_pass<0, CSMRI_F32>(lh, inp, nullptr, mask, B, W, scale, (float2*)kspace, 1, st);
   if (rc != CSMRI_OK) return rc;
-  return rows_pass(lw, true, inp, 2, (float2*)inp, nullptr, 0, B * H, scale, st);
+  return rows_pass<CSMRI_F32>(lw, true, inp, 2, inp, nullptr, 0, B * H, scale, st);
 }
 
 // Stand-alone batched 2-D FFT / inverse FFT of interleaved complex fp32 images: the operation behind the
 // reference's Fft2d / Ifft2d Functions (myfft.py:78-128), whose backward passes are the same transforms in
 // the other direction (myfft.py:92-102,119-128).  ortho != 0: both directions scaled by 1/sqrt(HW) (the
 // reference's normalized=True); ortho == 0: forward unscaled, inverse scaled by 1/(HW) (pytorch_fft).
-extern "C" int csmri_fft2(const float* x, float* out, int B, int H, int W, int inverse, int ortho, void* stream) {
+template <int IO>
+static int fft2_passes(const void* x, void* out, int B, int H, int W, int inverse, int ortho, hipStream_t st) {
   CSMRI_CHECK_ARG(x && out && B > 0);
   const int lh = log2_in_range(H), lw = log2_in_range(W);
   if (lh < 0 || lw < 0) return CSMRI_E_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)out) & 15) return CSMRI_E_ALIGN;
-  hipStream_t st = (hipStream_t)stream;
   const float scale = ortho ? 1.0f / sqrtf((float)H * (float)W) : (inverse ? 1.0f / ((float)H * (float)W) : 1.0f);
-  int rc = rows_pass(lw, inverse != 0, x, 2, (float2*)out, nullptr, 0, B * H, 1.0f, st);
+  int rc = rows_pass<IO>(lw, inverse != 0, x, 2, out, nullptr, 0, B * H, 1.0f, st);
   if (rc != CSMRI_OK) return rc;
-  return inverse ? cols_pass<2>(lh, (float2*)out, nullptr, nullptr, B, W, scale, nullptr, 0, st)
-                 : cols_pass<1>(lh, (float2*)out, nullptr, nullptr, B, W, scale, nullptr, 0, st);
+  return inverse ? cols_pass<2, IO>(lh, out, nullptr, nullptr, B, W, scale, nullptr, 0, st)
+                 : cols_pass<1, IO>(lh, out, nullptr, nullptr, B, W, scale, nullptr, 0, st);
+}
+extern "C" int csmri_fft2(const float* x, float* out, int B, int H, int W, int inverse, int ortho, void* stream) {
+  return fft2_passes<CSMRI_F32>(x, out, B, H, W, inverse, ortho, (hipStream_t)stream);
+}
+extern "C" int csmri_fft2_bf16(const void* x, void* out, int B, int H, int W, int inverse, int ortho, void* stream) {
+  return fft2_passes<CSMRI_BF16>(x, out, B, H, W, inverse, ortho, (hipStream_t)stream);
 }

@@ -18,7 +18,7 @@ from models.weight_inits import initialize_weights
 RECNET_REQUIRED_PARAMS = ['num_blocks', 'num_convs', 'num_filters']
 RECNET_OPTIONAL_PARAMS = ['num_final_outputs', 'dilations_per_conv', 'kernel_size',
                           'relu_leakiness', 'padding', 'use_refinement', 'skip_final_dc',
-                          'return_intermediate_recs', 'compute_dtype']
+                          'return_intermediate_recs', 'compute_dtype', 'dc_storage']
 
 
 def construct_model(conf, model_name, **kwargs):
@@ -49,6 +49,7 @@ class ConvBlock(nn.Module):
       cin = cout
     self.layers = nn.ModuleDict(convs)
     self.num_outputs = num_outputs
+    self.out_dtype = torch.float32      # RecNet(dc_storage='bf16') switches the block's last conv to bf16 output
 
   def weight_init_params(self, user_weight_init=None):
     first = self.layers['1']
@@ -62,7 +63,7 @@ class ConvBlock(nn.Module):
     cps = [self.layers[str(3 * i + 1)] for i in range(n)]
     plan = [(cp.layer, 1.0 if i == n - 1 else self.slope) for i, cp in enumerate(cps)]
     params = [p for cp in cps for p in (cp.weight, cp.bias)]
-    return ops.ConvActStack.apply(x, plan, torch.float32, *params)
+    return ops.ConvActStack.apply(x, plan, self.out_dtype, *params)
 
 
 class RecNet(nn.Module):
@@ -71,7 +72,7 @@ class RecNet(nn.Module):
   def __init__(self, num_blocks, num_convs, num_filters, num_final_outputs=2,
                dilations_per_conv=1, kernel_size=3, relu_leakiness=DEFAULT_RELU_LEAKINESS,
                padding='zero', use_refinement=False, skip_final_dc=False,
-               return_intermediate_recs=False, compute_dtype=None):
+               return_intermediate_recs=False, compute_dtype=None, dc_storage=None):
     super(RecNet, self).__init__()
     if isinstance(num_filters, int):
       num_filters = [num_filters] * num_blocks
@@ -91,6 +92,18 @@ class RecNet(nn.Module):
     self.use_refinement = use_refinement
     self.skip_final_dc = skip_final_dc
     self.return_intermediate_recs = return_intermediate_recs
+    # 'bf16': the conv blocks hand the data-consistency layers bf16 images and the FFT passes keep their
+    # images / intermediates in bf16 (csmri_dc_bf16, the "bf16 cFFT" of BASELINE config 5; default with
+    # compute_dtype 'fp8').  Default 'fp32' keeps the image path of the cascade in fp32 (PSNR parity).
+    from models.utils import default_fp8_forward
+    if dc_storage is None:
+      dc_storage = 'bf16' if (compute_dtype == 'fp8' or (compute_dtype is None and default_fp8_forward())) else 'fp32'
+    assert dc_storage in ('fp32', 'bf16')
+    self.dc_storage = dc_storage
+    if dc_storage == 'bf16':
+      assert dtype == torch.bfloat16 and not use_refinement, 'bf16 DC storage needs bf16 compute without refinement'
+      for block in self.conv_blocks:
+        block.out_dtype = torch.bfloat16
 
   def forward(self, inp, kspace, mask):
     """inp, kspace, mask: [B,2,H,W] fp32 (re, im planes).  Returns [B,2,H,W]."""
@@ -131,11 +144,12 @@ class _PadAlias(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x_c, x_pad):
+    ctx.dt = x_c.dtype
     return x_pad.view_as(x_pad)
 
   @staticmethod
   def backward(ctx, g):
-    return ops.copy_channels(g, 2, torch.float32), None
+    return ops.copy_channels(g, 2, ctx.dt), None
 
 
 class _CastPad(torch.autograd.Function):

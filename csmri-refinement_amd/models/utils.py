@@ -25,6 +25,10 @@ def set_default_compute_dtype(name_or_dtype):
   _FP8_FORWARD[0] = name_or_dtype == 'fp8'
 
 
+def default_fp8_forward():
+  return _FP8_FORWARD[0]
+
+
 def set_fp8_forward(module, on=True):
   """Switch the fp8 forward variant of every trainable convolution under ``module``."""
   n = 0

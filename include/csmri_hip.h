@@ -236,6 +236,14 @@ size_t csmri_dc_work_bytes(int B, int H, int W);
  * (normalized=True); ortho == 0: forward unscaled, inverse 1/(HW) (pytorch_fft.fft2 / ifft2).
  * H, W powers of two in [32, 512]. */
 int csmri_fft2(const float* x, float* out, int B, int H, int W, int inverse, int ortho, void* stream);
+/* bf16 image storage ("bf16 cFFT", BASELINE config 5): the same passes with x, out and the intermediate
+ * between them held as interleaved complex bf16 (4 bytes per value; x_pix_stride in bf16 elements, 8 reads
+ * channels 0,1 of a channel-padded bf16 conv output); arithmetic fp32 in registers / LDS; k0 stays fp32.
+ * The reference's transform (myfft.py:78-163) is fp32; stated tolerance of this storage format:
+ * 1e-2 of the output's maximum (tests/test_hip_ops.py). */
+int csmri_fft2_bf16(const void* x, void* out, int B, int H, int W, int inverse, int ortho, void* stream);
+int csmri_dc_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, void* out,
+                  void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream);
 
 /* layout converters (H2D boundary: batch dict tensors are NCHW fp32,
  * training/base_runner.py:29-41) */

@@ -256,6 +256,57 @@ def test_dc(hip, shape):
   assert torch.allclose(out2.cpu(), xd.detach().cpu(), atol=2e-5)
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 64), (1, 256, 256), (2, 128, 32), (1, 512, 512)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_dc_and_fft2_bf16_storage(hip, shape):
+  """The "bf16 cFFT" of BASELINE config 5 (csmri_dc_bf16 / csmri_fft2_bf16): images and the intermediates between
+  the three passes are stored as bf16, arithmetic is fp32.  Checked against (a) a numpy restatement that rounds at
+  exactly those storage points (float64 arithmetic in between): relative L2 <= 1e-3 (isolated one-ulp flips where
+  the fp32 value sits on a bf16 rounding boundary); (b) the exact transform (myfft.py:131-163 in float64):
+  relative L2 <= 5e-3, max error <= 1e-2 of the output maximum -- the cost of the storage format."""
+  ops = hip.ops
+  b, h, w = shape
+  rng = np.random.RandomState(h * 3 + w)
+
+  def bf(a):      # round a complex float64 array to bf16 storage
+    t = torch.from_numpy(np.stack((a.real, a.imag), -1)).float().bfloat16().double().numpy()
+    return t[..., 0] + 1j * t[..., 1]
+  x = bf(rng.randn(b, h, w) + 1j * rng.randn(b, h, w))
+  m = rng.rand(b, h, w) < 0.3
+  k0 = ((rng.randn(b, h, w) + 1j * rng.randn(b, h, w)) * m).astype(np.complex64).astype(np.complex128)
+  sc = 1.0 / np.sqrt(h * w)
+  exact = np.fft.ifft2(np.where(m, 0, np.fft.fft2(x, norm='ortho')) + k0, norm='ortho')
+  t = bf(np.fft.fft(x, axis=2))                                   # pass 1: rows, unscaled
+  t = np.where(m, 0, np.fft.fft(t, axis=1) * sc) + k0              # pass 2: columns, scale, merge ...
+  t = bf(np.fft.ifft(t, axis=1) * h)                               # ... inverse columns (unscaled)
+  emu = bf(np.fft.ifft(t, axis=2) * w * sc)                        # pass 3: inverse rows, scale
+  xd = torch.from_numpy(np.stack((x.real, x.imag), -1)).bfloat16().cuda()
+  k0d = torch.from_numpy(np.stack((k0.real, k0.imag), -1)).float().cuda()
+  mu8 = torch.from_numpy(m.astype(np.uint8)).cuda()
+  out, pad = ops.dc_raw(xd, k0d, mu8, torch.bfloat16)
+  assert out.dtype == torch.bfloat16
+  got = out.float().cpu().numpy().astype(np.float64)
+  got = got[..., 0] + 1j * got[..., 1]
+  e_emu = np.linalg.norm(got - emu) / np.linalg.norm(emu)
+  e_ex = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+  e_max = np.abs(got - exact).max() / np.abs(exact).max()
+  print('dc bf16 %s vs rounding restatement %.2e | vs exact rel_l2 %.2e max %.2e' % (shape, e_emu, e_ex, e_max))
+  assert e_emu < 1e-3 and e_ex < 5e-3 and e_max < 1e-2
+  assert torch.equal(pad[..., :2], out) and float(pad[..., 2:].float().abs().max()) == 0.0
+  # channel-padded bf16 conv output as the input (pixel stride 8)
+  x8 = torch.zeros(b, h, w, 8, dtype=torch.bfloat16, device='cuda')
+  x8[..., :2] = xd
+  x8[..., 2:] = 7.0
+  out8, _ = ops.dc_raw(x8, k0d, mu8, None)
+  assert torch.equal(out8, out)
+  # stand-alone transform, both directions
+  for inverse in (False, True):
+    ref = (np.fft.ifft2 if inverse else np.fft.fft2)(x, norm='ortho')
+    g2 = ops.fft2(xd, inverse, True).float().cpu().numpy().astype(np.float64)
+    err = np.linalg.norm((g2[..., 0] + 1j * g2[..., 1]) - ref) / np.linalg.norm(ref)
+    assert err < 4e-3, (inverse, err)
+
+
 def test_layout_roundtrip(hip):
   ops = hip.ops
   x = torch.randn(2, 3, 8, 12)

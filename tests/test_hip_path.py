@@ -116,6 +116,45 @@ def test_recnet_bf16_psnr_within_0p01_db(env):
   assert float((k - kr)[m].abs().max()) < 1e-4
 
 
+def test_recnet_bf16_dc_storage_forward_backward(env):
+  """RecNet(dc_storage='bf16') -- the "bf16 cFFT" of BASELINE config 5: the conv blocks hand bf16 images to the
+  data-consistency layers and the FFT passes store bf16 (csmri_dc_bf16).  256x256, 5 cascades, against the fp32
+  CPU oracle.  Stated tolerance of this storage choice: PSNR within 0.05 dB (measured ~0.01-0.02 dB: every
+  cascade rounds the image to 8 mantissa bits, which the default fp32 image path avoids), prediction relative
+  L2 <= 1e-2, MSE-loss gradient of every parameter cos >= 0.99 with the oracle's."""
+  Configuration, set_dtype = env
+  from models import construct_model
+  conf = recnet_conf(Configuration, 5, 'bf16')
+  conf.model['dc_storage'] = 'bf16'
+  mc = Configuration.from_dict(conf.model, conf)
+  torch.manual_seed(0)
+  model = construct_model(mc, 'RecNet').cuda().train()
+  assert model.dc_storage == 'bf16'
+  P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+  batch = O.synth_batch(2, 256, 256, acc=4, seed=7)
+  pred = model(batch['inp'].cuda(), batch['kspace'].cuda(), batch['mask'].cuda())
+  ref = O.recnet_forward(P, batch['inp'], batch['kspace'], batch['mask'], 5)
+  p_hip, p_ref = O.psnr_batch(pred.detach().cpu(), batch['target']), O.psnr_batch(ref.detach(), batch['target'])
+  rel = float((pred.detach().cpu() - ref.detach()).norm() / ref.detach().norm())
+  print('recnet bf16 + bf16 DC storage: psnr hip %.4f cpu %.4f delta %.5f dB rel_l2 %.3e' %
+        (p_hip, p_ref, abs(p_hip - p_ref), rel))
+  assert abs(p_hip - p_ref) < 0.05 and rel < 1e-2
+  ((pred - batch['target'].cuda()) ** 2).mean().backward()
+  ((ref - batch['target']) ** 2).mean().backward()
+  worst = 1.0
+  gmax = max(float(P[k].grad.norm()) for k, _ in model.named_parameters())
+  for k, p in model.named_parameters():
+    if float(P[k].grad.norm()) < 1e-4 * gmax:
+      # bias of a block's last conv: its gradient is the pixel sum of a DC-adjoint output, whose k-space
+      # origin is sampled -- exactly zero in exact arithmetic, rounding noise in any implementation
+      assert float(p.grad.norm()) < 1e-2 * gmax, (k, float(p.grad.norm()), gmax)
+      continue
+    cos, err = _cos_err(p.grad.cpu(), P[k].grad)
+    worst = min(worst, cos)
+    assert cos > 0.99, (k, cos, err)
+  print('recnet bf16 DC storage: worst gradient cosine %.5f' % worst)
+
+
 def gan_conf(Configuration, dtype, small=True):
   conf = Configuration.from_json(os.path.join(PKG, 'configs', '2-refinement.json'))
   conf.batch_size = 2
