@@ -288,8 +288,13 @@ extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   // 3 slices (768 workgroups), smaller ones ~512 workgroups (less slab traffic for the same latency hiding)
   static const char* tgt_env = getenv("CSMRI_GCONV_BLOCKS");       // tuning knob: target workgroups
   static const char* nos_env = getenv("CSMRI_GCONV_NOSPLIT_TILES");   // A/B knob
-  if (tiles >= (nos_env ? atoi(nos_env) : 224)) return 1;
-  const int target = tgt_env ? atoi(tgt_env) : (tiles >= 192 ? 768 : 512);
+  // ... except deep-K problems at exactly one workgroup per CU (VGG conv4_x data gradients on 8 images: 256 tiles,
+  // 72 steps): 2 slices = 2 workgroups per CU overlap each other's loads, 53.7 vs 64.1 us incl. the reduce
+  // (tools/sk_sweep.sh); at 32 steps (U-Net 128 -> 128 4x4) the same split loses 2x
+  static const char* deep_env = getenv("CSMRI_GCONV_DEEP_SPLIT");   // A/B knob: 0 disables
+  const bool deep = !(deep_env && atoi(deep_env) == 0) && tiles <= 256 && nsteps >= 64 && !d->out_halo && nclass == 1;
+  if (tiles >= (nos_env ? atoi(nos_env) : 224) && !deep) return 1;
+  const int target = tgt_env ? atoi(tgt_env) : (deep ? 512 : tiles >= 192 ? 768 : 512);
   int sk = (int)((target + tiles - 1) / tiles);
   int maxsk = nsteps / 8; if (maxsk < 1) maxsk = 1;
   if (sk > maxsk) sk = maxsk;

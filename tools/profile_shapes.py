@@ -9,16 +9,14 @@ import bench
 from csmri_hip import ops
 from data.synthetic import synth_batch
 
-runner, conf = bench.build_runner('bf16', 8)
+runner, conf = bench.build_runner('c3', 'bf16', 8)
 dev = torch.device('cuda', 0)
 hb = [synth_batch(8, 256, 256, acc=4, seed=i) for i in range(2)]
-batches = [{k: v.to(dev) for k, v in b.items()} for b in hb]
-loader = bench.DeviceLoader(batches, 3)
-runner.train_epoch(loader, 0)
+runner.train_epoch(bench.PinnedHostLoader(hb, 3, dev, resident=True), 0)
 ops.PROFILE_SHAPES = True
 ops.PROFILE = []
 steps = 3
-runner.train_epoch(bench.DeviceLoader(batches, steps), 1)
+runner.train_epoch(bench.PinnedHostLoader(hb, steps, dev, resident=True), 1)
 torch.cuda.synchronize()
 recs, ops.PROFILE = ops.PROFILE, None
 agg = {}
