@@ -51,6 +51,21 @@ class GConvDesc(C.Structure):
   ]
 
 
+class ConvBlockDesc(C.Structure):
+  _fields_ = [
+      ('dtype', i32),
+      ('num_convs', i32), ('num_filters', i32), ('kernel_size', i32), ('num_inputs', i32), ('num_outputs', i32),
+      ('border', i32),
+      ('x', vp), ('x_pix_stride', i32),
+      ('B', i32), ('H', i32), ('W', i32),
+      ('w', vp * 3), ('Kp', i32 * 3),
+      ('bias', vp * 3),
+      ('slope', f32),
+      ('act', vp * 2), ('act_pix_stride', i32 * 2),
+      ('out', vp), ('out_dtype', i32), ('out_pix_stride', i32),
+  ]
+
+
 class PackItem(C.Structure):
   _fields_ = [('w', vp), ('out', vp), ('mode', i32), ('dtype', i32), ('Cout', i32), ('Cin', i32),
               ('KH', i32), ('KW', i32)]
@@ -92,6 +107,8 @@ _SIGS = {
                                 C.POINTER(i64), C.POINTER(i32), vp]),
     'csmri_pack_weight_multi': (i32, [vp, i32, vp]),
     'csmri_absmax': (i32, [i32, vp, i64, vp, vp]),
+    'csmri_convblock_fused_supported': (i32, [vp]),
+    'csmri_convblock_fused_fwd': (i32, [vp, vp]),
     'csmri_quantize_fp8': (i32, [i32, vp, vp, i64, vp, vp, vp]),
     'csmri_wgrad': (i32, [C.POINTER(WGradDesc), vp]),
     'csmri_wgrad_slab_bytes': (sz, [C.POINTER(WGradDesc)]),

@@ -8,6 +8,7 @@ padded to a multiple of 8, pad channels zero) in the compute dtype
 (``stride(3)==1``, dense in B,H,W).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -661,6 +662,56 @@ class ConvAct(torch.autograd.Function):
     return gx0, gx1, None, None, None, None, None
 
 
+# RecNet conv blocks of the supported shape run as one launch (csmri_convblock_fused_fwd); env knob for A/B runs
+FUSED_CONVBLOCK = not os.environ.get('CSMRI_NO_FUSED_CONVBLOCK')
+
+
+def convblock_fused_forward(x, plan, out_dtype_last, need_acts):
+  """The whole conv block in one launch (csrc/convblock.hip) when its shape is the supported one, else None.
+  Returns [x, a1, a2, y] (a1 / a2 = None when ``need_acts`` is false: nothing of them reaches HBM)."""
+  if len(plan) != 3 or x.dtype != torch.bfloat16 or not is_nhwc(x):
+    return None
+  layers = [l for l, _ in plan]
+  slopes = [s for _, s in plan]
+  if slopes[0] != slopes[1] or slopes[2] != 1.0 or any(l.bias is None or l.fp8 for l in layers):
+    return None
+  d = lib.ConvBlockDesc()
+  d.dtype = BF16
+  l0 = layers[0]
+  d.num_convs, d.num_filters, d.kernel_size = 3, l0.cout, l0.kh
+  d.num_inputs, d.num_outputs, d.border = l0.cin, layers[2].cout, l0.border
+  d.slope = float(slopes[0])
+  chain_ok = all(l.kh == l.kw == l0.kh and l.stride == 1 and not l.upsample and l.border == l0.border and
+                 l.dtype == torch.bfloat16 and tuple(l.pads) == (1, 1, 1, 1) for l in layers) and \
+      layers[1].cin == layers[1].cout == l0.cout and layers[2].cin == l0.cout and x.shape[3] == l0.cin_p
+  if not chain_ok or not lib.raw('csmri_convblock_fused_supported')(C.byref(d)):
+    return None
+  _need_gpu(x)
+  b, h, w, _ = x.shape
+  keep = []
+  for i, l in enumerate(layers):
+    wp, kp, _, _ = l._pack(0)
+    bp = l.bias_padded()
+    d.w[i], d.Kp[i], d.bias[i] = wp.data_ptr(), kp, bp.data_ptr()
+    keep += [wp, bp]
+  d.x, d.x_pix_stride, d.B, d.H, d.W = x.data_ptr(), x.stride(2), b, h, w
+  d.slope = float(slopes[0])
+  a1 = a2 = None
+  if need_acts:
+    a1 = torch.empty(b, h, w, layers[0].cout_p, dtype=torch.bfloat16, device=x.device)
+    a2 = torch.empty(b, h, w, layers[1].cout_p, dtype=torch.bfloat16, device=x.device)
+    d.act[0], d.act[1] = a1.data_ptr(), a2.data_ptr()
+    d.act_pix_stride[0], d.act_pix_stride[1] = a1.stride(2), a2.stride(2)
+  y = torch.empty(b, h, w, layers[2].cout_p, dtype=out_dtype_last or torch.bfloat16, device=x.device)
+  d.out, d.out_dtype, d.out_pix_stride = y.data_ptr(), dt_of(y), y.stride(2)
+  if LAUNCH_LOG is not None:
+    LAUNCH_LOG.append(('convblock', 'convblock_fwd_kernel<%s>' % ('true' if need_acts else 'false'), 1))
+  flops = 2.0 * b * h * w * 9 * (l0.cin * l0.cout + l0.cout * l0.cout + l0.cout * layers[2].cout)
+  with _Timed('convblock_fwd_kernel', flops):
+    lib.call('csmri_convblock_fused_fwd', C.byref(d), stream())
+  return [x, a1, a2, y]
+
+
 class ConvActStack(torch.autograd.Function):
   """A chain of (pad -> conv -> +bias -> LeakyReLU) layers as ONE autograd node (RecNet's ConvBlock,
   reference models/recnet.py:29-62).  Same kernels as ConvAct per layer; in the backward the activation
@@ -673,11 +724,17 @@ class ConvActStack(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, plan, out_dtype_last, *params):
-    saved, cur = [x], x
     n = len(plan)
-    for i, (layer, slope) in enumerate(plan):
-      cur, _ = conv_forward(layer, cur, None, True, slope, False, out_dtype_last if i == n - 1 else None)
-      saved.append(cur)
+    saved = None
+    if FUSED_CONVBLOCK:
+      need_acts = any(ctx.needs_input_grad[i] for i in (0,) + tuple(range(3, 3 + len(params))))
+      saved = convblock_fused_forward(x, plan, out_dtype_last, need_acts)
+    if saved is None:
+      saved, cur = [x], x
+      for i, (layer, slope) in enumerate(plan):
+        cur, _ = conv_forward(layer, cur, None, True, slope, False, out_dtype_last if i == n - 1 else None)
+        saved.append(cur)
+    cur = saved[-1]
     ctx.plan = plan
     ctx.w_req = [layer.weight.requires_grad and layer.train_weights for layer, _ in plan]
     ctx.save_for_backward(*saved)

@@ -147,6 +147,31 @@ typedef struct csmri_pack_item {
 int csmri_pack_weight_multi(const csmri_pack_item* items_dev, int n, void* stream);
 
 /* ------------------------------------------------------------------------
+ * One RecNet conv block as a single launch (SURVEY 8b `csmri_convblock_fused_fwd`):
+ *   [ZeroPad(1) -> Conv3x3 + bias -> LeakyReLU(slope)] x (num_convs-1) -> ZeroPad(1) -> Conv3x3 + bias
+ * (reference models/recnet.py:29-62, padding rule models/utils.py:75-85), intermediates kept in LDS, halo rings
+ * recomputed.  Supported: bf16, num_convs 3, num_filters 32, kernel 3, 2 -> 2 channels, zero padding
+ * (csmri_convblock_fused_supported); anything else: the per-layer csmri_gconv path.
+ * x: [B,H,W,>=8] bf16, channels 0,1; w[i] / Kp[i]: csmri_pack_weight(mode 0, CSMRI_BF16) of layer i; bias[i]:
+ * fp32, zero padded to >= 32 / 32 / 16 entries; out: [B,H,W,>=8] of out_dtype, channels 0..7 written (2..7 zero).
+ * act[0], act[1] (both or neither): if set, the activations after layer 1 and 2, [B,H,W,>=32] bf16, are also
+ * written (what the data-gradient / weight-gradient kernels of the backward pass read).
+ * ---------------------------------------------------------------------- */
+typedef struct csmri_convblock_desc {
+  int dtype;
+  int num_convs, num_filters, kernel_size, num_inputs, num_outputs, border;
+  const void* x; int x_pix_stride;
+  int B, H, W;
+  const void* w[3]; int Kp[3];
+  const float* bias[3];
+  float slope;
+  void* act[2]; int act_pix_stride[2];
+  void* out; int out_dtype; int out_pix_stride;
+} csmri_convblock_desc;
+int csmri_convblock_fused_supported(const csmri_convblock_desc* d);
+int csmri_convblock_fused_fwd(const csmri_convblock_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------
  * fp8 operand preparation (BASELINE.json config 5: "fp8 MFMA convs").  The reference has no fp8 path;
  * the variant computes the same nn.Conv2d (models/unet.py:40-52, models/discriminators.py,
  * models/vgg.py) on operands rounded to OCP e4m3fn with one power-of-two scale per tensor:

@@ -307,6 +307,66 @@ def test_dc_and_fft2_bf16_storage(hip, shape):
     assert err < 4e-3, (inverse, err)
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 64), (1, 256, 256), (3, 40, 56), (2, 17, 33), (1, 512, 512)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_convblock_fused_equals_per_layer_path(hip, shape):
+  """csmri_convblock_fused_fwd (one launch for RecNet's [pad, conv, LeakyReLU] x 2 + [pad, conv] block, reference
+  models/recnet.py:29-62) against the per-layer csmri_gconv path it replaces: output, both saved activations and --
+  through the unchanged backward kernels -- every gradient must be BIT-IDENTICAL (same K order per output
+  element; halo pixels are recomputed with the same arithmetic as their owner tile); and against the CPU oracle on
+  bf16-rounded operands within the bf16 tolerance of the per-layer tests (relative L2 <= 1e-2)."""
+  ops = hip.ops
+  b, h, w = shape
+  g = torch.Generator().manual_seed(h * 5 + w)
+  ws = [torch.randn(32, 2, 3, 3, generator=g) * 0.4, torch.randn(32, 32, 3, 3, generator=g) * 0.08,
+        torch.randn(2, 32, 3, 3, generator=g) * 0.08]
+  bs = [torch.randn(32, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(2, generator=g) * 0.1]
+  x = torch.randn(b, 2, h, w, generator=g)
+  gy = torch.randn(b, 2, h, w, generator=g)
+
+  def run(fused, train):
+    ops.FUSED_CONVBLOCK = fused
+    try:
+      params = [(torch.nn.Parameter(wt.clone().cuda(), requires_grad=train),
+                 torch.nn.Parameter(bi.clone().cuda(), requires_grad=train)) for wt, bi in zip(ws, bs)]
+      plan = [(ops.ConvLayer(wp, bp, 1, (1, 1, 1, 1), 'zero', torch.bfloat16), 0.01 if i < 2 else 1.0)
+              for i, (wp, bp) in enumerate(params)]
+      xd = to_dev_nhwc(x, torch.bfloat16).requires_grad_(train)
+      log = ops.LAUNCH_LOG = []
+      y = ops.ConvActStack.apply(xd, plan, torch.float32, *[t for pr in params for t in pr])
+      names = [e[1] for e in log]
+      ops.LAUNCH_LOG = None
+      grads = None
+      if train:
+        y.backward(to_dev_nhwc(gy, torch.float32))
+        ops.join_wgrad_stream()
+        grads = [xd.grad.clone()] + [t.grad.clone() for pr in params for t in pr]
+      torch.cuda.synchronize()
+      return y.detach().clone(), grads, names
+    finally:
+      ops.FUSED_CONVBLOCK = True
+      ops.LAUNCH_LOG = None
+  for train in (False, True):
+    yf, gf, nf = run(True, train)
+    yu, gu, nu = run(False, train)
+    assert nf == ['convblock_fwd_kernel<%s>' % ('true' if train else 'false')], nf
+    assert len(nu) == 3 and not any('convblock' in n for n in nu), nu
+    assert torch.equal(yf, yu), float((yf - yu).abs().max())
+    assert float(yf[..., 2:].abs().max()) == 0.0
+    if train:
+      for a, c in zip(gf, gu):
+        assert torch.equal(a, c)
+  # oracle: the reference block on bf16-rounded operands (fp32 accumulate), intermediates rounded to bf16
+  r = x.bfloat16().float()
+  for i in range(3):
+    r = F.conv2d(F.pad(r, (1, 1, 1, 1)), ws[i].bfloat16().float(), bs[i])
+    if i < 2:
+      r = F.leaky_relu(r, 0.01).bfloat16().float()
+  err = rel_l2(from_dev_nhwc(yf, 2), r)
+  print('convblock fused %s vs oracle rel_l2 %.3e' % (shape, err))
+  assert err < 1e-2
+
+
 def test_layout_roundtrip(hip):
   ops = hip.ops
   x = torch.randn(2, 3, 8, 12)
