@@ -57,6 +57,17 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   return __builtin_bit_cast(unsigned short, h);
 }
 
+// four floats -> four bf16 (RNE) with two v_cvt_pk_bf16_f32: the scalar form costs a conversion, a shift and an
+// or per pair on top (PMC: 3-4 VALU instructions per MFMA in the conv kernels, much of it epilogue)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ u32x2_t pack4_bf16(f32x4_t v) {
+  u32x2_t u;
+  u[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t));
+  u[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t));
+  return u;
+}
+
 // typed scalar load/store by runtime dtype
 __device__ __forceinline__ float load_elem(const void* p, long long idx, int dt) {
   if (dt == CSMRI_F32) return ((const float*)p)[idx];
@@ -83,10 +94,7 @@ __device__ __forceinline__ void store4(void* p, long long idx, int dt, f32x4_t v
   if (dt == CSMRI_F32) {
     *(f32x4_t*)((float*)p + idx) = v;
   } else {
-    u32x2_t u;
-    u[0] = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-    u[1] = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-    *(u32x2_t*)((unsigned short*)p + idx) = u;
+    *(u32x2_t*)((unsigned short*)p + idx) = pack4_bf16(v);
   }
 }
 

@@ -51,14 +51,7 @@ struct CBParams {
 #define CB_A2_BYTES (4 * CB_A2PX * 16)
 #define CB_LDS (CB_P0_BYTES + CB_A1_BYTES + CB_A2_BYTES)
 
-typedef __attribute__((ext_vector_type(2))) float cb_f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 cb_bf16x2_t;
-__device__ __forceinline__ u32x2_t cb_pack4(f32x4_t v) {      // two v_cvt_pk_bf16_f32 (RNE), no shifts / ors
-  u32x2_t u;
-  u[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((cb_f32x2_t){v[0], v[1]}, cb_bf16x2_t));
-  u[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((cb_f32x2_t){v[2], v[3]}, cb_bf16x2_t));
-  return u;
-}
+__device__ __forceinline__ u32x2_t cb_pack4(f32x4_t v) { return pack4_bf16(v); }
 
 // LeakyReLU as max(v, slope*v) (0 <= slope <= 1: exactly v or slope*v, the reference's v*slope rounding); the
 // in-image flag is only applied on tiles that touch the image border (wave-uniform branch)
