@@ -72,6 +72,10 @@ template <int LOGN> struct FftCfg {
 template <int LOGN> struct LaneTw {
   float2 reg[FftCfg<LOGN>::LOGR > 0 ? FftCfg<LOGN>::LOGR : 1];
   float2 lane[FftCfg<LOGN>::LOGL];
+  // lane-level stages are written branch-free: the pair's LOWER lane (bit `half` of the lane index clear) uses the
+  // twiddle 1 and the sign +1, the UPPER lane its factor and the sign -1 -- a divergent if/else costs both sides
+  // plus the exec-mask bookkeeping (41 branches per transform in the first version)
+  float sgn[FftCfg<LOGN>::LOGL];
   __device__ __forceinline__ void init(int l) {
     typedef FftCfg<LOGN> C;
 #pragma unroll
@@ -79,7 +83,10 @@ template <int LOGN> struct LaneTw {
 #pragma unroll
     for (int s = 0; s < C::LOGL; ++s) {
       const int half = C::L >> (s + 1);
-      lane[s] = tw512((l & (half - 1)) * (256 / (half > 0 ? half : 1)));                     // w_{2 half}^(l mod half)
+      const bool upper = (l & half) != 0;
+      const float2 w = tw512((l & (half - 1)) * (256 / (half > 0 ? half : 1)));              // w_{2 half}^(l mod half)
+      lane[s] = upper ? w : make_float2(1.f, 0.f);
+      sgn[s] = upper ? -1.f : 1.f;
     }
   }
 };
@@ -115,16 +122,14 @@ __device__ __forceinline__ void fft_dif(float2 (&v)[FftCfg<LOGN>::R], const Lane
 #pragma unroll
   for (int s = 0; s < C::LOGL; ++s) {
     const int half = C::L >> (s + 1);
-    const bool upper = (lane & half) != 0;
+    float px[C::R], py[C::R];
+#pragma unroll
+    for (int q = 0; q < C::R; ++q) { px[q] = __shfl_xor(v[q].x, half); py[q] = __shfl_xor(v[q].y, half); }
 #pragma unroll
     for (int q = 0; q < C::R; ++q) {
-      const float px = __shfl_xor(v[q].x, half), py = __shfl_xor(v[q].y, half);
-      if (upper) {
-        const float2 d = make_float2(px - v[q].x, py - v[q].y);
-        v[q] = half > 1 ? cmul(d, tw.lane[s]) : d;
-      } else {
-        v[q] = make_float2(v[q].x + px, v[q].y + py);
-      }
+      // lower lane: v + p; upper lane: (p - v) * w
+      const float2 d = make_float2(fmaf(tw.sgn[s], v[q].x, px[q]), fmaf(tw.sgn[s], v[q].y, py[q]));
+      v[q] = half > 1 ? cmul(d, tw.lane[s]) : d;
     }
   }
 }
@@ -136,15 +141,17 @@ __device__ __forceinline__ void fft_dit_inv(float2 (&v)[FftCfg<LOGN>::R], const 
 #pragma unroll
   for (int s = C::LOGL - 1; s >= 0; --s) {
     const int half = C::L >> (s + 1);
-    const bool upper = (lane & half) != 0;
+    // both lanes of a pair need conj(w) * b, b = the upper lane's value: the upper lane forms it (the lower
+    // lane's factor is 1), both exchange, then lower = a + w'b, upper = a - w'b = p - (own w'b)
+    float2 wb[C::R];
+    float px[C::R], py[C::R];
 #pragma unroll
     for (int q = 0; q < C::R; ++q) {
-      // both lanes of a pair need conj(w) * b, b = the upper lane's value
-      const float2 wb = half > 1 ? cmulc(v[q], tw.lane[s]) : v[q];
-      const float2 mine = upper ? wb : v[q];
-      const float px = __shfl_xor(mine.x, half), py = __shfl_xor(mine.y, half);
-      v[q] = upper ? make_float2(px - wb.x, py - wb.y) : make_float2(v[q].x + px, v[q].y + py);
+      wb[q] = half > 1 ? cmulc(v[q], tw.lane[s]) : v[q];
+      px[q] = __shfl_xor(wb[q].x, half); py[q] = __shfl_xor(wb[q].y, half);
     }
+#pragma unroll
+    for (int q = 0; q < C::R; ++q) v[q] = make_float2(fmaf(tw.sgn[s], wb[q].x, px[q]), fmaf(tw.sgn[s], wb[q].y, py[q]));
   }
 #pragma unroll
   for (int t = C::LOGR - 1; t >= 0; --t) {
