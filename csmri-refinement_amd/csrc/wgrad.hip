@@ -19,6 +19,7 @@ struct WParams {
   int KH, KW, S, pt, pl;
   const char* dy; int dyps; int Ho, Wo, Cout;
   float* slab; int splitk; int M, NK, nsteps, steps_per_split, ptiles, qtiles;
+  int stages;   // wpatch: 2 = the next tile's images stream in under this tile's MFMAs (LDS permitting), 1 = in place
 };
 
 template <int DT>
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
   const int TPW = 16 + p.KW - 1, TPH = 16 + p.KH - 1, npix = TPH * TPW;
   const int xinstr = (npix + XROWS - 1) / XROWS;
   const int IMG_X = xinstr * 1024;                  // dY image follows the patch
-  char* ximg = smem; char* yimg = smem + IMG_X;
+  const int IMG_BOTH = IMG_X + 256 * COUT * 2;      // one stage = patch + dY tile; two stages (double buffer)
   const int taps = p.KH * p.KW;
   const int tiles_x = (p.Wo + 15) >> 4, tiles_y = (p.Ho + 15) >> 4, ntiles = p.B * tiles_x * tiles_y;
   const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
@@ -777,11 +778,23 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
   const int klo = 8 * g + tq;
   const int prow = (klo >> 4) * TPW + (klo & 15);   // patch row of pixel k for tap (0,0), tile row 0
 
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  // this wave's taps (tap pairs for CIN = 8, where the tap is a lane property) as patch-row offsets ty * TPW + tx:
+  // decoded ONCE -- the integer division by the filter width sat inside the K loop (PMC: 9.5 VALU per MFMA)
+  int toff[MAXT];
+#pragma unroll
+  for (int a = 0; a < MAXT; ++a) {
+    const int unit = wid + a * WAVES;
+    int tap = CIN >= 16 ? unit : 2 * unit + (tp >> 1);
+    if (CIN < 16 && tap >= taps) tap = 2 * unit;      // odd tap count: the last pair repeats its first tap
+    const int ty = tap / p.KW, tx = tap - ty * p.KW;
+    toff[a] = ty * TPW + tx;
+  }
+
+  auto stage = [&](int t, char* buf) {
+    char* ximg = buf; char* yimg = buf + IMG_X;
     const int b = t / (tiles_x * tiles_y);
     const int rem = t - b * tiles_x * tiles_y;
     const int y0 = (rem / tiles_x) * 16, x0 = (rem % tiles_x) * 16;
-    // ---- stage the patch and the dY tile ----------------------------------------------------
     for (int i = wid; i < xinstr; i += WAVES) {
       const int P = i * XROWS + xr;
       const int py = (int)__umulhi((unsigned)P, magic), px = P - py * TPW;
@@ -807,17 +820,31 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
       const char* src = ok ? p.dy + ((((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dyps + qoff + chunk * 8) * 2 : w_zero_page;
       __builtin_amdgcn_global_load_lds((wgptr_t)src, (wlptr_t)(yimg + i * 1024), 16, 0, 0);
     }
+  };
+  if (p.stages >= 2 && (int)blockIdx.x < ntiles) stage(blockIdx.x, smem);
+  int it = 0;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x, ++it) {
+    // ---- this tile's images were staged one iteration ahead (LDS-DMA, asynchronous): wait for my pieces, then the
+    // barrier publishes all pieces AND retires every wave's reads of the other stage, which the next tile's DMA
+    // overwrites from here on while this tile is multiplied -----------------------------------------------------
+    if (p.stages < 2) {                       // single stage: every wave is done with the previous tile, then reload
+      if (it) __syncthreads();
+      stage(t, smem);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    char* ximg = smem + (p.stages < 2 ? 0 : (it & 1) * IMG_BOTH); char* yimg = ximg + IMG_X;
+    if (p.stages >= 2 && t + (int)gridDim.x < ntiles) stage(t + gridDim.x, smem + ((it & 1) ^ 1) * IMG_BOTH);
     // ---- 8 K chunks of 32 pixels x my taps -----------------------------------------------------
 #pragma unroll 1
     for (int kc = 0; kc < 8; ++kc) {
       bf16x8_t yf[NF];
       const int yrlo = kc * 32 + klo, yrhi = yrlo + 4;
+      {
+        // chunk n*2 + (tp>>1) = (n*2) ^ (tp>>1): the fragments of a row differ by an XOR of the slot bits only
+        const int ylo = img_off<CQ>(yrlo, tp >> 1) + (tp & 1) * 8, yhi = img_off<CQ>(yrhi, tp >> 1) + (tp & 1) * 8;
 #pragma unroll
-      for (int n = 0; n < NF; ++n) {
-        const int ch = n * 2 + (tp >> 1);
-        yf[n] = tr_frag(yimg, img_off<CQ>(yrlo, ch) + (tp & 1) * 8, img_off<CQ>(yrhi, ch) + (tp & 1) * 8);
+        for (int n = 0; n < NF; ++n) yf[n] = tr_frag(yimg, ylo ^ (n << 5), yhi ^ (n << 5));
       }
       if (wid == 0 && p.nsteps) {                  // p.nsteps != 0: the caller wants the bias gradient
 #pragma unroll
@@ -827,14 +854,12 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
       for (int a = 0; a < MAXT; ++a) {
         const int unit = wid + a * WAVES;
         if constexpr (CIN >= 16) {
-          const int tap = unit;
-          if (tap >= taps) break;                     // wave-uniform
-          const int ty = tap / p.KW, tx = tap - ty * p.KW;
-          const int rlo = prow + (2 * kc + ty) * TPW + tx, rhi = rlo + 4;
+          if (unit >= taps) break;                    // wave-uniform
+          const int rlo = prow + 2 * kc * TPW + toff[a], rhi = rlo + 4;
+          const int xlo = img_off<CPR>(rlo, tp >> 1) + (tp & 1) * 8, xhi = img_off<CPR>(rhi, tp >> 1) + (tp & 1) * 8;
 #pragma unroll
           for (int c = 0; c < CF; ++c) {
-            const int ch = c * 2 + (tp >> 1);
-            const bf16x8_t xf = tr_frag(ximg, img_off<CPR>(rlo, ch) + (tp & 1) * 8, img_off<CPR>(rhi, ch) + (tp & 1) * 8);
+            const bf16x8_t xf = tr_frag(ximg, xlo ^ (c << 5), xhi ^ (c << 5));
 #pragma unroll
             for (int n = 0; n < NF; ++n)
               acc[a][c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[n], acc[a][c][n], 0, 0, 0);
@@ -843,10 +868,7 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
           if (2 * unit >= taps) break;                // wave-uniform
           // lanes tp = 0,1 address the first tap of the pair, tp = 2,3 the second (the last pair of an odd
           // tap count repeats the first tap; its half of the result is never written)
-          int tap = 2 * unit + (tp >> 1);
-          if (tap >= taps) tap = 2 * unit;
-          const int ty = tap / p.KW, tx = tap - ty * p.KW;
-          const int rlo = prow + (2 * kc + ty) * TPW + tx, rhi = rlo + 4;
+          const int rlo = prow + 2 * kc * TPW + toff[a], rhi = rlo + 4;
           const bf16x8_t xf = tr_frag(ximg, rlo * 16 + (tp & 1) * 8, rhi * 16 + (tp & 1) * 8);
 #pragma unroll
           for (int n = 0; n < NF; ++n)
@@ -854,7 +876,6 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
         }
       }
     }
-    __syncthreads();
   }
   // ---- one slab per workgroup: [Cout][NK], NK index = tap * Cin + ci ------------------------------
   if (wid == 0 && p.nsteps && g == 0) {            // row 0 of the ones product: sum over pixels per output channel
@@ -911,10 +932,15 @@ static int wpatch_groups(const csmri_wgrad_desc* d) {
   return (int)(g < 1 ? 1 : g);
 }
 template <int CIN, int COUT, int WAVES>
-static int launch_wpatch(const WParams& p, hipStream_t st, int qtiles = 1) {
+static int launch_wpatch(const WParams& p0, hipStream_t st, int qtiles = 1) {
+  WParams p = p0;
   const int TPW = 16 + p.KW - 1, TPH = 16 + p.KH - 1;
   const int xrows = 1024 / (CIN / 8 * 16);
-  const int lds = ((TPH * TPW + xrows - 1) / xrows) * 1024 + 256 * COUT * 2;
+  const int one = ((TPH * TPW + xrows - 1) / xrows) * 1024 + 256 * COUT * 2;
+  // two stages where two workgroups per CU still fit (<= 80 KiB each); the big-patch variants stay single-staged
+  static const char* env = getenv("CSMRI_WPATCH_STAGES");      // A/B knob
+  p.stages = env ? atoi(env) : (2 * one <= 80 * 1024 ? 2 : 1);
+  const int lds = p.stages >= 2 ? 2 * one : one;
   CSMRI_SET_MAX_LDS((wpatch_kernel<CIN, COUT, WAVES>), lds);
   hipLaunchKernelGGL((wpatch_kernel<CIN, COUT, WAVES>), dim3(p.splitk, qtiles), dim3(WAVES * 64), lds, st, p);
   CSMRI_LAUNCH_CHECK();
