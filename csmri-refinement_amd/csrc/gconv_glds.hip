@@ -24,11 +24,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int glds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int BN, int NST>
-__global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_glds_kernel(const GParams p) {
-  constexpr int BM = 128, WM = 2, WN = 2;
+// NW = 8 (experiment, CSMRI_GLDS_WAVES=8): the same tile on 2 x 4 waves, every wave issuing half the LDS-DMA
+template <int BN, int NST, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_glds_kernel(const GParams p) {
+  constexpr int BM = 128, WM = 2, WN = NW / 2;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
-  constexpr int GA = 4, GB = BN / 32;                  // 8-row groups per wave: positions / weights
+  constexpr int GA = 16 / NW, GB = BN / (8 * NW);      // 8-row groups per wave: positions / weights
   constexpr int TILE_Q = BM * 128, BUF = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
   int by[GA], bx[GA], ib[GA];
 #pragma unroll
   for (int j = 0; j < GA; ++j) {
-    const int m = m0 + (j * 4 + wid) * 8 + lrow;
+    const int m = m0 + (j * NW + wid) * 8 + lrow;
     if (m < p.M) {
       int b, oy, ox;
       if (p.howo_shift >= 0) { b = m >> p.howo_shift; const int r = m & (HoWo - 1); oy = r >> p.wo_shift; ox = r & (p.Wo - 1); }
@@ -92,20 +93,20 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
   const char* wptr[GB];
 #pragma unroll
   for (int j = 0; j < GB; ++j)
-    wptr[j] = p.w + ((size_t)cls * (size_t)p.wcs + (size_t)(n0 + (j * 4 + wid) * 8 + lrow) * p.Kp + chunk * 8) * 2 +
+    wptr[j] = p.w + ((size_t)cls * (size_t)p.wcs + (size_t)(n0 + (j * NW + wid) * 8 + lrow) * p.Kp + chunk * 8) * 2 +
               (size_t)s_begin * 128;
 
   auto issue_a = [&](char* buf) {
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(buf + (j * 4 + wid) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(buf + (j * NW + wid) * 1024), 16, 0, 0);
       aptr[j] += ainc[j];
     }
   };
   auto issue_b = [&](char* buf) {
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(buf + TILE_Q + (j * 4 + wid) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(buf + TILE_Q + (j * NW + wid) * 1024), 16, 0, 0);
       wptr[j] += 128;
     }
   };
@@ -117,12 +118,12 @@ __global__ __launch_bounds__(256, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_
   auto issue = [&](int s, char* buf) {
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(buf + (j * 4 + wid) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)aptr[j], (lptr_t)(buf + (j * NW + wid) * 1024), 16, 0, 0);
       aptr[j] += ainc[j];
     }
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(buf + TILE_Q + (j * 4 + wid) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)wptr[j], (lptr_t)(buf + TILE_Q + (j * NW + wid) * 1024), 16, 0, 0);
       wptr[j] += 128;
     }
     ci += 64;
@@ -324,13 +325,13 @@ int gconv_glds_eligible(const csmri_gconv_desc* d) {
   return 1;
 }
 
-template <int BN, int NST>
+template <int BN, int NST, int NW = 4>
 static int launch_glds(const GParams& p, hipStream_t st) {
   constexpr int lds = (128 + BN) * 128 * NST;
   dim3 grid(p.mtiles * p.ntiles, 1, p.nclass * p.splitk);
-  auto kern = gconv_glds_kernel<BN, NST>;
+  auto kern = gconv_glds_kernel<BN, NST, NW>;
   CSMRI_SET_MAX_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, p);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
@@ -360,6 +361,17 @@ int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t 
   static const char* ord = getenv("CSMRI_GLDS_ORDER");          // A/B knob: 0 = mt-major, 1 = nt-major
   p.nt_major = ord ? atoi(ord) : (w_elems > x_elems);
   const int nst = glds_stages((long long)p.mtiles * p.ntiles * p.nclass * p.splitk);   // (kernel_name mirrors this)
+  // 8 waves (2 x 4) instead of 4 (2 x 2) on the same tile: every wave issues half the LDS-DMA instructions.  A wave's
+  // DMA stream is what limits the operand intake of these grid-limited layers (1-2 workgroups per CU): 481 -> 618
+  // TFLOP/s on the U-Net 128 -> 128 4x4 layer, +4..12 % on the discriminator / VGG conv3-4 shapes, -2 % on 16 x 16
+  // maps (tools/w8_sweep.sh).  CSMRI_GLDS_WAVES: A/B knob (4 = round-1 layout everywhere; bit mask 1 = two-buffer
+  // BN 128, 2 = one-buffer BN 128, 4 = BN 64).
+  static const char* nw_env = getenv("CSMRI_GLDS_WAVES");
+  const int nw_mask = nw_env ? (atoi(nw_env) == 4 ? 0 : atoi(nw_env) == 8 ? 7 : atoi(nw_env)) : 1;
+  if (bn == 128 && nst == 2 && (nw_mask & 1)) return launch_glds<128, 2, 8>(p, st);
+  if (bn == 128 && nst == 1 && (nw_mask & 2)) return launch_glds<128, 1, 8>(p, st);
+  if (bn == 64 && nst == 2 && (nw_mask & 4)) return launch_glds<64, 2, 8>(p, st);
+  if (bn == 64 && nst == 1 && (nw_mask & 4)) return launch_glds<64, 1, 8>(p, st);
   if (bn == 128) return nst == 4 ? launch_glds<128, 4>(p, st) : nst == 2 ? launch_glds<128, 2>(p, st) : launch_glds<128, 1>(p, st);
   return nst == 4 ? launch_glds<64, 4>(p, st) : nst == 2 ? launch_glds<64, 2>(p, st) : launch_glds<64, 1>(p, st);
 }
@@ -367,5 +379,10 @@ int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t 
 void gconv_glds_kernel_name(const csmri_gconv_desc* d, char* buf, int n) {
   const int bn = gconv_glds_bn(d), nclass = d->nclass > 0 ? d->nclass : 1, sk = d->splitk > 0 ? d->splitk : 1;
   const long long blocks = (long long)cdiv((long long)d->B * d->Ho * d->Wo, 128) * (d->Cout / bn) * nclass * sk;
-  snprintf(buf, n, "gconv_glds_kernel<%d, %d>", bn, glds_stages(blocks));
+  const int nst = glds_stages(blocks);
+  static const char* nw_env = getenv("CSMRI_GLDS_WAVES");
+  const int nw_mask = nw_env ? (atoi(nw_env) == 4 ? 0 : atoi(nw_env) == 8 ? 7 : atoi(nw_env)) : 1;
+  const bool w8 = (bn == 128 && nst == 2 && (nw_mask & 1)) || (bn == 128 && nst == 1 && (nw_mask & 2)) ||
+                  (bn == 64 && nst <= 2 && (nw_mask & 4));
+  snprintf(buf, n, "gconv_glds_kernel<%d, %d, %d>", bn, nst, w8 ? 8 : 4);
 }
