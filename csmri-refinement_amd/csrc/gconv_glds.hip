@@ -364,7 +364,8 @@ int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t 
   // 8 waves (2 x 4) instead of 4 (2 x 2) on the same tile: every wave issues half the LDS-DMA instructions.  A wave's
   // DMA stream is what limits the operand intake of these grid-limited layers (1-2 workgroups per CU): 481 -> 618
   // TFLOP/s on the U-Net 128 -> 128 4x4 layer, +4..12 % on the discriminator / VGG conv3-4 shapes, -2 % on 16 x 16
-  // maps (tools/w8_sweep.sh).  CSMRI_GLDS_WAVES: A/B knob (4 = round-1 layout everywhere; bit mask 1 = two-buffer
+  // maps; 16 waves (2 x 8) lose 5-12 % again: one fragment column per wave doubles the LDS reads per MFMA
+  // (profiles/r02_gconv_glds_8wave_sweep.log).  CSMRI_GLDS_WAVES: A/B knob (4 = round-1 layout everywhere; bit mask 1 = two-buffer
   // BN 128, 2 = one-buffer BN 128, 4 = BN 64).
   static const char* nw_env = getenv("CSMRI_GLDS_WAVES");
   const int nw_mask = nw_env ? (atoi(nw_env) == 4 ? 0 : atoi(nw_env) == 8 ? 7 : atoi(nw_env)) : 1;

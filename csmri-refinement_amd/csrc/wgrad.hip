@@ -474,10 +474,11 @@ typedef __attribute__((address_space(3))) void* wlptr_t;
 // origin + a per-lane constant, which cuts the address arithmetic from ~100 to ~15 vector
 // instructions per 16-byte piece; the general kernel below is vector-ALU bound on exactly that.
 template <int BP, int BQ, int WP, int WQ, bool REFLECT, bool UPS>
-__global__ __launch_bounds__(256, ((BP == 128 && BQ == 128) || (BP == 256 && BQ == 64)) ? 3 : 4) void wgrad_glds_row_kernel(const WParams p) {
+__global__ __launch_bounds__(64 * WP * WQ, WP * WQ == 8 ? 2 : (((BP == 128 && BQ == 128) || (BP == 256 && BQ == 64)) ? 3 : 4)) void wgrad_glds_row_kernel(const WParams p) {
   constexpr int PS = 64;
+  constexpr int NW = WP * WQ;                         // waves: every wave issues 1/NW of a step's LDS-DMA instructions
   constexpr int CP = BP / 8, CQ = BQ / 8;
-  constexpr int NXI = CP / 4, NYI = (CQ + 3) / 4;
+  constexpr int NXI = CP / NW, NYI = (CQ + NW - 1) / NW;
   constexpr int WTP = BP / WP, WTQ = BQ / WQ, FP = WTP / 16, FQ = WTQ / 16;
   constexpr int IMG_X = 64 * BP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256, ((BP == 128 && BQ == 128) || (BP == 256 && BQ 
   const char* xsrc[NXI]; int xps[NXI], cu[NXI], cw[NXI];
 #pragma unroll
   for (int j = 0; j < NXI; ++j) {
-    const int e = (j * 4 + wid) * 64 + lane, row = e / CP, slot = e % CP;
+    const int e = (j * NW + wid) * 64 + lane, row = e / CP, slot = e % CP;
     const int chunk = ((img_off<CP>(row, slot) >> 4) % CP);
     const int col = p0 + chunk * 8;
     const int ry = p.Wo >= 64 ? 0 : row / p.Wo, rx = p.Wo >= 64 ? row : row - ry * p.Wo;
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(256, ((BP == 128 && BQ == 128) || (BP == 256 && BQ 
   const char* ysrc[NYI]; unsigned ystep[NYI];
 #pragma unroll
   for (int j = 0; j < NYI; ++j) {
-    const int e = (j * 4 + wid) * 64 + lane, row = e / CQ, slot = e % CQ;
+    const int e = (j * NW + wid) * 64 + lane, row = e / CQ, slot = e % CQ;
     const int chunk = ((img_off<CQ>(row, slot) >> 4) % CQ);
     const bool yv = q0 + chunk * 8 < p.Cout;
     ysrc[j] = yv ? p.dy + ((size_t)(s_begin * PS + row) * p.dyps + q0 + chunk * 8) * 2 : w_zero_page;
@@ -540,12 +541,12 @@ __global__ __launch_bounds__(256, ((BP == 128 && BQ == 128) || (BP == 256 && BQ 
       const unsigned pix = (unsigned)sbase + __umul24(u, p.Win) + (unsigned)w;   // < 2^24 (host check)
       const char* g = xsrc[j] + __umul24(pix, xps[j]);
       if (!REFLECT) g = ok ? g : w_zero_page;
-      __builtin_amdgcn_global_load_lds((wgptr_t)g, (wlptr_t)(smem + (j * 4 + wid) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((wgptr_t)g, (wlptr_t)(smem + (j * NW + wid) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < NYI; ++j) {
-      if (CQ % 4 == 0 || j * 4 + wid < CQ) {
-        __builtin_amdgcn_global_load_lds((wgptr_t)ysrc[j], (wlptr_t)(smem + IMG_X + (j * 4 + wid) * 1024), 16, 0, 0);
+      if (CQ % NW == 0 || j * NW + wid < CQ) {
+        __builtin_amdgcn_global_load_lds((wgptr_t)ysrc[j], (wlptr_t)(smem + IMG_X + (j * NW + wid) * 1024), 16, 0, 0);
         ysrc[j] += ystep[j];
       }
     }
@@ -1038,13 +1039,16 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
     CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, false>), lds);
     CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, true>), lds);
     CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, false>), lds);
-    if (refl && p.ups) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, true>), grid, dim3(256), lds, st, p);
-    else if (refl) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, false>), grid, dim3(256), lds, st, p);
-    else if (p.ups) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, true>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, false>), grid, dim3(256), lds, st, p);
-  } else
-    hipLaunchKernelGGL((wgrad_glds_kernel<BP, BQ, WP, WQ>), dim3(p.ptiles * p.qtiles, 1, p.splitk), dim3(256), lds,
-                       st, p);
+    const dim3 blk(64 * WP * WQ);
+    if (refl && p.ups) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, true>), grid, blk, lds, st, p);
+    else if (refl) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, false>), grid, blk, lds, st, p);
+    else if (p.ups) hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, true>), grid, blk, lds, st, p);
+    else hipLaunchKernelGGL((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, false>), grid, blk, lds, st, p);
+  } else {
+    if constexpr (WP * WQ != 4) return CSMRI_E_UNSUPPORTED;     // (callers pick 8 waves only for row-aligned geometries)
+    else hipLaunchKernelGGL((wgrad_glds_kernel<BP, BQ, WP, WQ>), dim3(p.ptiles * p.qtiles, 1, p.splitk), dim3(256), lds,
+                            st, p);
+  }
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
@@ -1107,7 +1111,10 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
     q.nsteps = d->db ? 1 : 0;                      // wpatch reuses the field: also produce the bias-gradient partials
     rc = wpatch_launch(q, d, st);
   } else if (d->dtype == CSMRI_BF16 && !use_tr) {
-    if (c.BQ == 128) rc = launch_wgrad_glds<128, 128, 2, 2>(p, st);
+    static const char* w8_env = getenv("CSMRI_WGRAD_WAVES");     // A/B knob: 8 = 2 x 4 waves on the 128 x 128 tile
+    const bool w8 = w8_env && atoi(w8_env) == 8 && wgrad_row_aligned(d);
+    if (c.BQ == 128 && w8) rc = launch_wgrad_glds<128, 128, 2, 4>(p, st);
+    else if (c.BQ == 128) rc = launch_wgrad_glds<128, 128, 2, 2>(p, st);
     else if (c.BQ == 64 && c.BP == 256) rc = launch_wgrad_glds<256, 64, 4, 1>(p, st);
     else if (c.BQ == 64) rc = launch_wgrad_glds<128, 64, 2, 2>(p, st);
     else if (c.BQ == 32) rc = launch_wgrad_glds<256, 32, 4, 1>(p, st);
