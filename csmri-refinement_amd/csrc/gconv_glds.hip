@@ -3,7 +3,8 @@
 //
 //   D[n][m] = sum_k W[n][k] * X[m][k],  k = (tap, ci),  bf16 operands, fp32 accumulate
 //
-// Tile: 128 positions x BN channels x 64 K per step, 256 threads = 2x2 waves.  One LDS buffer
+// Tile: 128 positions x BN channels x 64 K per step, 2 x 2 waves (256 threads) or, for the two-buffer 128-channel
+// variant, 2 x 4 waves (512 threads: each wave issues half the LDS-DMA, see gconv_glds_launch).  One LDS buffer
 // (16 KiB + BN*128 B): a step is {8 or 6 LDS-DMA per thread -> vmcnt(0) -> barrier -> 2x(8 or 6
 // ds_read_b128 + 16 or 8 MFMA) -> barrier}; 3-4 workgroups per CU overlap one another's loads
 // and MFMAs.  An LDS-DMA wave-instruction writes 1 KiB linearly (8 rows x 128 B), so the XOR
