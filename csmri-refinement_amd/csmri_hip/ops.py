@@ -782,9 +782,25 @@ class BNState(object):
     self.eps, self.momentum = eps, momentum
 
 
+# one-launch BatchNorm forward / backward for small layers (csmri_bn_small_*): correct and tested, measured slower
+# on the step than the three-launch sequences, hence opt-in
+BN_SMALL = bool(os.environ.get('CSMRI_BN_SMALL'))
+
+
 def _bn_forward(y, stats, bn, c_real, slope, training, dropmask, groups=1):
   b, h, w, cp = y.shape
   dev = y.device
+  if BN_SMALL and training and stats is None and lib.raw('csmri_bn_small_eligible')(dt_of(y), b, h * w, cp, groups):
+    # small layer: statistics, running-statistics update and normalise + activation in one launch
+    mean = torch.empty(groups, cp, dtype=torch.float32, device=dev)
+    invstd = torch.empty(groups, cp, dtype=torch.float32, device=dev)
+    snap = torch.empty(2, cp, dtype=torch.float32, device=dev)
+    z = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
+    lib.call('csmri_bn_small_fwd', dt_of(y), y.data_ptr(), y.stride(2), z.data_ptr(), z.stride(2), b, h * w, cp,
+             c_real, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum, bn.running_mean.data_ptr(),
+             bn.running_var.data_ptr(), float(slope), ptr(dropmask), mean.data_ptr(), invstd.data_ptr(),
+             snap.data_ptr(), groups, stream())
+    return z, mean, invstd, snap
   if training:
     if stats is None:
       rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups, cp)
@@ -852,11 +868,6 @@ class ConvBnAct(torch.autograd.Function):
     b, h, w, cp = y.shape
     dev = y.device
     groups = ctx.groups
-    rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups, cp)
-    partial = torch.empty(rows + groups, 2, cp, dtype=torch.float32, device=dev)
-    lib.call('csmri_bn_bwd_reduce', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
-             0, 0, b, h * w, cp, mean.data_ptr(), invstd.data_ptr(),
-             float(ctx.slope), ptr(dropmask), partial.data_ptr(), snap.data_ptr(), groups, stream())
     gy = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
     want_affine = ctx.w_req
     if want_affine:
@@ -864,12 +875,29 @@ class ConvBnAct(torch.autograd.Function):
         bn.weight.grad = torch.zeros_like(bn.weight)
       if bn.bias.grad is None:
         bn.bias.grad = torch.zeros_like(bn.bias)
+    if BN_SMALL and lib.raw('csmri_bn_small_eligible')(dt_of(y), b, h * w, cp, groups):
+      lib.call('csmri_bn_small_bwd', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
+               gy.data_ptr(), gy.stride(2), b, h * w, cp, layer.cout, mean.data_ptr(), invstd.data_ptr(),
+               bn.weight.data_ptr(), float(ctx.slope), ptr(dropmask), snap.data_ptr(),
+               bn.weight.grad.data_ptr() if want_affine else 0, bn.bias.grad.data_ptr() if want_affine else 0,
+               1, groups, stream())
+      return ConvBnAct._finish_backward(ctx, gy, x0, x1, want_affine)
+    rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups, cp)
+    partial = torch.empty(rows + groups, 2, cp, dtype=torch.float32, device=dev)
+    lib.call('csmri_bn_bwd_reduce', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
+             0, 0, b, h * w, cp, mean.data_ptr(), invstd.data_ptr(),
+             float(ctx.slope), ptr(dropmask), partial.data_ptr(), snap.data_ptr(), groups, stream())
     lib.call('csmri_bn_bwd_apply', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
              0, 0, gy.data_ptr(), gy.stride(2), b, h * w, cp, layer.cout,
              mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), float(ctx.slope), ptr(dropmask),
              partial.data_ptr(), rows,
              bn.weight.grad.data_ptr() if want_affine else 0,
              bn.bias.grad.data_ptr() if want_affine else 0, 1, snap.data_ptr(), groups, stream())
+    return ConvBnAct._finish_backward(ctx, gy, x0, x1, want_affine)
+
+  @staticmethod
+  def _finish_backward(ctx, gy, x0, x1, want_affine):
+    layer = ctx.layer
     if want_affine:
       conv_wgrad(layer, x0, x1, gy)
       if GRAD_READY_HOOK is not None:
