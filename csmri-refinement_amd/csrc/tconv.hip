@@ -42,6 +42,13 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
+#ifdef CSMRI_DBG_STAMPS
+  unsigned long long ts[4];
+#define T_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define T_STAMP(i) do {} while (0)
+#endif
+  T_STAMP(0);
   const int tiles_x = (p.Wo + 15) >> 4, tiles_y = (p.Ho + 15) >> 4;
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int b = t / (tiles_x * tiles_y);
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  T_STAMP(1);
 
   // ---- K loop out of LDS -----------------------------------------------------------------
   f32x4_t acc[FN][4];
@@ -120,40 +128,68 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
 #pragma unroll
   for (int i = 0; i < FN; ++i) wbase[i] = tile_off(i * 16 + r16, g);
   int ty = 0, txg = 0, cb = 0;
-  auto compute = [&](const char* wt) {      // wt: this chunk's [BN][64 B] weight tile (wave-uniform)
+  // fragment reads of chunk q+1 are issued BEFORE the MFMAs of chunk q (two register sets): in-kernel stamps showed
+  // the K loop at a third of the MFMA rate with read -> wait -> MFMA per chunk (tools/stamp_tconv.py)
+  auto load_frags = [&](const char* wt, u32x4_t* a, u32x4_t* bw) {   // wt: the chunk's [BN][64 B] weight tile
     const int soff = ((ty * TPW + txg * TPC) << 4) + (CIN >= 32 ? cb * 4 * PLANE : 0);
-    u32x4_t a[4], bw[FN];
 #pragma unroll
     for (int i = 0; i < FN; ++i) bw[i] = *(const u32x4_t*)(wt + wbase[i]);
 #pragma unroll
     for (int f = 0; f < 4; ++f) a[f] = *(const u32x4_t*)(smem + abase[f] + soff);
+    if (++cb == KCH) { cb = 0; if (++txg == groups_x) { txg = 0; ++ty; } }
+  };
+  auto mma = [&](const u32x4_t* a, const u32x4_t* bw) {
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
       for (int f = 0; f < 4; ++f)
         acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bw[i]),
                                                             __builtin_bit_cast(bf16x8_t, a[f]), acc[i][f], 0, 0, 0);
-    if (++cb == KCH) { cb = 0; if (++txg == groups_x) { txg = 0; ++ty; } }
   };
+  // (the 4-workgroups-per-CU variants with 64 output channels have no registers for a second set: 128-VGPR cap)
+  // Measured: +2..6 % on the streamed 64-channel variants, -3 % on the resident-weight ones (more waves per CU hide
+  // the read latency there already), nothing on the step.
+  constexpr int PF = (STREAM && !(CIN <= 32 && FN == 4)) ? 1 : 0;
+  u32x4_t fa[1 + PF][4], fb[1 + PF][FN];
   if (!STREAM) {
-    for (int q = 0; q < nq; ++q) compute(wl + q * WT);
+    if (!PF) {
+      for (int q = 0; q < nq; ++q) { load_frags(wl + q * WT, fa[0], fb[0]); mma(fa[0], fb[0]); }
+    } else if (nq > 0) {
+      // two register sets alternate with STATIC indices (a runtime index would put the fragments in scratch)
+      load_frags(wl, fa[0], fb[0]);
+      for (int q = 0;;) {
+        if (q + 1 < nq) load_frags(wl + (q + 1) * WT, fa[PF], fb[PF]);
+        mma(fa[0], fb[0]);
+        if (++q >= nq) break;
+        if (q + 1 < nq) load_frags(wl + (q + 1) * WT, fa[0], fb[0]);
+        mma(fa[PF], fb[PF]);
+        if (++q >= nq) break;
+      }
+    }
   } else {
     // CPS chunks per stage, two stage buffers: stage st+1 streams in under the MFMAs of stage st
     const int nst = (nq + CPS - 1) / CPS;
     for (int st = 0; st < nst; ++st) {
       char* cur = wl + (st & 1) * CPS * WT;
       char* nxt = wl + ((st & 1) ^ 1) * CPS * WT;
+      const int nc = min(CPS, nq - CPS * st);          // chunks of this stage (wave-uniform)
+      if (PF) load_frags(cur, fa[0], fb[0]);
 #pragma unroll
       for (int c = 0; c < CPS; ++c) {
         const int qn = CPS * (st + 1) + c;             // next stage's chunk c, issued in front of this stage's chunk c
         if (qn < nq) wload(qn, nxt + c * WT);
-        if (CPS * st + c < nq) compute(cur + c * WT);
+        if (c < nc) {
+          if (!PF) load_frags(cur + c * WT, fa[0], fb[0]);
+          else if (c + 1 < nc) load_frags(cur + (c + 1) * WT, fa[(c + 1) & PF], fb[(c + 1) & PF]);
+          mma(fa[c & PF], fb[c & PF]);
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
   }
 
+  T_STAMP(2);
   // ---- epilogue (same contract as gconv) -----------------------------------------------------
   float s1[FN][4], s2[FN][4];
   if (p.stats) {
@@ -204,6 +240,13 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
         }
       }
   }
+#ifdef CSMRI_DBG_STAMPS
+  T_STAMP(3);
+  if (lane == 0 && p.slab && p.splitk == 1) {
+    unsigned long long* dbg = (unsigned long long*)p.slab + ((size_t)blockIdx.x * 4 + wv) * 4;
+    dbg[0] = ts[1] - ts[0]; dbg[1] = ts[2] - ts[1]; dbg[2] = ts[3] - ts[2]; dbg[3] = ts[0];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
