@@ -33,6 +33,9 @@ CASES = {
     'u128': (128, 128, 4, 1, 'reflection', False, 64, 64, 8),
     'disc2b8': (64, 128, 4, 2, 'reflection', False, 64, 64, 8),
     'rec_first': (2, 32, 3, 1, 'zero', False, 256, 256, 8),
+    'unet_head': (32, 1, 1, 1, 'zero', False, 256, 256, 8),
+    'disc_final': (1024, 1, 4, 1, 'zero', False, 8, 8, 16),
+    'disc_first': (1, 64, 4, 2, 'reflection', False, 256, 256, 16),
     'rec_last': (32, 2, 3, 1, 'zero', False, 256, 256, 8),
 }
 
