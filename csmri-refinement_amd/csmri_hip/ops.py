@@ -562,7 +562,13 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
   assert wgt.grad.is_contiguous()
   d.dw = wgt.grad.data_ptr()
   d.db = layer.bias.grad.data_ptr() if layer.bias is not None else 0
-  d.accumulate = int(accumulate)
+  # lazily zeroed gradients (FlatAdam.lazy_zero): the first write after zero_grad() overwrites
+  fresh = getattr(wgt, '_grad_fresh', False)
+  if fresh:
+    wgt._grad_fresh = False
+    if layer.bias is not None:
+      layer.bias._grad_fresh = False
+  d.accumulate = int(accumulate and not fresh)
   d.splitk = lib.raw('csmri_wgrad_suggest_splitk')(C.byref(d))
   nbytes = lib.raw('csmri_wgrad_slab_bytes')(C.byref(d))
 
@@ -875,12 +881,17 @@ class ConvBnAct(torch.autograd.Function):
         bn.weight.grad = torch.zeros_like(bn.weight)
       if bn.bias.grad is None:
         bn.bias.grad = torch.zeros_like(bn.bias)
+    acc_affine = 1
+    if want_affine and getattr(bn.weight, '_grad_fresh', False):     # lazily zeroed gradients: first write overwrites
+      acc_affine = 0
+      bn.weight._grad_fresh = False
+      bn.bias._grad_fresh = False
     if BN_SMALL and lib.raw('csmri_bn_small_eligible')(dt_of(y), b, h * w, cp, groups):
       lib.call('csmri_bn_small_bwd', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
                gy.data_ptr(), gy.stride(2), b, h * w, cp, layer.cout, mean.data_ptr(), invstd.data_ptr(),
                bn.weight.data_ptr(), float(ctx.slope), ptr(dropmask), snap.data_ptr(),
                bn.weight.grad.data_ptr() if want_affine else 0, bn.bias.grad.data_ptr() if want_affine else 0,
-               1, groups, stream())
+               acc_affine, groups, stream())
       return ConvBnAct._finish_backward(ctx, gy, x0, x1, want_affine)
     rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups, cp)
     partial = torch.empty(rows + groups, 2, cp, dtype=torch.float32, device=dev)
@@ -892,7 +903,7 @@ class ConvBnAct(torch.autograd.Function):
              mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), float(ctx.slope), ptr(dropmask),
              partial.data_ptr(), rows,
              bn.weight.grad.data_ptr() if want_affine else 0,
-             bn.bias.grad.data_ptr() if want_affine else 0, 1, snap.data_ptr(), groups, stream())
+             bn.bias.grad.data_ptr() if want_affine else 0, acc_affine, snap.data_ptr(), groups, stream())
     return ConvBnAct._finish_backward(ctx, gy, x0, x1, want_affine)
 
   @staticmethod

@@ -55,13 +55,24 @@ class FlatAdam(object):
     # callable -> PackGroups holding packed copies of exactly these weights: a step then invalidates
     # only those (without it: the global epoch, i.e. every trainable network's packs)
     self.pack_groups = None
+    # lazy_zero: zero_grad() only MARKS the gradients stale; the first weight-gradient launch of a parameter then
+    # overwrites instead of accumulating (csmri_wgrad / csmri_bn_bwd_apply `accumulate = 0`), later ones accumulate
+    # as usual, and whatever is still marked at apply() is zeroed there.  Same values as fill + accumulate; saves
+    # the fill of the flat buffer (112 MB for the discriminator) and one read of it.  Only valid when every
+    # gradient of these parameters is written by the library's kernels (not by torch autograd): the runner
+    # switches it on for the discriminator.
+    self.lazy_zero = False
     ops.bump_weight_epoch()
 
   def zero_grad(self):
-    self.flat_g.zero_()
     for p, off in zip(self.params, self.offsets):   # re-attach if something replaced .grad
       if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
         p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+    if self.lazy_zero:
+      for p in self.params:
+        p._grad_fresh = True
+    else:
+      self.flat_g.zero_()
 
   def start_allreduce(self):
     self.bucket.start()
@@ -88,6 +99,11 @@ class FlatAdam(object):
 
   def apply(self):
     """The Adam kernel itself (step counter on the device: hipGraph-capturable)."""
+    if self.lazy_zero:
+      for p in self.params:                         # parameters no kernel wrote since zero_grad(): zero gradient
+        if getattr(p, '_grad_fresh', False):
+          p.grad.zero_()
+          p._grad_fresh = False
     ops.adam_step_dev(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq,
                       self.param_groups[0]['lr'], self.betas[0], self.betas[1], self.eps,
                       self.step_dev, self._scale)
