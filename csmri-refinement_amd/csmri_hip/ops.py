@@ -302,6 +302,7 @@ class PackGroup(object):
     return True
 
 
+WGRAD_FIRST = bool(os.environ.get('CSMRI_WGRAD_FIRST'))     # A/B knob: issue weight gradients before data gradients
 FOLD_WINDOW = True      # reflection dgrads: centre written in place + border-only halo fold
 PROFILE_SHAPES = False  # tools: append the problem shape to gconv labels
 PROFILE = None        # bench.py sets this to a list to collect per-launch HIP event timings
@@ -594,16 +595,61 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
     return
   # weight gradients are only consumed by the optimizer: run them on a side stream next to the
   # data-gradient chain (they are mutually ordered there, so the accumulation stays race-free)
-  side.wait_stream(torch.cuda.current_stream())
+  if WGRAD_DEFER <= 0:
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      launch()
+    for t in (x0, x1, gy):
+      if t is not None:
+        t.record_stream(side)
+    _WGRAD['pending'] = True
+    return
+  # Deferred issue: the operands are ready NOW (event), but the launch itself is issued one weight gradient later.
+  # In a captured graph a node's first-issued successor stays on its hardware queue; issuing the side-stream launch
+  # right here made it the first successor of the node the backward's critical chain continues from, and that chain
+  # paid a cross-queue hand-off (10-15 us in the kernel trace) at every layer.
+  ev = torch.cuda.Event()
+  ev.record(torch.cuda.current_stream())
+  q = _WGRAD['deferred']
+  if not q:
+    # whatever is still held back when this backward pass ends is issued then (autograd engine callback): a caller
+    # that reads .grad after backward() + synchronize / join_wgrad_stream() sees every launch, as without deferral
+    try:
+      torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_wgrad)
+    except RuntimeError:            # not inside a backward pass (direct call): no deferral
+      _issue_deferred_wgrad((ev, launch, (x0, x1, gy), layer))
+      return
+  q.append((ev, launch, (x0, x1, gy), layer))
+  while len(q) > WGRAD_DEFER:
+    _issue_deferred_wgrad(q.pop(0))
+
+
+def _wgrad_deferred_mode():
+  return WGRAD_DEFER > 0 and _WGRAD['stream'] is not None
+
+
+def _issue_deferred_wgrad(d):
+  ev, launch, tensors, layer = d
+  side = _WGRAD['stream']
+  side.wait_event(ev)
   with torch.cuda.stream(side):
     launch()
-  for t in (x0, x1, gy):
+  for t in tensors:
     if t is not None:
       t.record_stream(side)
   _WGRAD['pending'] = True
+  if GRAD_READY_HOOK is not None:
+    GRAD_READY_HOOK(layer)
 
 
-_WGRAD = {'stream': None, 'pending': False}
+def _flush_deferred_wgrad():
+  q = _WGRAD['deferred']
+  while q:
+    _issue_deferred_wgrad(q.pop(0))
+
+
+WGRAD_DEFER = int(os.environ.get('CSMRI_WGRAD_DEFER', '2'))     # A/B knob: weight-gradient launches held back (0 = none)
+_WGRAD = {'stream': None, 'pending': False, 'deferred': []}
 
 
 def enable_wgrad_stream(on):
@@ -617,6 +663,7 @@ def enable_wgrad_stream(on):
 
 def join_wgrad_stream():
   """Make the current stream wait for every weight-gradient launch issued so far."""
+  _flush_deferred_wgrad()
   if _WGRAD['pending']:
     torch.cuda.current_stream().wait_stream(_WGRAD['stream'])
     _WGRAD['pending'] = False
@@ -654,17 +701,20 @@ class ConvAct(torch.autograd.Function):
     if gy.dtype != layer.dtype:
       gy = gy.to(layer.dtype)
     g = act_bwd(gy, y, ctx.act_slope) if ctx.act_slope != 1.0 else gy
-    if ctx.w_req:
+    gx0 = gx1 = None                  # data gradient first, weight gradient second (see ConvBnAct._finish_backward)
+    if ctx.w_req and WGRAD_FIRST:
       conv_wgrad(layer, x0, x1, g)
-      if GRAD_READY_HOOK is not None:
-        GRAD_READY_HOOK(layer)
-    gx0 = gx1 = None
     if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
       gx = conv_dgrad(layer, g, ctx.in_hw)
       if x1 is None:
         gx0 = gx
       else:
         gx0, gx1 = gx[..., :ctx.c0], gx[..., ctx.c0:]
+    if ctx.w_req:
+      if not WGRAD_FIRST:
+        conv_wgrad(layer, x0, x1, g)
+      if GRAD_READY_HOOK is not None and not _wgrad_deferred_mode():
+        GRAD_READY_HOOK(layer)
     return gx0, gx1, None, None, None, None, None
 
 
@@ -759,18 +809,22 @@ class ConvActStack(torch.autograd.Function):
     for i in range(n - 1, -1, -1):
       layer, _ = plan[i]
       xin = saved[i]
-      if ctx.w_req[i]:
-        conv_wgrad(layer, xin, None, g)
-        if GRAD_READY_HOOK is not None:
-          GRAD_READY_HOOK(layer)
       in_hw = (xin.shape[1], xin.shape[2])
+      g_out = g                          # data gradient first, weight gradient second (see ConvBnAct._finish_backward)
+      if ctx.w_req[i] and WGRAD_FIRST:
+        conv_wgrad(layer, xin, None, g_out)
       if i > 0:
         prev_slope = plan[i - 1][1]
-        g = conv_dgrad(layer, g, in_hw, g_src=xin if prev_slope != 1.0 else None, g_slope=prev_slope)
+        g = conv_dgrad(layer, g_out, in_hw, g_src=xin if prev_slope != 1.0 else None, g_slope=prev_slope)
       elif ctx.needs_input_grad[0]:
-        g = conv_dgrad(layer, g, in_hw)
+        g = conv_dgrad(layer, g_out, in_hw)
       else:
         g = None
+      if ctx.w_req[i]:
+        if not WGRAD_FIRST:
+          conv_wgrad(layer, xin, None, g_out)
+        if GRAD_READY_HOOK is not None and not _wgrad_deferred_mode():
+          GRAD_READY_HOOK(layer)
     return (g, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
@@ -909,17 +963,24 @@ class ConvBnAct(torch.autograd.Function):
   @staticmethod
   def _finish_backward(ctx, gy, x0, x1, want_affine):
     layer = ctx.layer
-    if want_affine:
-      conv_wgrad(layer, x0, x1, gy)
-      if GRAD_READY_HOOK is not None:
-        GRAD_READY_HOOK(layer)
+    # ISSUE ORDER: the data gradient (the backward's critical chain) first, the weight gradient (side stream) second.
+    # In a captured graph the first successor of a node stays on its hardware queue and the second one pays a
+    # cross-queue hand-off (~10 us in the kernel trace): with the weight gradient issued first, every layer's
+    # data gradient paid it (tools/trace_timeline.py).
     gx0 = gx1 = None
+    if want_affine and WGRAD_FIRST:
+      conv_wgrad(layer, x0, x1, gy)
     if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
       gx = conv_dgrad(layer, gy, ctx.in_hw)
       if x1 is None:
         gx0 = gx
       else:
         gx0, gx1 = gx[..., :ctx.c0], gx[..., ctx.c0:]
+    if want_affine:
+      if not WGRAD_FIRST:
+        conv_wgrad(layer, x0, x1, gy)
+      if GRAD_READY_HOOK is not None and not _wgrad_deferred_mode():
+        GRAD_READY_HOOK(layer)
     return gx0, gx1, None, None, None, None, None, None, None, None, None
 
 

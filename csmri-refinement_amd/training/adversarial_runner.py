@@ -268,13 +268,14 @@ class AdversarialRunner(BaseRunner):
       self.vgg_early = (env == '1') if env in ('0', '1') else dist_utils.world_size() == 1
     gen_inp = self.train_model_input_fn(batch)
     st['gen_inp0'] = gen_inp[0]
-    if st.get('batch_next') is not None:
-      if self._pf_stream is None:
-        self._pf_stream = torch.cuda.Stream()
-      self._pf_stream.wait_stream(torch.cuda.current_stream())
-      with torch.cuda.stream(self._pf_stream):
-        st['pre_next'] = self.gen.precompute(*self.train_model_input_fn(st['batch_next']))
-      st['_pf_pending'] = True
+    # Where the look-ahead (frozen RecNet of batch t+1) is ISSUED matters as much as what it overlaps with: a hipGraph
+    # replays its nodes in capture order at the host's enqueue rate, so ~35 look-ahead nodes in front of the U-Net
+    # forward kept the step's critical chain waiting for 0.3 ms at every step start (tools/trace_timeline.py).
+    # Measured (ms per step): start 6.83-6.85, after the generator forward 6.92-6.96, after D's forward 6.94, end of
+    # segment 1 (default) 6.72-6.75, segment 2 6.75, segment 3 6.99; the VGG fork issued after D's forward 7.10.
+    pf_at = os.environ.get('CSMRI_PF_FORK', 'end1')             # A/B knob: start | after_gen | after_dfwd | end1 | seg2 | seg3
+    if pf_at == 'start':
+      self._fork_prefetch(st)
     if st.get('pre_cur') is not None:
       st['pre_cur'].record_stream(torch.cuda.current_stream())   # produced on the prefetch stream
       out_gen = self.gen.forward_with_pre(*gen_inp, pre=st['pre_cur'])
@@ -282,8 +283,11 @@ class AdversarialRunner(BaseRunner):
       out_gen = self.gen(*gen_inp)
     st['out_gen'] = out_gen
     st['side_results'] = {}
-    if self.overlap_streams and self.vgg_early:
+    vgg_at = os.environ.get('CSMRI_VGG_FORK', 'early')               # A/B knob: early | after_dfwd (issue order)
+    if self.overlap_streams and self.vgg_early and vgg_at == 'early':
       self._fork_vgg(st, out_gen, batch)
+    if pf_at == 'after_gen':
+      self._fork_prefetch(st)
     in_fake = self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False, detach=True,
                                  pool_decisions=self.pool_decisions)
     in_real = self.disc_input_fn(batch['target'], gen_inp[0], out_gen, is_real_input=True, detach=True)
@@ -297,6 +301,10 @@ class AdversarialRunner(BaseRunner):
       out_real = self.disc(nhwc=in_real)
     st['out_disc_real'] = out_real
     st['out_disc_fake_early'] = None
+    if self.overlap_streams and self.vgg_early and vgg_at == 'after_dfwd':
+      self._fork_vgg(st, out_gen, batch)
+    if pf_at == 'after_dfwd':
+      self._fork_prefetch(st)
     if self.overlap_streams and self.vgg_early and self.third_pass_early:
       # single GPU: the third D forward (reference :354-357; same D weights, it only has to
       # follow the two passes above for the BatchNorm running statistics) runs on its own stream
@@ -324,7 +332,19 @@ class AdversarialRunner(BaseRunner):
       torch.cuda.current_stream().wait_stream(self._side_stream)
     if st['out_disc_fake_early'] is not None:
       torch.cuda.current_stream().wait_stream(self._side_stream3)
+    if pf_at == 'end1':
+      self._fork_prefetch(st)
     self._join_prefetch(st, 1)
+
+  def _fork_prefetch(self, st):
+    if st.get('batch_next') is None:
+      return
+    if self._pf_stream is None:
+      self._pf_stream = torch.cuda.Stream()
+    self._pf_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(self._pf_stream):
+      st['pre_next'] = self.gen.precompute(*self.train_model_input_fn(st['batch_next']))
+    st['_pf_pending'] = True
 
   def _join_prefetch(self, st, seg):
     """Join the look-ahead stream.  A captured segment must end with every stream joined: with one
@@ -361,6 +381,8 @@ class AdversarialRunner(BaseRunner):
 
   def _seg2(self, st):
     batch, out_gen = st['batch'], st['out_gen']
+    if os.environ.get('CSMRI_PF_FORK', 'end1') == 'seg2':
+      self._fork_prefetch(st)
     forked_here = False
     if self.overlap_streams and not st['side_results']:
       self._fork_vgg(st, out_gen, batch)
@@ -407,6 +429,8 @@ class AdversarialRunner(BaseRunner):
     st['_metrics_pending'] = True
 
   def _seg3(self, st):
+    if os.environ.get('CSMRI_PF_FORK', 'end1') == 'seg3':
+      self._fork_prefetch(st)
     self._fork_train_metrics(st)
     if st.get('out_disc_fake_early') is not None:
       # the third D pass lives on its own stream: run D's Adam there too.  Only that pass's
