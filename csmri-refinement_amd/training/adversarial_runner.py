@@ -283,7 +283,11 @@ class AdversarialRunner(BaseRunner):
       out_gen = self.gen(*gen_inp)
     st['out_gen'] = out_gen
     st['side_results'] = {}
-    vgg_at = os.environ.get('CSMRI_VGG_FORK', 'early')               # A/B knob: early | after_dfwd (issue order)
+    vgg_at = os.environ.get('CSMRI_VGG_FORK', 'early')       # A/B knob: early | after_dfwd | after_dfwd_ev | after_din_ev
+    ev_gen = None
+    if vgg_at.endswith('_ev'):
+      ev_gen = torch.cuda.Event()
+      ev_gen.record(torch.cuda.current_stream())
     if self.overlap_streams and self.vgg_early and vgg_at == 'early':
       self._fork_vgg(st, out_gen, batch)
     if pf_at == 'after_gen':
@@ -291,6 +295,8 @@ class AdversarialRunner(BaseRunner):
     in_fake = self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False, detach=True,
                                  pool_decisions=self.pool_decisions)
     in_real = self.disc_input_fn(batch['target'], gen_inp[0], out_gen, is_real_input=True, detach=True)
+    if self.overlap_streams and self.vgg_early and vgg_at == 'after_din_ev':
+      self._fork_vgg(st, out_gen, batch, ev_gen)
     if self.batch_disc_passes:
       # the two passes of reference :333-341 as ONE pass over [fake; real] with per-half BatchNorm
       # statistics and dropout draws (identical results, half the launches on D's small maps)
@@ -301,17 +307,28 @@ class AdversarialRunner(BaseRunner):
       out_real = self.disc(nhwc=in_real)
     st['out_disc_real'] = out_real
     st['out_disc_fake_early'] = None
-    if self.overlap_streams and self.vgg_early and vgg_at == 'after_dfwd':
-      self._fork_vgg(st, out_gen, batch)
+    if self.overlap_streams and self.vgg_early and vgg_at in ('after_dfwd', 'after_dfwd_ev'):
+      self._fork_vgg(st, out_gen, batch, ev_gen)
     if pf_at == 'after_dfwd':
       self._fork_prefetch(st)
+    third_at = os.environ.get('CSMRI_THIRD_FORK', 'early')           # A/B knob: early | after_loss_ev | after_dbwd_ev
+    ev_dfwd = None
     if self.overlap_streams and self.vgg_early and self.third_pass_early:
       # single GPU: the third D forward (reference :354-357; same D weights, it only has to
       # follow the two passes above for the BatchNorm running statistics) runs on its own stream
       # next to the D loss and backward below -- two chains of small kernels share the chip
       if self._side_stream3 is None:
         self._side_stream3 = torch.cuda.Stream()
-      self._side_stream3.wait_stream(torch.cuda.current_stream())
+      if third_at == 'early':
+        self._side_stream3.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side_stream3):
+          st['out_disc_fake_early'] = self._third_disc_pass(st)
+      else:
+        ev_dfwd = torch.cuda.Event()
+        ev_dfwd.record(torch.cuda.current_stream())
+
+    def third_now():
+      self._side_stream3.wait_event(ev_dfwd)
       with torch.cuda.stream(self._side_stream3):
         st['out_disc_fake_early'] = self._third_disc_pass(st)
     names, vals, disc_losses = [], [], []
@@ -322,8 +339,12 @@ class AdversarialRunner(BaseRunner):
       vals.append(loss.detach())
     total_disc = self._weighted_total(disc_losses, self.disc_loss_weights)
     self.disc_optimizer.zero_grad()
+    if ev_dfwd is not None and third_at == 'after_loss_ev':
+      third_now()
     ops.enable_wgrad_stream(self.overlap_streams)
     total_disc.backward()
+    if ev_dfwd is not None and third_at == 'after_dbwd_ev':
+      third_now()
     ops.join_wgrad_stream()
     names.append('disc_loss')
     vals.append(total_disc.detach())
@@ -365,7 +386,7 @@ class AdversarialRunner(BaseRunner):
     self.disc.set_wgrad(True)
     return out_fake
 
-  def _fork_vgg(self, st, out_gen, batch):
+  def _fork_vgg(self, st, out_gen, batch, event=None):
     """The VGG perceptual branch (big GEMMs) only needs the generator output: run it on a side
     stream next to chains of small kernels -- the discriminator passes and backward of segment 1
     on a single GPU (vgg_early), or the third D forward of segment 2 when segment 2 has to hide
@@ -373,7 +394,10 @@ class AdversarialRunner(BaseRunner):
     gradient chains into `pred` overlap as well."""
     if self._side_stream is None:
       self._side_stream = torch.cuda.Stream(priority=int(os.environ.get('CSMRI_PRIO_VGG', '0')))
-    self._side_stream.wait_stream(torch.cuda.current_stream())
+    if event is not None:             # the branch only depends on the generator output (issue order: see _seg1)
+      self._side_stream.wait_event(event)
+    else:
+      self._side_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(self._side_stream):
       for name, criterion in self.gen_criteria.items():
         if name == 'VGG19':
@@ -413,9 +437,11 @@ class AdversarialRunner(BaseRunner):
     for g in trainable_pack_groups(self.disc) or []:
       g.repack_stale()
 
-  def _fork_train_metrics(self, st):
+  def _fork_train_metrics(self, st, event=None):
     """The training metrics only read forward results: compute them on their own stream next to
-    the generator backward instead of as a serial tail of ~20 tiny launches after the G step."""
+    the generator backward instead of as a serial tail of ~20 tiny launches after the G step.
+    ``event``: what the metrics depend on was complete at that event (issue the launches later without
+    making them wait for what was issued in between)."""
     data = (st['batch'], st['out_gen'], st['out_disc_fake'], st['out_disc_real'])
     if not self.overlap_streams:
       with torch.no_grad():
@@ -423,7 +449,10 @@ class AdversarialRunner(BaseRunner):
       return
     if self._metric_stream is None:
       self._metric_stream = torch.cuda.Stream()
-    self._metric_stream.wait_stream(torch.cuda.current_stream())
+    if event is not None:
+      self._metric_stream.wait_event(event)
+    else:
+      self._metric_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(self._metric_stream), torch.no_grad():
       st['train_metrics'] = self._compute_train_metrics(data)
     st['_metrics_pending'] = True
@@ -431,7 +460,13 @@ class AdversarialRunner(BaseRunner):
   def _seg3(self, st):
     if os.environ.get('CSMRI_PF_FORK', 'end1') == 'seg3':
       self._fork_prefetch(st)
-    self._fork_train_metrics(st)
+    metrics_at = os.environ.get('CSMRI_METRICS_FORK', 'late_ev')       # A/B knob: early | late_ev
+    ev_m = None
+    if metrics_at == 'late_ev' and self.overlap_streams:
+      ev_m = torch.cuda.Event()
+      ev_m.record(torch.cuda.current_stream())
+    else:
+      self._fork_train_metrics(st)
     if st.get('out_disc_fake_early') is not None:
       # the third D pass lives on its own stream: run D's Adam there too.  Only that pass's
       # backward (data gradients through the UPDATED D, ordering A) needs the new weights; the
@@ -444,6 +479,8 @@ class AdversarialRunner(BaseRunner):
     self.gen_optimizer.zero_grad()
     ops.enable_wgrad_stream(self.overlap_streams)
     st['total_gen'].backward()
+    if ev_m is not None:
+      self._fork_train_metrics(st, ev_m)
     ops.join_wgrad_stream()
     st['names'].append('gen_loss')
     st['vals'].append(st['total_gen'].detach())
