@@ -2,6 +2,8 @@
 
 _train_step: zero_grad -> forward -> criteria -> weighted sum -> backward (which runs
 the adjoint of every data-consistency layer) -> all-reduce -> fused Adam."""
+import os
+
 import torch
 
 from metrics import get_metric_fn, get_loss_metric
@@ -105,8 +107,12 @@ class Runner(BaseRunner):
       names.append(name)
       losses.append(criterion(out, batch))
     total = torch.sum(torch.stack(losses) * self.loss_weights)
-    total.backward()
     from csmri_hip import ops
+    # weight gradients on a side stream next to the data-gradient chain, as in the adversarial runner?  Measured on
+    # C2 (batch 64, every kernel fills the chip and is HBM-bound): 10.37 vs 8.5 ms -- co-running only adds contention.
+    # Off; CSMRI_RUNNER_WGRAD_STREAM=1 to try it on small batches.
+    ops.enable_wgrad_stream(total.is_cuda and os.environ.get('CSMRI_RUNNER_WGRAD_STREAM', '0') == '1')
+    total.backward()
     ops.join_wgrad_stream()
     return names, [l.detach() for l in losses], total.detach(), out
 
