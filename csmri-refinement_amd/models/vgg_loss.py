@@ -13,6 +13,8 @@ from csmri_hip import ops
 _KIND = {'L1': 0, 'MSE': 1}
 
 
+_VGG_MULTI = __import__('os').environ.get('CSMRI_VGG_MULTI', '1') != '0'     # A/B knob
+
 class VGGLoss(nn.Module):
   def __init__(self, loss_name, cuda, blocks=-1, criterion='L1', weights=None, seed=0,
                weights_path=None, allow_random=None):
@@ -62,6 +64,12 @@ class VGGLoss(nn.Module):
       with torch.no_grad():
         t_feats = self.vgg.forward_nhwc(t_in)
       p_feats = self.vgg.forward_nhwc(p_in)
+    n = len(p_feats)
+    if _VGG_MULTI and n <= 16 and len({f.dtype for f in p_feats}) == 1:
+      # every block's distance in one launch pair (and one backward launch) instead of three launches per block
+      # in a chain between the VGG branch and the generator backward (same kernel FeatureMatchingLoss uses)
+      return ops.MultiMeanLoss.apply(self.kind, [float(w) for w in self.weights], [f.shape[3] for f in p_feats],
+                                     *p_feats, *[t.detach() for t in t_feats])
     loss = 0
     for wgt, pf, tf in zip(self.weights, p_feats, t_feats):
       loss = loss + wgt * ops.MeanLoss.apply(pf, tf.detach(), self.kind, pf.shape[3])
