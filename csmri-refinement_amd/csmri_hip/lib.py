@@ -141,6 +141,7 @@ _SIGS = {
     'csmri_act_bwd': (i32, [i32, vp, i32, vp, i32, vp, i32, i64, i32, f32, vp]),
     'csmri_maxpool2': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     'csmri_maxpool2_bwd': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'csmri_maxpool2_bwd_act': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i32, f32, vp, i32, vp]),
     'csmri_complex_abs': (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
     'csmri_complex_abs_bwd': (i32, [vp, i64, vp, i32, i32, i32, i32, vp, i32, vp]),
     'csmri_minmax_floats': (sz, [i32]),
@@ -162,6 +163,7 @@ _SIGS = {
     'csmri_ssim': (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     'csmri_adam': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
     'csmri_adam_dev': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp]),
+    'csmri_image_pool_exchange': (i32, [vp, vp, vp, vp, i32, i64, vp]),
     'csmri_fill_f32': (i32, [vp, i64, f32, vp]),
     'csmri_cast': (i32, [vp, i32, vp, i32, i64, vp]),
     'csmri_copy_channels': (i32, [vp, i32, i32, i32, vp, i32, i32, i32, i64, vp]),

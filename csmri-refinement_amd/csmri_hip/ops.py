@@ -589,12 +589,12 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
     with _Timed(label, 2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw):
       lib.call('csmri_wgrad', C.byref(d), stream())
 
-  side = _WGRAD['stream']
-  if side is None:
+  if _WGRAD['stream'] is None:
     launch()
     return
   # weight gradients are only consumed by the optimizer: run them on a side stream next to the
-  # data-gradient chain (they are mutually ordered there, so the accumulation stays race-free)
+  # data-gradient chain (a layer always uses the same side stream, so its accumulation stays race-free)
+  side = _side_stream_of(layer)
   if WGRAD_DEFER <= 0:
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -628,9 +628,26 @@ def _wgrad_deferred_mode():
   return WGRAD_DEFER > 0 and _WGRAD['stream'] is not None
 
 
+def _side_stream_of(layer):
+  """The side stream of a layer's weight-gradient launches: fixed per layer (its accumulations stay ordered),
+  layers alternate between the WGRAD_STREAMS streams in order of first use (one layer's slab reduce then runs
+  under the next layer's main kernel)."""
+  k = getattr(layer, '_wgrad_stream', None)
+  if k is None:
+    k = layer._wgrad_stream = _WGRAD['next']
+    _WGRAD['next'] += 1
+  if WGRAD_STREAMS <= 1:
+    return _WGRAD['stream']
+  extra = _WGRAD['extra']
+  while len(extra) < WGRAD_STREAMS - 1:
+    extra.append(torch.cuda.Stream())
+  k %= WGRAD_STREAMS
+  return _WGRAD['stream'] if k == 0 else extra[k - 1]
+
+
 def _issue_deferred_wgrad(d):
   ev, launch, tensors, layer = d
-  side = _WGRAD['stream']
+  side = _side_stream_of(layer)
   side.wait_event(ev)
   with torch.cuda.stream(side):
     launch()
@@ -649,7 +666,8 @@ def _flush_deferred_wgrad():
 
 
 WGRAD_DEFER = int(os.environ.get('CSMRI_WGRAD_DEFER', '2'))     # A/B knob: weight-gradient launches held back (0 = none)
-_WGRAD = {'stream': None, 'pending': False, 'deferred': []}
+WGRAD_STREAMS = int(os.environ.get('CSMRI_WGRAD_STREAMS', '1'))  # A/B knob: side streams the layers alternate between
+_WGRAD = {'stream': None, 'pending': False, 'deferred': [], 'extra': [], 'next': 0}
 
 
 def enable_wgrad_stream(on):
@@ -666,6 +684,8 @@ def join_wgrad_stream():
   _flush_deferred_wgrad()
   if _WGRAD['pending']:
     torch.cuda.current_stream().wait_stream(_WGRAD['stream'])
+    for st in _WGRAD['extra']:
+      torch.cuda.current_stream().wait_stream(st)
     _WGRAD['pending'] = False
 
 
@@ -995,13 +1015,26 @@ def maxpool2_fwd(x):
   return y, arg
 
 
-def maxpool2_bwd(gy, arg, shape):
+def maxpool2_bwd(gy, arg, shape, g_src=None, g_slope=1.0, g_add=None):
+  """Gradient of MaxPool2d(2,2).  ``g_add``: a second gradient of the pool's input, added in the same pass;
+  ``g_src`` (the output of the activation layer that fed the pool): the result also carries that activation's
+  derivative (csmri_maxpool2_bwd_act)."""
   b, h, w, c = shape
   gy = as_nhwc(gy)
   gx = torch.empty(b, h, w, c, dtype=gy.dtype, device=gy.device)
+  if g_src is not None or g_add is not None:
+    for t in (g_src, g_add):
+      assert t is None or (t.dtype == gy.dtype and tuple(t.shape) == (b, h, w, c) and t.stride(3) == 1)
+    lib.call('csmri_maxpool2_bwd_act', dt_of(gy), gy.data_ptr(), gy.stride(2), arg.data_ptr(),
+             gx.data_ptr(), gx.stride(2), b, h, w, c, ptr(g_src), g_src.stride(2) if g_src is not None else 0,
+             float(g_slope), ptr(g_add), g_add.stride(2) if g_add is not None else 0, stream())
+    return gx
   lib.call('csmri_maxpool2_bwd', dt_of(gy), gy.data_ptr(), gy.stride(2), arg.data_ptr(),
            gx.data_ptr(), gx.stride(2), b, h, w, c, stream())
   return gx
+
+
+POOL_ACT_FUSED = os.environ.get('CSMRI_NO_POOL_ACT_FUSED') is None   # A/B knob
 
 
 class MaxPool2(torch.autograd.Function):
@@ -1016,6 +1049,30 @@ class MaxPool2(torch.autograd.Function):
   def backward(ctx, gy):
     arg, = ctx.saved_tensors
     return maxpool2_bwd(gy, arg, ctx.shape)
+
+
+class MaxPool2Skip(torch.autograd.Function):
+  """x -> (MaxPool2d(2,2)(x), x): the U-Net encoder's pool together with the skip connection that leaves the same
+  tensor (models/unet.py:58-72).  Backward adds the skip gradient while un-pooling (one pass instead of the
+  un-pooling launch + autograd's accumulation of the two gradients)."""
+
+  @staticmethod
+  def forward(ctx, x):
+    y, arg = maxpool2_fwd(x)
+    ctx.save_for_backward(arg)
+    ctx.shape = tuple(x.shape)
+    return y, x.view_as(x)
+
+  @staticmethod
+  def backward(ctx, gy, gskip):
+    arg, = ctx.saved_tensors
+    if gy is None:
+      return gskip
+    if gskip is not None:
+      gskip = as_nhwc(gskip)
+      if gskip.dtype != gy.dtype or tuple(gskip.shape) != ctx.shape or gskip.stride(3) != 1:
+        return maxpool2_bwd(gy, arg, ctx.shape) + gskip
+    return maxpool2_bwd(gy, arg, ctx.shape, g_add=gskip)
 
 
 class FrozenConvStackPair(torch.autograd.Function):
@@ -1087,8 +1144,15 @@ class FrozenConvStackPair(torch.autograd.Function):
         else:
           g = conv_dgrad(layer, gp, ctx.shapes[i])
       else:
-        g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i])
-        act_done = False
+        prev = plan[i - 1] if i > 0 else None
+        if POOL_ACT_FUSED and prev is not None and prev[0] == 'conv' and prev[2] != 1.0 and \
+            saved[i - 1].dtype == g.dtype:
+          # the pool's producer is an activated conv: its derivative rides on the un-pooling pass
+          g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i], g_src=saved[i - 1][:b], g_slope=prev[2])
+          act_done = True
+        else:
+          g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i])
+          act_done = False
     return g, None, None, None
 
 
@@ -1104,6 +1168,20 @@ def copy_channels(x, c_dst, dtype=None):
   out = torch.empty(b, h, w, c_dst, dtype=dtype or x.dtype, device=x.device)
   lib.call('csmri_copy_channels', x.data_ptr(), dt_of(x), x.stride(2), min(c, c_dst), out.data_ptr(),
            dt_of(out), c_dst, c_dst, b * h * w, stream())
+  return out
+
+
+def image_pool_exchange(x, pool, plan):
+  """One query of the image history pool (utils/image_pool.py): x [n,...], pool [pool_size+1,...] (updated in
+  place), plan int64 [5,n] on the device.  Returns the images handed to the discriminator."""
+  _need_gpu(x)
+  x = x.contiguous()
+  n = x.shape[0]
+  assert pool.is_contiguous() and pool.dtype == x.dtype and tuple(pool.shape[1:]) == tuple(x.shape[1:])
+  assert plan.is_contiguous() and plan.dtype == torch.int64 and tuple(plan.shape) == (5, n)
+  out = torch.empty_like(x)
+  lib.call('csmri_image_pool_exchange', x.data_ptr(), pool.data_ptr(), out.data_ptr(), plan.data_ptr(), n,
+           x[0].numel() * x.element_size(), stream())
   return out
 
 

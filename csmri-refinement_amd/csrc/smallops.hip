@@ -40,6 +40,14 @@ __global__ void complex_abs_kernel(const float2* x, long long npix, void* out, i
   GRID_STRIDE(p, npix) {
     const float2 v = x[p];
     const float a = sqrtf(v.x * v.x + v.y * v.y);
+    if (Cpad == 8 && (ps & 3) == 0) {          // the channel-padded conv input: the pixel's 8 channels as two 4-wide stores
+      f32x4_t lo = (f32x4_t){a, 0.f, 0.f, 0.f};
+      if (mode != 0) lo = (f32x4_t){(a - c_vgg_mean[0]) / c_vgg_std[0], (a - c_vgg_mean[1]) / c_vgg_std[1],
+                                    (a - c_vgg_mean[2]) / c_vgg_std[2], 0.f};
+      store4(out, p * ps, dt, lo);
+      store4(out, p * ps + 4, dt, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+      continue;
+    }
     for (int c = 0; c < Cpad; ++c) {
       float o = 0.f;
       if (mode == 0) o = c == 0 ? a : 0.f;
@@ -623,6 +631,41 @@ extern "C" int csmri_adam_dev(float* p, const float* g, float* m, float* v, long
                      beta2, eps, (const int*)step_dev, grad_scale);
   CSMRI_LAUNCH_CHECK();
   hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(64), 0, st, step_dev);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+// --------------------------------------------------------- image pool ----
+// One query of the history pool of generated images (reference utils/image_pool.py:8-60) on the device, given
+// the host's plan (int64 [5][n]: kind, pool_idx, x_idx, write_slot, write_src):
+//   out[i]              = kind[i] == 1 ? pool[pool_idx[i]] : kind[i] == 2 ? x[x_idx[i]] : x[i]
+//   pool[write_slot[j]] = x[write_src[j]]                     (slot == pool_size: the write-only dummy)
+// A thread owns one 16-byte column of EVERY image: it performs all n reads of the old pool content before its
+// n writes, so the gather-before-scatter order of the sequential reference holds without a grid-wide barrier.
+#define POOL_MAX_N 64
+__global__ __launch_bounds__(256) void image_pool_exchange_kernel(const uint4* __restrict__ x, uint4* pool, uint4* __restrict__ out,
+                                                                  const long long* __restrict__ plan, int n, long long vecs) {
+  __shared__ int s_plan[5 * POOL_MAX_N];
+  for (int t = threadIdx.x; t < 5 * n; t += blockDim.x) s_plan[t] = (int)plan[t];
+  __syncthreads();
+  GRID_STRIDE(v, vecs) {
+    for (int i = 0; i < n; ++i) {
+      const int kind = s_plan[i];
+      const uint4* src = kind == 1 ? pool + (long long)s_plan[n + i] * vecs : x + (long long)(kind == 2 ? s_plan[2 * n + i] : i) * vecs;
+      out[(long long)i * vecs + v] = src[v];
+    }
+    for (int j = 0; j < n; ++j)
+      pool[(long long)s_plan[3 * n + j] * vecs + v] = x[(long long)s_plan[4 * n + j] * vecs + v];
+  }
+}
+extern "C" int csmri_image_pool_exchange(const void* x, void* pool, void* out, const long long* plan, int n,
+                                         long long bytes_per_image, void* stream) {
+  CSMRI_CHECK_ARG(x && pool && out && plan && n > 0 && n <= POOL_MAX_N && bytes_per_image > 0 &&
+                  bytes_per_image % 16 == 0);
+  if (((uintptr_t)x | (uintptr_t)pool | (uintptr_t)out) & 15) return CSMRI_E_ALIGN;
+  const long long vecs = bytes_per_image / 16;
+  hipLaunchKernelGGL(image_pool_exchange_kernel, dim3(grid_for(vecs)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)x, (uint4*)pool, (uint4*)out, plan, n, vecs);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

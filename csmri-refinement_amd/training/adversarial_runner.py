@@ -350,6 +350,8 @@ class AdversarialRunner(BaseRunner):
     names.append('disc_loss')
     vals.append(total_disc.detach())
     st['names'], st['vals'] = names, vals
+    if os.environ.get('CSMRI_VGG_BWD', 'late') == 'early':
+      self._vgg_backward_early(st)               # issued here: behind D's chain in the replay's enqueue order
     if st['side_results']:                       # a segment (graph) ends with every stream joined
       torch.cuda.current_stream().wait_stream(self._side_stream)
     if st['out_disc_fake_early'] is not None:
@@ -399,10 +401,59 @@ class AdversarialRunner(BaseRunner):
       self._side_stream.wait_event(event)
     else:
       self._side_stream.wait_stream(torch.cuda.current_stream())
+    cut = os.environ.get('CSMRI_VGG_BWD', 'late') != 'late' and torch.is_grad_enabled()     # A/B knob: seg3 | early | fork | late
     with torch.cuda.stream(self._side_stream):
       for name, criterion in self.gen_criteria.items():
         if name == 'VGG19':
-          st['side_results'][name] = criterion(out_gen, batch)
+          src = self._vgg_cut(out_gen) if cut else None
+          if src is None:
+            st['side_results'][name] = criterion(out_gen, batch)
+            continue
+          # The branch hangs on a detached copy of the prediction: its backward does not have to wait for the
+          # generator backward (_vgg_backward_early), and the gradient it leaves joins there as a second root.
+          pred, leaf, out_cut = src
+          loss = criterion(out_cut, batch)
+          st['vgg_cut'] = (name, pred, leaf, loss)
+          st['side_results'][name] = loss.detach()
+    if st.get('vgg_cut') is not None and os.environ.get('CSMRI_VGG_BWD', 'late') == 'fork':
+      self._vgg_backward_early(st)
+
+  @staticmethod
+  def _vgg_cut(out_gen):
+    """(prediction tensor the criteria read, detached leaf, generator output with the leaf in its place)."""
+    if not isinstance(out_gen, dict):
+      if not out_gen.requires_grad:
+        return None
+      leaf = out_gen.detach().requires_grad_(True)
+      return out_gen, leaf, leaf
+    fast = out_gen.get('_nhwc')
+    out_cut = dict(out_gen)
+    if fast is not None and 'pred' in fast:
+      pred = fast['pred']
+      leaf = pred.detach().requires_grad_(True)
+      out_cut['_nhwc'] = dict(fast, pred=leaf)
+      out_cut.pop('pred', None)
+    else:
+      pred = out_gen['pred']
+      leaf = pred.detach().requires_grad_(True)
+      out_cut['pred'] = leaf
+    return (pred, leaf, out_cut) if pred.requires_grad else None
+
+  def _vgg_backward_early(self, st):
+    """Backward of the forked VGG branch, on its stream, as soon as its forward is done -- next to the discriminator
+    step instead of on the generator backward's critical chain: d(total_gen)/d(prediction) through the frozen
+    extractor depends on nothing but the branch's own forward and its (constant) loss weight.  The per-queue
+    timeline showed the branch's backward (0.8 ms of large data-gradient GEMMs) issued BEHIND the third
+    discriminator pass's backward (autograd runs the later-created branch first) with the U-Net backward waiting
+    for both.  Leaves st['vgg_grad'] = (prediction, gradient) for _seg3."""
+    cut = st.pop('vgg_cut', None)
+    if cut is None:
+      return
+    name, pred, leaf, loss = cut
+    idx = len(self.gen_adv_criteria) + list(self.gen_criteria.keys()).index(name)
+    with torch.cuda.stream(self._side_stream):
+      loss.backward(self.gen_loss_weights[idx].to(loss.dtype))
+    st['vgg_grad'] = (pred, leaf.grad)
 
   def _seg2(self, st):
     batch, out_gen = st['batch'], st['out_gen']
@@ -428,6 +479,8 @@ class AdversarialRunner(BaseRunner):
       gen_losses.append(loss)
       st['names'].append('gen_loss_' + name)
       st['vals'].append(loss.detach())
+    if forked_here and os.environ.get('CSMRI_VGG_BWD', 'late') == 'early':
+      self._vgg_backward_early(st)
     if side and forked_here:
       torch.cuda.current_stream().wait_stream(self._side_stream)
     st['total_gen'] = self._weighted_total(gen_losses, self.gen_loss_weights)
@@ -479,7 +532,31 @@ class AdversarialRunner(BaseRunner):
       self.disc_optimizer.apply()
     self.gen_optimizer.zero_grad()
     ops.enable_wgrad_stream(self.overlap_streams)
-    st['total_gen'].backward()
+    hook = None
+    if st.get('vgg_cut') is not None:
+      # The VGG branch's backward issued FIRST, on its own stream: it then runs next to D's Adam and the third pass's
+      # backward (a chain of small kernels) instead of behind them, and its gradient joins where the prediction's
+      # gradient is complete (tensor hook: the wait lands on the generator backward's stream at that point only).
+      self._side_stream.wait_stream(torch.cuda.current_stream())    # (joins the branch's stream into this segment's capture)
+      self._vgg_backward_early(st)
+      pred, g_vgg = st.pop('vgg_grad')
+      ev_v = torch.cuda.Event()
+      ev_v.record(self._side_stream)
+
+      def _join_vgg(g):
+        torch.cuda.current_stream().wait_event(ev_v)
+        g_vgg.record_stream(torch.cuda.current_stream())
+        return g + g_vgg.to(g.dtype)
+      hook = pred.register_hook(_join_vgg)
+    vg = st.pop('vgg_grad', None)
+    if vg is not None:
+      # the VGG branch's gradient (computed on its stream, joined at the end of its segment) enters as a second root
+      vg[1].record_stream(torch.cuda.current_stream())
+      torch.autograd.backward([st['total_gen'], vg[0]], [None, vg[1]])
+    else:
+      st['total_gen'].backward()
+    if hook is not None:
+      hook.remove()
     if ev_m is not None:
       self._fork_train_metrics(st, ev_m)
     ops.join_wgrad_stream()

@@ -3,7 +3,8 @@
 Same decision process -- python ``random``: one uniform draw per image once the pool is
 full, then one randint for the slot; images are processed in batch order, so an image
 stored by item i can be drawn by item j > i -- but the pool lives in ONE device buffer and
-a query is three gathers + one scatter driven by small index tensors.  The host computes
+a query is one launch driven by small index tensors (csmri_image_pool_exchange; host tensors: three gathers +
+one scatter in torch).  The host computes
 the indices ("plan") from the decisions; the device part has a fixed shape and can be
 captured into a hipGraph (the runner then only refreshes the index tensors per step)."""
 import random
@@ -75,6 +76,10 @@ class ImagePool(object):
 
   # -- device side (fixed shape) -------------------------------------------------
   def apply_plan(self, x):
+    if x.is_cuda:
+      # one launch (csmri_image_pool_exchange) instead of three gathers, two selects and a scatter
+      from csmri_hip import ops
+      return ops.image_pool_exchange(x, self.buffer, self._idx)
     kind, pidx, xidx, wslot, wsrc = self._idx.unbind(0)
     from_pool = self.buffer.index_select(0, pidx)
     from_x = x.index_select(0, xidx)

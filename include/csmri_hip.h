@@ -353,6 +353,16 @@ int csmri_maxpool2(int dtype, const void* x, int x_pix_stride, void* y, int y_pi
                    uint8_t* argmax, int B, int H, int W, int C, void* stream);
 int csmri_maxpool2_bwd(int dtype, const void* dy, int dy_pix_stride, const uint8_t* argmax,
                        void* dx, int dx_pix_stride, int B, int H, int W, int C, void* stream);
+/* same with the neighbouring elementwise steps of the backward folded into the one pass over the
+ * full-resolution gradient:  dx = (unpool(dy) + g_add) * act'(g_src).
+ * g_add (optional, [B,H,W,C]): the other gradient of the pool's input -- the skip connection of the U-Net
+ * encoder (models/unet.py:58-72: the block output feeds both the pool and the decoder's concat);
+ * g_src (optional): output of the activated layer that fed the pool, derivative 1 where g_src > 0 else
+ * g_slope -- the VGG19 backward's pool -> relu' step (torchvision features: conv, ReLU, MaxPool2d). */
+int csmri_maxpool2_bwd_act(int dtype, const void* dy, int dy_pix_stride, const uint8_t* argmax,
+                           void* dx, int dx_pix_stride, int B, int H, int W, int C, const void* g_src,
+                           int g_pix_stride, float g_slope, const void* g_add, int g_add_pix_stride,
+                           void* stream);
 
 /* ------------------------------------------------------------------------
  * small fused ops of the refinement wrapper / losses / optimizer
@@ -441,6 +451,17 @@ int csmri_adam(float* p, const float* g, float* m, float* v, long long n, float 
 int csmri_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr,
                    float beta1, float beta2, float eps, int* step_dev, float grad_scale,
                    void* stream);
+
+/* One query of the discriminator's history pool of generated images (reference utils/image_pool.py:8-60,
+ * called from the discriminator input function, training/adversarial_training.py) as ONE launch:
+ *   out[i]              = kind[i] == 1 ? pool[pool_idx[i]] : kind[i] == 2 ? x[x_idx[i]] : x[i]
+ *   pool[write_slot[j]] = x[write_src[j]]        (every read of the old pool content precedes the writes)
+ * x, out: n images of bytes_per_image bytes (any dtype / layout, a multiple of 16 bytes, 16-byte aligned);
+ * pool: pool_size + 1 such images (the last one is a write-only dummy); plan: DEVICE int64 [5][n] rows
+ * kind, pool_idx, x_idx, write_slot, write_src -- the reference's sequential python-random decisions resolved
+ * into indices by the host (utils/image_pool.py ImagePool.plan).  n <= 64. */
+int csmri_image_pool_exchange(const void* x, void* pool, void* out, const long long* plan, int n,
+                              long long bytes_per_image, void* stream);
 
 /* misc */
 int csmri_fill_f32(float* p, long long n, float v, void* stream);

@@ -229,6 +229,77 @@ def test_maxpool(hip, dtype):
   assert torch.equal(from_dev_nhwc(xd.grad, 16), xr.grad)
 
 
+def test_image_pool_exchange_matches_sequential_reference(hip):
+  """csmri_image_pool_exchange (one launch) against the oracle's sequential pool (reference utils/image_pool.py:29-60)
+  on the same decisions: filling phase, draws, a slot drawn twice in one batch (the second draw must see the image
+  the first one stored), plus the device pool content afterwards.  Bit-exact (copies)."""
+  import random
+  import csmri_oracle as O
+  from utils.image_pool import ImagePool
+  rng = random.Random(7)
+  a, b = ImagePool(6), O.ImagePool(6)
+  for step in range(12):
+    x = torch.randn(4, 8, 8, 8, generator=torch.Generator().manual_seed(step)).bfloat16()
+    dec = a.decide(4)
+    if step >= 2:                      # force pool draws, some hitting the same slot within the batch
+      dec = [(rng.random() < 0.7, rng.randrange(3)) for _ in range(4)]
+    ra = a.query(x.cuda(), dec)
+    rb = b.query(x, list(dec))
+    assert torch.equal(ra.cpu(), rb), step
+  for slot in range(6):
+    assert torch.equal(a.buffer[slot].cpu(), b.images[slot].reshape(a.buffer[slot].shape)), slot
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_maxpool_skip_and_act_fused_backward(hip, dtype):
+  """csmri_maxpool2_bwd_act: un-pooling + skip-connection gradient (U-Net encoder, MaxPool2Skip) and un-pooling x
+  activation derivative (VGG backward) against autograd on max_pool2d / leaky_relu; exact in fp32, one bf16
+  rounding of the sum in bf16."""
+  ops = hip.ops
+  gen = torch.Generator().manual_seed(12)
+  x = torch.randn(2, 16, 12, 20, generator=gen)
+  g = torch.randn(2, 16, 6, 10, generator=gen)
+  gs = torch.randn(2, 16, 12, 20, generator=gen)
+  if dtype == torch.bfloat16:
+    x, g, gs = x.bfloat16().float(), g.bfloat16().float(), gs.bfloat16().float()
+  # pool + skip
+  xd = to_dev_nhwc(x, dtype).requires_grad_(True)
+  y, skip = ops.MaxPool2Skip.apply(xd)
+  xr = x.clone().requires_grad_(True)
+  yr = F.max_pool2d(xr, 2, 2)
+  assert torch.equal(from_dev_nhwc(y, 16), yr.detach()) and torch.equal(from_dev_nhwc(skip, 16), x)
+  torch.autograd.backward([yr, xr], [g, gs])
+  torch.autograd.backward([y, skip], [to_dev_nhwc(g, dtype), to_dev_nhwc(gs, dtype)])
+  got, ref = from_dev_nhwc(xd.grad, 16), xr.grad
+  if dtype == torch.float32:
+    assert torch.equal(got, ref)
+  else:
+    assert torch.equal(got, ref.bfloat16().float())
+  # only one of the two outputs used
+  for which in (0, 1):
+    xd = to_dev_nhwc(x, dtype).requires_grad_(True)
+    outs = ops.MaxPool2Skip.apply(xd)
+    outs[which].backward(to_dev_nhwc((g, gs)[which], dtype))
+    xr = x.clone().requires_grad_(True)
+    (F.max_pool2d(xr, 2, 2) if which == 0 else xr * 1).backward((g, gs)[which])
+    assert torch.equal(from_dev_nhwc(xd.grad, 16), xr.grad)
+  # pool gradient times the derivative of the activation that fed the pool
+  for slope in (0.0, 0.2):
+    z = F.leaky_relu(x, slope) if slope else F.relu(x)
+    if dtype == torch.bfloat16:
+      z = z.bfloat16().float()
+    zd = to_dev_nhwc(z, dtype)
+    _, arg = ops.maxpool2_fwd(zd)
+    got = ops.maxpool2_bwd(to_dev_nhwc(g, dtype), arg, tuple(zd.shape), g_src=zd, g_slope=slope)
+    two = ops.act_bwd(ops.maxpool2_bwd(to_dev_nhwc(g, dtype), arg, tuple(zd.shape)), zd, slope)
+    assert torch.equal(got, two)
+    zr = z.clone().requires_grad_(True)
+    F.max_pool2d(zr, 2, 2).backward(g)
+    ref = zr.grad * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+    ref = ref if dtype == torch.float32 else ref.bfloat16().float()
+    assert torch.equal(from_dev_nhwc(got, 16), ref)
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 64), (1, 256, 256), (2, 128, 64), (1, 512, 512), (3, 32, 32)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_dc(hip, shape):
