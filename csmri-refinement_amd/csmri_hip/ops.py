@@ -565,6 +565,9 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
   d.db = layer.bias.grad.data_ptr() if layer.bias is not None else 0
   # lazily zeroed gradients (FlatAdam.lazy_zero): the first write after zero_grad() overwrites
   fresh = getattr(wgt, '_grad_fresh', False)
+  wgt._kernel_grad = True                 # (FlatAdam.lazy_zero: these gradients are written here, not by autograd)
+  if layer.bias is not None:
+    layer.bias._kernel_grad = True
   if fresh:
     wgt._grad_fresh = False
     if layer.bias is not None:
@@ -956,6 +959,8 @@ class ConvBnAct(torch.autograd.Function):
       if bn.bias.grad is None:
         bn.bias.grad = torch.zeros_like(bn.bias)
     acc_affine = 1
+    if want_affine:
+      bn.weight._kernel_grad = bn.bias._kernel_grad = True
     if want_affine and getattr(bn.weight, '_grad_fresh', False):     # lazily zeroed gradients: first write overwrites
       acc_affine = 0
       bn.weight._grad_fresh = False
@@ -1087,9 +1092,20 @@ class FrozenConvStackPair(torch.autograd.Function):
   prediction features then target features."""
 
   @staticmethod
-  def forward(ctx, p_in, t_in, plan, taps):
+  def forward(ctx, p_in, t_in, plan, taps, cabs=None):
+    # cabs = (dtype, mode): p_in / t_in are interleaved complex fp32 images [B,H,W,2]; their magnitudes (ComplexAbs
+    # of that mode) are written straight into the two halves of the batched input (no torch.cat), and the backward
+    # ends with the magnitude's derivative
     b = p_in.shape[0]
-    x = torch.cat((p_in, t_in), 0)
+    ctx.cabs = cabs
+    if cabs is not None:
+      _need_gpu(p_in)
+      x = torch.empty(2 * b, p_in.shape[1], p_in.shape[2], 8, dtype=cabs[0], device=p_in.device)
+      complex_abs_raw(p_in.detach(), cabs[0], cabs[1], x[:b])
+      complex_abs_raw(t_in.detach().contiguous(), cabs[0], cabs[1], x[b:])
+      ctx.cabs_x = p_in.detach()
+    else:
+      x = torch.cat((p_in, t_in), 0)
     saved, shapes, feats = [], [], []
     for i, (kind, layer, slope) in enumerate(plan):
       if kind == 'conv':
@@ -1133,7 +1149,7 @@ class FrozenConvStackPair(torch.autograd.Function):
         gp = g if (act_done or slope == 1.0) else act_bwd(g, y, slope)
         act_done = False
         if i == 0 and not ctx.needs_input_grad[0]:
-          return None, None, None, None
+          return None, None, None, None, None
         # fuse the producer's activation derivative into this dgrad's epilogue when the
         # producer is the previous conv of the stack (its output IS this layer's input)
         prev = plan[i - 1] if i > 0 else None
@@ -1153,7 +1169,14 @@ class FrozenConvStackPair(torch.autograd.Function):
         else:
           g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i])
           act_done = False
-    return g, None, None, None
+    if ctx.cabs is not None and g is not None:
+      xc = ctx.cabs_x
+      g = as_nhwc(g)
+      dx = torch.empty_like(xc)
+      lib.call('csmri_complex_abs_bwd', xc.data_ptr(), xc.shape[0] * xc.shape[1] * xc.shape[2], g.data_ptr(),
+               dt_of(g), g.stride(2), 3 if ctx.cabs[1] == 3 else 1, ctx.cabs[1], dx.data_ptr(), 0, stream())
+      g = dx
+    return g, None, None, None, None
 
 
 # ----------------------------------------------------------------------------
@@ -1171,15 +1194,18 @@ def copy_channels(x, c_dst, dtype=None):
   return out
 
 
-def image_pool_exchange(x, pool, plan):
+def image_pool_exchange(x, pool, plan, out=None):
   """One query of the image history pool (utils/image_pool.py): x [n,...], pool [pool_size+1,...] (updated in
-  place), plan int64 [5,n] on the device.  Returns the images handed to the discriminator."""
+  place), plan int64 [5,n] on the device.  Returns the images handed to the discriminator (in ``out`` if given:
+  a dense tensor of x's shape that does not overlap x)."""
   _need_gpu(x)
   x = x.contiguous()
   n = x.shape[0]
   assert pool.is_contiguous() and pool.dtype == x.dtype and tuple(pool.shape[1:]) == tuple(x.shape[1:])
   assert plan.is_contiguous() and plan.dtype == torch.int64 and tuple(plan.shape) == (5, n)
-  out = torch.empty_like(x)
+  if out is None:
+    out = torch.empty_like(x)
+  assert out.is_contiguous() and out.dtype == x.dtype and out.shape == x.shape and out.data_ptr() != x.data_ptr()
   lib.call('csmri_image_pool_exchange', x.data_ptr(), pool.data_ptr(), out.data_ptr(), plan.data_ptr(), n,
            x[0].numel() * x.element_size(), stream())
   return out
@@ -1274,6 +1300,19 @@ class DataConsistency(torch.autograd.Function):
 # ----------------------------------------------------------------------------
 # complex magnitude, refinement combine, losses, metric, optimizer
 # ----------------------------------------------------------------------------
+
+
+def complex_abs_raw(x, dtype, mode, out=None):
+  """|x| of interleaved complex fp32 [B,H,W,2] into NHWC [B,H,W,8] (no autograd); ``out``: a dense [B,H,W,8] view to
+  write into (e.g. one half of a batch that two calls fill, instead of a torch.cat of their results)."""
+  _need_gpu(x)
+  assert x.is_contiguous() and x.dtype == torch.float32
+  b, h, w, _ = x.shape
+  if out is None:
+    out = torch.empty(b, h, w, 8, dtype=dtype, device=x.device)
+  assert out.is_contiguous() and out.dtype == dtype and tuple(out.shape) == (b, h, w, 8)
+  lib.call('csmri_complex_abs', x.data_ptr(), b * h * w, out.data_ptr(), dt_of(out), 8, 8, mode, stream())
+  return out
 
 
 class ComplexAbs(torch.autograd.Function):

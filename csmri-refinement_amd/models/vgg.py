@@ -104,12 +104,14 @@ class VGG19(nn.Module):
       out.append(x)
     return out
 
-  def features_pair(self, p_in, t_in):
+  def features_pair(self, p_in, t_in, complex_input=False):
     """Features of a (prediction, target) pair in one batched pass; only the prediction
-    half carries gradient.  Returns (pred_feats, target_feats)."""
+    half carries gradient.  Returns (pred_feats, target_feats).  ``complex_input``: p_in / t_in are the
+    interleaved complex images [B,H,W,2] fp32 and the normalised magnitude (ComplexAbs mode 3) is part of the op."""
     plan = [('conv', conv.layer, 0.0) if kind == 'conv' else ('pool', None, None)
             for kind, conv, _ in self._plan]
-    outs = ops.FrozenConvStackPair.apply(p_in, t_in, plan, tuple(self._taps))
+    outs = ops.FrozenConvStackPair.apply(p_in, t_in, plan, tuple(self._taps),
+                                         (self.dtype, 3) if complex_input else None)
     n = len(self._taps)
     return list(outs[:n]), list(outs[n:])
 

@@ -54,13 +54,19 @@ class VGGLoss(nn.Module):
     if target.shape[-1] != 2:
       target = ops.nchw_to_nhwc(target.detach(), torch.float32, 2)
     dt = self.vgg.dtype
-    p_in = ops.ComplexAbs.apply(prediction, dt, 3)
-    with torch.no_grad():
-      t_in = ops.ComplexAbs.apply(target.detach().contiguous(), dt, 3)
-    if all(not p.requires_grad for p in self.vgg.parameters()):
-      # frozen extractor: one batched pass over [pred; target]
+    frozen = all(not p.requires_grad for p in self.vgg.parameters())
+    if frozen and prediction.is_cuda and prediction.is_contiguous():
+      # frozen extractor: one batched pass over [pred; target], the magnitudes written into its two halves
+      p_feats, t_feats = self.vgg.features_pair(prediction, target.detach(), complex_input=True)
+    elif frozen:
+      p_in = ops.ComplexAbs.apply(prediction, dt, 3)
+      with torch.no_grad():
+        t_in = ops.ComplexAbs.apply(target.detach().contiguous(), dt, 3)
       p_feats, t_feats = self.vgg.features_pair(p_in, t_in)
     else:
+      p_in = ops.ComplexAbs.apply(prediction, dt, 3)
+      with torch.no_grad():
+        t_in = ops.ComplexAbs.apply(target.detach().contiguous(), dt, 3)
       with torch.no_grad():
         t_feats = self.vgg.forward_nhwc(t_in)
       p_feats = self.vgg.forward_nhwc(p_in)

@@ -140,6 +140,9 @@ class AdversarialRunner(BaseRunner):
     if disc_optimizer is not None and hasattr(disc_optimizer, 'lazy_zero') and \
         os.environ.get('CSMRI_LAZY_ZERO', '1') == '1':                               # A/B knob
       disc_optimizer.lazy_zero = True
+    if gen_optimizer is not None and hasattr(gen_optimizer, 'lazy_zero') and \
+        os.environ.get('CSMRI_LAZY_ZERO_G', '1') == '1':                             # A/B knob
+      gen_optimizer.lazy_zero = True       # (the wrapper's scale, an autograd-accumulated gradient, is still zeroed)
     if dist_utils.world_size() > 1 and gen_optimizer is not None and disc_optimizer is not None:
       # data parallelism: a sub-bucket of gradients leaves as soon as the backward has issued its last layer
       def _ready(layer, opts=(disc_optimizer, gen_optimizer)):
@@ -293,16 +296,25 @@ class AdversarialRunner(BaseRunner):
       self._fork_vgg(st, out_gen, batch)
     if pf_at == 'after_gen':
       self._fork_prefetch(st)
+    pair = None
+    tgt = batch['target']
+    if self.batch_disc_passes and tgt.is_cuda and tgt.dim() == 4 and tgt.shape[1] == 2 and \
+        hasattr(self.disc_input_fn, 'out_dtype'):
+      # [fake; real] of the batched discriminator pass: the two inputs are written straight into the halves of
+      # one tensor (no torch.cat of their results)
+      b, _, h, w = tgt.shape
+      pair = torch.empty(2 * b, h, w, 8, dtype=self.disc_input_fn.out_dtype(), device=tgt.device)
     in_fake = self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False, detach=True,
-                                 pool_decisions=self.pool_decisions)
-    in_real = self.disc_input_fn(batch['target'], gen_inp[0], out_gen, is_real_input=True, detach=True)
+                                 pool_decisions=self.pool_decisions, **({} if pair is None else {'out': pair[:b]}))
+    in_real = self.disc_input_fn(tgt, gen_inp[0], out_gen, is_real_input=True, detach=True,
+                                 **({} if pair is None else {'out': pair[b:]}))
     if self.overlap_streams and self.vgg_early and vgg_at == 'after_din_ev':
       self._fork_vgg(st, out_gen, batch, ev_gen)
     if self.batch_disc_passes:
       # the two passes of reference :333-341 as ONE pass over [fake; real] with per-half BatchNorm
       # statistics and dropout draws (identical results, half the launches on D's small maps)
       out_fake_d, out_real = _split_disc_output(
-          self.disc(nhwc=torch.cat([in_fake, in_real], 0), groups=2), in_fake.shape[0])
+          self.disc(nhwc=pair if pair is not None else torch.cat([in_fake, in_real], 0), groups=2), in_fake.shape[0])
     else:
       out_fake_d = self.disc(nhwc=in_fake)
       out_real = self.disc(nhwc=in_real)

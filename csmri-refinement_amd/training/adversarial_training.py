@@ -25,19 +25,28 @@ def _build_input_fn(method, dtype_fn, image_pool=None, pool_label_swapping=False
     raise NotImplementedError("discriminator input_method '%s' is outside the hot path" % method)
 
   def input_wrapper(prediction_or_target, inp, out_gen, is_real_input, detach=False,
-                    pool_decisions=None):
+                    pool_decisions=None, out=None):
+    """``out`` (detached inputs only): a dense [B,H,W,8] tensor of the compute dtype that receives the result --
+    the runner hands the two halves of one batch to the fake / real calls instead of concatenating their results."""
     if isinstance(prediction_or_target, dict):
       fast = prediction_or_target.get('_nhwc')
       pred = fast['pred'] if fast is not None else prediction_or_target['pred']
     else:
       pred = prediction_or_target
     xc = _as_complex_nhwc(pred, detach)
+    if detach and xc.is_cuda:
+      pooled = image_pool is not None and (not is_real_input or pool_label_swapping) and image_pool.pool_size > 0
+      mag = ops.complex_abs_raw(xc.contiguous(), dtype_fn(), 0, None if pooled else out)
+      return image_pool.query(mag, pool_decisions, out) if pooled else mag
+    assert out is None
     mag = ops.ComplexAbs.apply(xc.contiguous(), dtype_fn(), 0)       # [B,H,W,8], channel 0
     if detach:
       mag = mag.detach()
       if image_pool is not None and (not is_real_input or pool_label_swapping):
         mag = image_pool.query(mag, pool_decisions)
     return mag
+
+  input_wrapper.out_dtype = dtype_fn
 
   return input_wrapper
 

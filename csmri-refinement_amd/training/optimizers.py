@@ -58,9 +58,8 @@ class FlatAdam(object):
     # lazy_zero: zero_grad() only MARKS the gradients stale; the first weight-gradient launch of a parameter then
     # overwrites instead of accumulating (csmri_wgrad / csmri_bn_bwd_apply `accumulate = 0`), later ones accumulate
     # as usual, and whatever is still marked at apply() is zeroed there.  Same values as fill + accumulate; saves
-    # the fill of the flat buffer (112 MB for the discriminator) and one read of it.  Only valid when every
-    # gradient of these parameters is written by the library's kernels (not by torch autograd): the runner
-    # switches it on for the discriminator.
+    # the fill of the flat buffer (112 MB for the discriminator) and one read of it.  Applies to the parameters
+    # the library's kernels have written before (they set `_kernel_grad`); the others are zeroed as usual.
     self.lazy_zero = False
     ops.bump_weight_epoch()
 
@@ -69,8 +68,19 @@ class FlatAdam(object):
       if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
         p.grad = self.flat_g[off:off + p.numel()].view_as(p)
     if self.lazy_zero:
+      # parameters whose gradients the library's kernels write (they honour the mark: ops.conv_wgrad, the BatchNorm
+      # backward) are only marked; whatever torch autograd accumulates into (e.g. the refinement wrapper's scale,
+      # and everything before the first backward has shown who writes what) is zeroed now, in one launch
+      rest = []
       for p in self.params:
-        p._grad_fresh = True
+        if getattr(p, '_kernel_grad', False):
+          p._grad_fresh = True
+        else:
+          rest.append(p.grad)
+      if len(rest) == len(self.params):
+        self.flat_g.zero_()
+      elif rest:
+        torch._foreach_zero_(rest)
     else:
       self.flat_g.zero_()
 

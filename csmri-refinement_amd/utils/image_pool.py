@@ -75,23 +75,24 @@ class ImagePool(object):
     self._idx.copy_(host, non_blocking=True)
 
   # -- device side (fixed shape) -------------------------------------------------
-  def apply_plan(self, x):
+  def apply_plan(self, x, out=None):
     if x.is_cuda:
       # one launch (csmri_image_pool_exchange) instead of three gathers, two selects and a scatter
       from csmri_hip import ops
-      return ops.image_pool_exchange(x, self.buffer, self._idx)
+      return ops.image_pool_exchange(x, self.buffer, self._idx, out)
     kind, pidx, xidx, wslot, wsrc = self._idx.unbind(0)
     from_pool = self.buffer.index_select(0, pidx)
     from_x = x.index_select(0, xidx)
     k = kind.view(-1, *([1] * (x.dim() - 1)))
-    out = torch.where(k == 1, from_pool, torch.where(k == 2, from_x, x))
+    dst, out = out, torch.where(k == 1, from_pool, torch.where(k == 2, from_x, x))
     self.buffer.index_copy_(0, wslot, x.index_select(0, wsrc))
-    return out
+    return out if dst is None else dst.copy_(out)
 
-  def query(self, image_batch, decisions=None):
+  def query(self, image_batch, decisions=None, out=None):
+    """``out``: optional tensor of the batch's shape that receives the result (and is returned)."""
     if self.pool_size == 0:
-      return image_batch
+      return image_batch if out is None else out.copy_(image_batch)
     x = image_batch.detach()
     if not self.external_plan:
       self.prepare(x, decisions)
-    return self.apply_plan(x)
+    return self.apply_plan(x, out)
