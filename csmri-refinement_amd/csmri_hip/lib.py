@@ -73,7 +73,8 @@ class PackItem(C.Structure):
 
 class LossItem(C.Structure):
   _fields_ = [('a', vp), ('b', vp), ('a_pix_stride', i32), ('b_pix_stride', i32), ('npix', i64),
-              ('C', i32), ('C_real', i32), ('weight', f32), ('ga', vp), ('ga_pix_stride', i32)]
+              ('C', i32), ('C_real', i32), ('weight', f32), ('ga', vp), ('ga_pix_stride', i32),
+              ('dtype_plus1', i32)]
 
 
 class WGradDesc(C.Structure):

@@ -1423,6 +1423,8 @@ class MultiMeanLoss(torch.autograd.Function):
       it.a, it.a_pix_stride = a.data_ptr(), a.stride(2)
       it.b, it.b_pix_stride = ptr(b), (b.stride(2) if b is not None else 0)
       it.npix, it.C, it.C_real, it.weight = bb * h * w, cp, chans[i], float(weights[i])
+      it.dtype_plus1 = dt_of(a) + 1                   # per item: a feature list may mix bf16 maps and fp32 logits
+      assert b is None or b.dtype == a.dtype
       if grads is not None:
         it.ga, it.ga_pix_stride = grads[i].data_ptr(), grads[i].stride(2)
     return arr

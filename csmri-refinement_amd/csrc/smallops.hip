@@ -295,6 +295,7 @@ extern "C" size_t csmri_loss_multi_work_bytes(int n) { return (size_t)n * LOSS_M
 
 __global__ __launch_bounds__(256) void loss_multi_partial_kernel(int kind, int dt, const LossItems L, double* work) {
   const csmri_loss_item& t = L.it[blockIdx.y];
+  if (t.dtype_plus1) dt = t.dtype_plus1 - 1;
   const int nv = (t.C_real + 3) >> 2;
   const unsigned total = (unsigned)(t.npix * nv);            // host: < 2^31
   double acc = 0.0;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(64) void loss_multi_final_kernel(const LossItems L,
 static int loss_items_ok(const csmri_loss_item* items, int n) {
   if (!items || n < 1 || n > CSMRI_LOSS_MAX_ITEMS) return 0;
   for (int i = 0; i < n; ++i)
-    if (!items[i].a || items[i].npix <= 0 || items[i].C_real <= 0 ||
+    if (!items[i].a || items[i].npix <= 0 || items[i].C_real <= 0 || items[i].dtype_plus1 < 0 || items[i].dtype_plus1 > 2 ||
         items[i].npix * ((items[i].C > items[i].C_real ? items[i].C : items[i].C_real) + 3) >= (1ll << 31)) return 0;
   return 1;
 }
@@ -355,6 +356,7 @@ extern "C" int csmri_loss_multi(int kind, int dtype, const csmri_loss_item* item
 }
 __global__ void loss_multi_bwd_kernel(int kind, int dt, const LossItems L, const float* coeff) {
   const csmri_loss_item& t = L.it[blockIdx.y];
+  if (t.dtype_plus1) dt = t.dtype_plus1 - 1;
   const int nv = t.C >> 2;
   const float k = (coeff ? coeff[0] : 1.f) * (t.weight / ((float)t.npix * (float)t.C_real));
   const unsigned total = (unsigned)(t.npix * nv);

@@ -54,7 +54,7 @@ class FeatureMatchingLoss(nn.Module):
     ff, fr = out_disc_fake['features'], out_disc_real['features']
     chans = out_disc_fake['feature_channels']
     n = len(ff)
-    if n <= 16 and len({f.dtype for f in ff}) == 1 and _FM_MULTI:
+    if n <= 16 and all(a.dtype == b.dtype for a, b in zip(ff, fr)) and _FM_MULTI:
       # every layer's distance in one launch pair (and one backward launch)
       return ops.MultiMeanLoss.apply(self.kind, [self.sign / n] * n, list(chans), *ff,
                                      *[b.detach() for b in fr])

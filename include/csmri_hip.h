@@ -415,6 +415,8 @@ typedef struct csmri_loss_item {
   long long npix; int C, C_real;
   float weight;
   void* ga; int ga_pix_stride;           /* backward only */
+  int dtype_plus1;                       /* 0: the call's dtype; else CSMRI_F32 + 1 / CSMRI_BF16 + 1 for this item's
+                                            tensors (a discriminator's feature list mixes bf16 maps and fp32 logits) */
 } csmri_loss_item;
 size_t csmri_loss_multi_work_bytes(int n);
 int csmri_loss_multi(int kind, int dtype, const csmri_loss_item* items, int n, float* result,
