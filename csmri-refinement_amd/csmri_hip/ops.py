@@ -623,6 +623,20 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
       _issue_deferred_wgrad((ev, launch, (x0, x1, gy), layer))
       return
   q.append((ev, launch, (x0, x1, gy), layer))
+  if WGRAD_FLUSH_EVERY > 0:
+    # Release point every few layers.  tools/graph_dep_probe.py: in a replayed hipGraph a side-stream node captured
+    # right behind its producer (the producer's FIRST successor) starts when the producer ends and the main chain
+    # continues on another queue after a short hop; captured any later it starts only when the producer's whole chain
+    # of first successors has ended.  So the held-back launches are released together, the first one made the first
+    # successor of the main stream's newest node: the main chain pays one hop per release instead of one per layer,
+    # and the weight gradients run next to the following layers instead of piling up behind the backward.
+    _WGRAD['since'] += 1
+    if _WGRAD['since'] >= WGRAD_FLUSH_EVERY:
+      _WGRAD['since'] = 0
+      _side_stream_of(layer).wait_stream(torch.cuda.current_stream())
+      while q:
+        _issue_deferred_wgrad(q.pop(0))
+    return
   while len(q) > WGRAD_DEFER:
     _issue_deferred_wgrad(q.pop(0))
 
@@ -664,13 +678,15 @@ def _issue_deferred_wgrad(d):
 
 def _flush_deferred_wgrad():
   q = _WGRAD['deferred']
+  _WGRAD['since'] = 0
   while q:
     _issue_deferred_wgrad(q.pop(0))
 
 
 WGRAD_DEFER = int(os.environ.get('CSMRI_WGRAD_DEFER', '2'))     # A/B knob: weight-gradient launches held back (0 = none)
+WGRAD_FLUSH_EVERY = int(os.environ.get('CSMRI_WGRAD_FLUSH_EVERY', '0'))   # A/B knob: release the held-back launches every N layers
 WGRAD_STREAMS = int(os.environ.get('CSMRI_WGRAD_STREAMS', '1'))  # A/B knob: side streams the layers alternate between
-_WGRAD = {'stream': None, 'pending': False, 'deferred': [], 'extra': [], 'next': 0}
+_WGRAD = {'stream': None, 'pending': False, 'deferred': [], 'extra': [], 'next': 0, 'since': 0}
 
 
 def enable_wgrad_stream(on):

@@ -159,6 +159,23 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const csmri_pack
   for (int t = blockIdx.x; t < g.rows * nchunk; t += gridDim.x) {
     const int r = t / nchunk, c0 = (t - r * nchunk) * 64;
     const int nc = max(0, min(64, chan - c0));
+    if (T == 16 && KW == 4 && nc == 64 && it.mode != 2 && it.dtype == CSMRI_BF16 && g.chan_pad - c0 >= 64 &&
+        (((uintptr_t)it_w | (uintptr_t)it.out) & 15) == 0 && (g.chan_pad & 3) == 0 && (g.Kp & 3) == 0) {
+      // full 64-channel x 4x4-tap tile (every discriminator / U-Net 4x4 layer): one 16-byte load of four taps and one
+      // 8-byte store of four channels per thread instead of four scalar loads and four 2-byte stores
+      const int ch = threadIdx.x >> 2, q4 = threadIdx.x & 3;
+      const f32x4_t v = *(const f32x4_t*)(swapped ? it_w + ((long long)(c0 + ch) * it.Cin + r) * 16 + q4 * 4
+                                                  : it_w + ((long long)r * it.Cin + c0 + ch) * 16 + q4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[q4 * 4 + j][ch] = v[j];
+      __syncthreads();
+      const int tp = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+      const int src = it.mode == 3 ? 15 - tp : tp;            // mode 3: taps flipped in both axes
+      const f32x4_t o = (f32x4_t){tile[src][c4], tile[src][c4 + 1], tile[src][c4 + 2], tile[src][c4 + 3]};
+      store4(it.out, (long long)r * g.Kp + (long long)tp * g.chan_pad + c0 + c4, CSMRI_BF16, o);
+      __syncthreads();
+      continue;
+    }
     // at most 64*16 elements per tile = 4 per thread: fixed-trip loops keep all four global loads
     // (and later all four stores) of a thread in flight together
     float vals[4];

@@ -229,6 +229,43 @@ def test_maxpool(hip, dtype):
   assert torch.equal(from_dev_nhwc(xd.grad, 16), xr.grad)
 
 
+def test_pack_group_repack_equals_single_layer_pack(hip):
+  """csmri_pack_weight_multi (one launch for every layer of a network after an optimizer step; vectorised path for
+  full 64-channel 4x4 tiles, generic path otherwise) against csmri_pack_weight layer by layer: bit-identical packed
+  buffers for the forward, data-gradient and sub-pixel modes, bf16 and fp32, aligned and unaligned weight storage."""
+  ops = hip.ops
+  gen = torch.Generator().manual_seed(21)
+  shapes = [(128, 64, 4, 4), (64, 128, 4, 4), (96, 72, 4, 4), (40, 24, 3, 3), (1, 512, 4, 4), (256, 256, 4, 4)]
+  flat = torch.randn(sum(a * b * c * d for a, b, c, d in shapes) + 8, generator=gen).cuda()
+  for dtype in (torch.bfloat16, torch.float32):
+    for shift in (0, 1):             # shift 1: weights start 4 bytes off a 16-byte boundary (flat optimizer buffers)
+      layers, off = [], shift
+      for sh in shapes:
+        n = sh[0] * sh[1] * sh[2] * sh[3]
+        layers.append(ops.ConvLayer(flat[off:off + n].view(sh), None, 1, (1, 2, 1, 2), 'zero', dtype))
+        off += n
+      group = ops.PackGroup(layers)
+      modes = (0, 3, 2)
+      for l in layers:
+        for m in modes:
+          if m == 2 and l.kh % 2:
+            continue
+          l._pack(m)
+      first = {(i, m): l._packs[m][1].clone() for i, l in enumerate(layers) for m in l._packs}
+      flat.mul_(-0.5).add_(0.25)       # "optimizer step"
+      group.bump()
+      for m in modes:
+        assert group.repack(m)
+      for i, l in enumerate(layers):
+        ref = ops.ConvLayer(l.weight, None, 1, (1, 2, 1, 2), 'zero', dtype)
+        for m in l._packs:
+          got = l._packs[m][1]
+          want = ref._pack(m)[0]
+          assert torch.equal(got, want), (dtype, shift, i, m)
+          assert not torch.equal(got, first[(i, m)]), (dtype, shift, i, m)
+      flat.sub_(0.25).div_(-0.5)
+
+
 def test_image_pool_exchange_matches_sequential_reference(hip):
   """csmri_image_pool_exchange (one launch) against the oracle's sequential pool (reference utils/image_pool.py:29-60)
   on the same decisions: filling phase, draws, a slot drawn twice in one batch (the second draw must see the image
