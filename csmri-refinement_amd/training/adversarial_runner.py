@@ -267,7 +267,6 @@ class AdversarialRunner(BaseRunner):
   def _seg1(self, st):
     batch = st['batch']
     if self.vgg_early is None:
-      from training import distributed as dist_utils
       env = os.environ.get('CSMRI_VGG_EARLY')          # A/B knob
       self.vgg_early = (env == '1') if env in ('0', '1') else dist_utils.world_size() == 1
     gen_inp = self.train_model_input_fn(batch)
@@ -358,7 +357,14 @@ class AdversarialRunner(BaseRunner):
     total_disc.backward()
     if ev_dfwd is not None and third_at == 'after_dbwd_ev':
       third_now()
-    ops.join_wgrad_stream()
+    # D's weight gradients (side stream) are only needed by D's Adam.  Joining them there instead of here (single
+    # GPU: no gradient exchange after this segment) would let the look-ahead fork, the generator's losses and the
+    # start of segment 3 run next to the weight-gradient tail of D's backward -- measured 9 % SLOWER (the replayed
+    # graph's chains re-form around the moved join), so the join stays here.
+    st['_dwgrad_join_late'] = (dist_utils.world_size() == 1 and st['out_disc_fake_early'] is not None and
+                               os.environ.get('CSMRI_DWGRAD_JOIN', 'early') == 'late')      # A/B knob: measured 6.50-6.60 vs 5.98 ms -> off
+    if not st['_dwgrad_join_late']:
+      ops.join_wgrad_stream()
     names.append('disc_loss')
     vals.append(total_disc.detach())
     st['names'], st['vals'] = names, vals
@@ -539,8 +545,12 @@ class AdversarialRunner(BaseRunner):
       # VGG backward and the rest of the generator backward start without waiting for it.
       self._side_stream3.wait_stream(torch.cuda.current_stream())
       with torch.cuda.stream(self._side_stream3):
+        if st.pop('_dwgrad_join_late', False):
+          ops.join_wgrad_stream()
         self.disc_optimizer.apply()
     else:
+      if st.pop('_dwgrad_join_late', False):
+        ops.join_wgrad_stream()
       self.disc_optimizer.apply()
     self.gen_optimizer.zero_grad()
     ops.enable_wgrad_stream(self.overlap_streams)
