@@ -605,7 +605,7 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
     for t in (x0, x1, gy):
       if t is not None:
         t.record_stream(side)
-    _WGRAD['pending'] = True
+    _mark_pending(side)
     return
   # Deferred issue: the operands are ready NOW (event), but the launch itself is issued one weight gradient later.
   # In a captured graph a node's first-issued successor stays on its hardware queue; issuing the side-stream launch
@@ -645,6 +645,26 @@ def _wgrad_deferred_mode():
   return WGRAD_DEFER > 0 and _WGRAD['stream'] is not None
 
 
+_NAMED_STREAMS = {}
+
+
+def named_stream(name, priority=0):
+  """One HIP stream per role and device for the whole process.  torch hands out streams from a pool of 32 per
+  priority, round-robin: runners that each create their own half-dozen side streams (tests build dozens of runners in
+  one process) end up with two roles ALIASED to one stream, and a graph captured across such a pair crashed the
+  runtime at replay.  Roles: 'wgrad', 'wgrad1'.., 'vgg', 'third', 'lookahead', 'metrics', 'capture', 'warmup'."""
+  key = (name, torch.cuda.current_device(), priority)
+  st = _NAMED_STREAMS.get(key)
+  if st is None:
+    st = _NAMED_STREAMS[key] = torch.cuda.Stream(priority=priority)
+  return st
+
+
+def _mark_pending(side):
+  if not any(st is side for st in _WGRAD['pending']):
+    _WGRAD['pending'].append(side)
+
+
 def _side_stream_of(layer):
   """The side stream of a layer's weight-gradient launches: fixed per layer (its accumulations stay ordered),
   layers alternate between the WGRAD_STREAMS streams in order of first use (one layer's slab reduce then runs
@@ -657,7 +677,7 @@ def _side_stream_of(layer):
     return _WGRAD['stream']
   extra = _WGRAD['extra']
   while len(extra) < WGRAD_STREAMS - 1:
-    extra.append(torch.cuda.Stream())
+    extra.append(named_stream('wgrad%d' % (len(extra) + 1)))
   k %= WGRAD_STREAMS
   return _WGRAD['stream'] if k == 0 else extra[k - 1]
 
@@ -671,7 +691,7 @@ def _issue_deferred_wgrad(d):
   for t in tensors:
     if t is not None:
       t.record_stream(side)
-  _WGRAD['pending'] = True
+  _mark_pending(side)
   if GRAD_READY_HOOK is not None:
     GRAD_READY_HOOK(layer)
 
@@ -686,13 +706,13 @@ def _flush_deferred_wgrad():
 WGRAD_DEFER = int(os.environ.get('CSMRI_WGRAD_DEFER', '2'))     # A/B knob: weight-gradient launches held back (0 = none)
 WGRAD_FLUSH_EVERY = int(os.environ.get('CSMRI_WGRAD_FLUSH_EVERY', '0'))   # A/B knob: release the held-back launches every N layers
 WGRAD_STREAMS = int(os.environ.get('CSMRI_WGRAD_STREAMS', '1'))  # A/B knob: side streams the layers alternate between
-_WGRAD = {'stream': None, 'pending': False, 'deferred': [], 'extra': [], 'next': 0, 'since': 0}
+_WGRAD = {'stream': None, 'pending': [], 'deferred': [], 'extra': [], 'next': 0, 'since': 0}
 
 
 def enable_wgrad_stream(on):
   """Route csmri_wgrad launches to a dedicated side stream (join with join_wgrad_stream)."""
   if on and _WGRAD['stream'] is None:
-    _WGRAD['stream'] = torch.cuda.Stream()
+    _WGRAD['stream'] = named_stream('wgrad')
   elif not on:
     join_wgrad_stream()
     _WGRAD['stream'] = None
@@ -701,11 +721,11 @@ def enable_wgrad_stream(on):
 def join_wgrad_stream():
   """Make the current stream wait for every weight-gradient launch issued so far."""
   _flush_deferred_wgrad()
-  if _WGRAD['pending']:
-    torch.cuda.current_stream().wait_stream(_WGRAD['stream'])
-    for st in _WGRAD['extra']:
-      torch.cuda.current_stream().wait_stream(st)
-    _WGRAD['pending'] = False
+  # only streams that received launches since the last join: waiting on an idle stream from inside a graph capture
+  # records an event outside the capture (the replay of such a graph crashed in the runtime)
+  for st in _WGRAD['pending']:
+    torch.cuda.current_stream().wait_stream(st)
+  _WGRAD['pending'] = []
 
 
 def act_bwd(gz, z, slope):

@@ -330,7 +330,7 @@ class AdversarialRunner(BaseRunner):
       # follow the two passes above for the BatchNorm running statistics) runs on its own stream
       # next to the D loss and backward below -- two chains of small kernels share the chip
       if self._side_stream3 is None:
-        self._side_stream3 = torch.cuda.Stream()
+        self._side_stream3 = ops.named_stream('third')
       if third_at == 'early':
         self._side_stream3.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._side_stream3):
@@ -357,14 +357,10 @@ class AdversarialRunner(BaseRunner):
     total_disc.backward()
     if ev_dfwd is not None and third_at == 'after_dbwd_ev':
       third_now()
-    # D's weight gradients (side stream) are only needed by D's Adam.  Joining them there instead of here (single
-    # GPU: no gradient exchange after this segment) would let the look-ahead fork, the generator's losses and the
-    # start of segment 3 run next to the weight-gradient tail of D's backward -- measured 9 % SLOWER (the replayed
-    # graph's chains re-form around the moved join), so the join stays here.
-    st['_dwgrad_join_late'] = (dist_utils.world_size() == 1 and st['out_disc_fake_early'] is not None and
-                               os.environ.get('CSMRI_DWGRAD_JOIN', 'early') == 'late')      # A/B knob: measured 6.50-6.60 vs 5.98 ms -> off
-    if not st['_dwgrad_join_late']:
-      ops.join_wgrad_stream()
+    # (Joining D's weight-gradient stream only at D's Adam -- so that the look-ahead fork and the generator's losses
+    # run next to the weight-gradient tail of D's backward -- measured 9 % slower on the bench and crashed the graph
+    # replay of a small configuration inside the runtime: removed)
+    ops.join_wgrad_stream()
     names.append('disc_loss')
     vals.append(total_disc.detach())
     st['names'], st['vals'] = names, vals
@@ -382,7 +378,7 @@ class AdversarialRunner(BaseRunner):
     if st.get('batch_next') is None:
       return
     if self._pf_stream is None:
-      self._pf_stream = torch.cuda.Stream()
+      self._pf_stream = ops.named_stream('lookahead')
     self._pf_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(self._pf_stream):
       st['pre_next'] = self.gen.precompute(*self.train_model_input_fn(st['batch_next']))
@@ -414,7 +410,7 @@ class AdversarialRunner(BaseRunner):
     the D-bucket all-reduce.  Autograd replays the stream assignment in the backward, so the two
     gradient chains into `pred` overlap as well."""
     if self._side_stream is None:
-      self._side_stream = torch.cuda.Stream(priority=int(os.environ.get('CSMRI_PRIO_VGG', '0')))
+      self._side_stream = ops.named_stream('vgg', int(os.environ.get('CSMRI_PRIO_VGG', '0')))
     if event is not None:             # the branch only depends on the generator output (issue order: see _seg1)
       self._side_stream.wait_event(event)
     else:
@@ -520,7 +516,7 @@ class AdversarialRunner(BaseRunner):
         st['train_metrics'] = self._compute_train_metrics(data)
       return
     if self._metric_stream is None:
-      self._metric_stream = torch.cuda.Stream()
+      self._metric_stream = ops.named_stream('metrics')
     if event is not None:
       self._metric_stream.wait_event(event)
     else:
@@ -545,12 +541,8 @@ class AdversarialRunner(BaseRunner):
       # VGG backward and the rest of the generator backward start without waiting for it.
       self._side_stream3.wait_stream(torch.cuda.current_stream())
       with torch.cuda.stream(self._side_stream3):
-        if st.pop('_dwgrad_join_late', False):
-          ops.join_wgrad_stream()
         self.disc_optimizer.apply()
     else:
-      if st.pop('_dwgrad_join_late', False):
-        ops.join_wgrad_stream()
       self.disc_optimizer.apply()
     self.gen_optimizer.zero_grad()
     ops.enable_wgrad_stream(self.overlap_streams)
@@ -625,7 +617,7 @@ class AdversarialRunner(BaseRunner):
       static_next = {k: v.detach().clone() for k, v in example_batch.items()}
       static_pre = self.gen.precompute(*self.train_model_input_fn(static)).clone()
     self._set_train()
-    side = torch.cuda.Stream()
+    side = ops.named_stream('warmup')
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
       for _ in range(warmup):
@@ -663,7 +655,7 @@ class AdversarialRunner(BaseRunner):
     else:
       segments = (self._seg1, self._seg2, self._seg3, self._seg4)
     prio = int(os.environ.get('CSMRI_PRIO_MAIN', '0'))
-    cap_stream = torch.cuda.Stream(priority=prio)
+    cap_stream = ops.named_stream('capture', prio)
     try:
       for seg in segments:
         g = torch.cuda.CUDAGraph()

@@ -123,7 +123,8 @@ class Runner(BaseRunner):
     assert dist_utils.world_size() == 1, 'graph mode of the standard runner is single-GPU'
     static = {k: v.detach().clone() for k, v in example_batch.items()}
     self._set_train()
-    side = torch.cuda.Stream()
+    from csmri_hip import ops as _ops
+    side = _ops.named_stream('warmup')
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
       for _ in range(warmup):
@@ -134,7 +135,7 @@ class Runner(BaseRunner):
     import gc
     gc.collect()
     g = torch.cuda.CUDAGraph()
-    cap = torch.cuda.Stream()
+    cap = _ops.named_stream('capture')
     with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
       names, losses, total, out = self._step_body(static)
       self.optimizer.step()
