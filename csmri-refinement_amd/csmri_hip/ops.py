@@ -781,9 +781,10 @@ class ConvAct(torch.autograd.Function):
 FUSED_CONVBLOCK = not os.environ.get('CSMRI_NO_FUSED_CONVBLOCK')
 
 
-def convblock_fused_forward(x, plan, out_dtype_last, need_acts):
+def convblock_fused_forward(x, plan, out_dtype_last, need_acts, out_complex=False):
   """The whole conv block in one launch (csrc/convblock.hip) when its shape is the supported one, else None.
-  Returns [x, a1, a2, y] (a1 / a2 = None when ``need_acts`` is false: nothing of them reaches HBM)."""
+  Returns [x, a1, a2, y] (a1 / a2 = None when ``need_acts`` is false: nothing of them reaches HBM).
+  ``out_complex``: y is the dense interleaved complex fp32 image [B,H,W,2] instead of the padded [B,H,W,8]."""
   if len(plan) != 3 or x.dtype != torch.bfloat16 or not is_nhwc(x):
     return None
   layers = [l for l, _ in plan]
@@ -817,7 +818,11 @@ def convblock_fused_forward(x, plan, out_dtype_last, need_acts):
     a2 = torch.empty(b, h, w, layers[1].cout_p, dtype=torch.bfloat16, device=x.device)
     d.act[0], d.act[1] = a1.data_ptr(), a2.data_ptr()
     d.act_pix_stride[0], d.act_pix_stride[1] = a1.stride(2), a2.stride(2)
-  y = torch.empty(b, h, w, layers[2].cout_p, dtype=out_dtype_last or torch.bfloat16, device=x.device)
+  if out_complex:
+    assert layers[2].cout == 2 and out_dtype_last == torch.float32
+    y = torch.empty(b, h, w, 2, dtype=torch.float32, device=x.device)
+  else:
+    y = torch.empty(b, h, w, layers[2].cout_p, dtype=out_dtype_last or torch.bfloat16, device=x.device)
   d.out, d.out_dtype, d.out_pix_stride = y.data_ptr(), dt_of(y), y.stride(2)
   if LAUNCH_LOG is not None:
     LAUNCH_LOG.append(('convblock', 'convblock_fwd_kernel<%s>' % ('true' if need_acts else 'false'), 1))
@@ -839,17 +844,29 @@ class ConvActStack(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, plan, out_dtype_last, *params):
+    # out_dtype_last = ('complex', torch.float32): a block that ends in 2 channels (re, im) without activation
+    # returns the dense interleaved complex fp32 image [B,H,W,2] -- what the DC layer reads and what its adjoint
+    # hands back -- instead of the channel-padded [B,H,W,8] (4x the bytes written, read, and returned as gradient)
     n = len(plan)
+    out_complex = isinstance(out_dtype_last, tuple)
+    if out_complex:
+      out_dtype_last = out_dtype_last[1]
+      assert out_dtype_last == torch.float32 and plan[-1][0].cout == 2 and plan[-1][1] == 1.0
     saved = None
     if FUSED_CONVBLOCK:
       need_acts = any(ctx.needs_input_grad[i] for i in (0,) + tuple(range(3, 3 + len(params))))
-      saved = convblock_fused_forward(x, plan, out_dtype_last, need_acts)
+      saved = convblock_fused_forward(x, plan, out_dtype_last, need_acts, out_complex)
     if saved is None:
       saved, cur = [x], x
       for i, (layer, slope) in enumerate(plan):
         cur, _ = conv_forward(layer, cur, None, True, slope, False, out_dtype_last if i == n - 1 else None)
         saved.append(cur)
+      if out_complex:
+        saved[-1] = copy_channels(saved[-1], 2, torch.float32)
     cur = saved[-1]
+    ctx.out_complex = out_complex
+    if out_complex:
+      saved = list(saved[:-1]) + [None]        # (the un-activated last output is not needed by the backward)
     ctx.plan = plan
     ctx.w_req = [layer.weight.requires_grad and layer.train_weights for layer, _ in plan]
     ctx.save_for_backward(*saved)
@@ -861,7 +878,9 @@ class ConvActStack(torch.autograd.Function):
     n = len(plan)
     g = as_nhwc(gy)
     last_layer, last_slope = plan[-1]
-    if g.dtype != last_layer.dtype:
+    if ctx.out_complex:              # [B,H,W,2] fp32 -> the data-gradient kernels' padded layout, one pass
+      g = copy_channels(g, last_layer.cout_p, last_layer.dtype)
+    elif g.dtype != last_layer.dtype:
       g = g.to(last_layer.dtype)
     if last_slope != 1.0:
       g = act_bwd(g, saved[n], last_slope)

@@ -280,7 +280,9 @@ __global__ __launch_bounds__(256, 2) void convblock_fwd_kernel(const CBParams p)
       if (g < 2 && y < p.H && x < p.W) {
         const size_t o = ((size_t)(b * p.H + y) * p.W + x) * (size_t)p.ops + 4 * g;
         const f32x4_t v = acc[u] + bias3;
-        if (p.out_dt == CSMRI_F32) *(f32x4_t*)((float*)p.out + o) = v;
+        if (p.ops == 2) {                 // dense interleaved complex output: the two real channels only
+          if (g == 0) *(f32x2_t*)((float*)p.out + o) = (f32x2_t){v[0], v[1]};
+        } else if (p.out_dt == CSMRI_F32) *(f32x4_t*)((float*)p.out + o) = v;
         else *(u32x2_t*)((unsigned short*)p.out + o) = cb_pack4(v);
       }
     }
@@ -308,7 +310,9 @@ extern "C" int csmri_convblock_fused_fwd(const csmri_convblock_desc* d, void* st
   CSMRI_CHECK_ARG(d && d->x && d->out && d->w[0] && d->w[1] && d->w[2] && d->bias[0] && d->bias[1] && d->bias[2]);
   if (!csmri_convblock_fused_supported(d)) return CSMRI_E_UNSUPPORTED;
   CSMRI_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->x_pix_stride >= 8 && d->x_pix_stride % 8 == 0);
-  CSMRI_CHECK_ARG(d->out_pix_stride >= 8 && d->out_pix_stride % 4 == 0);
+  // out: [B,H,W,8] (channels 2..7 zero), or the dense interleaved complex fp32 image [B,H,W,2] the DC layer consumes
+  CSMRI_CHECK_ARG((d->out_pix_stride >= 8 && d->out_pix_stride % 4 == 0) ||
+                  (d->out_pix_stride == 2 && d->out_dtype == CSMRI_F32));
   CSMRI_CHECK_ARG(d->out_dtype == CSMRI_F32 || d->out_dtype == CSMRI_BF16);
   CSMRI_CHECK_ARG(d->Kp[0] >= 96 && d->Kp[1] >= 288 && d->Kp[2] >= 288);
 #ifndef CSMRI_DBG_STAMPS

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from csmri_hip import ops
-from models.utils import ConvParams, same_padding, default_compute_dtype
+from models.utils import ConvParams, ensure_pack_group, same_padding, default_compute_dtype
 from models.weight_inits import initialize_weights
 
 RECNET_REQUIRED_PARAMS = ['num_blocks', 'num_convs', 'num_filters']
@@ -63,7 +63,10 @@ class ConvBlock(nn.Module):
     cps = [self.layers[str(3 * i + 1)] for i in range(n)]
     plan = [(cp.layer, 1.0 if i == n - 1 else self.slope) for i, cp in enumerate(cps)]
     params = [p for cp in cps for p in (cp.weight, cp.bias)]
-    return ops.ConvActStack.apply(x, plan, self.out_dtype, *params)
+    out = self.out_dtype
+    if self.num_outputs == 2 and out == torch.float32 and x.is_cuda:
+      out = ('complex', torch.float32)          # dense [B,H,W,2] fp32: what DC consumes
+    return ops.ConvActStack.apply(x, plan, out, *params)
 
 
 class RecNet(nn.Module):
@@ -107,6 +110,7 @@ class RecNet(nn.Module):
 
   def forward(self, inp, kspace, mask):
     """inp, kspace, mask: [B,2,H,W] fp32 (re, im planes).  Returns [B,2,H,W]."""
+    ensure_pack_group(self)          # trainable: one multi-layer re-pack per mode after an optimizer step (15 x 2 launches otherwise)
     x_pad = ops.ToNHWC.apply(inp, self.dtype, 8)             # conv input layout
     x_c = ops.ToNHWC.apply(inp, torch.float32, 2)            # interleaved complex
     k0 = ops.nchw_to_nhwc(kspace, torch.float32, 2)
@@ -114,9 +118,9 @@ class RecNet(nn.Module):
     recs = []
     nb = len(self.conv_blocks)
     for idx, block in enumerate(self.conv_blocks):
-      y = block(x_pad)                                       # fp32 [B,H,W,8], ch 0,1 = re,im
+      y = block(x_pad)                                       # fp32 [B,H,W,2] (re, im), or [B,H,W,8] with ch 0,1 = re,im
       if self.use_refinement:
-        y = y + _CastPad.apply(x_c, torch.float32)
+        y = y + (x_c if y.shape[3] == 2 else _CastPad.apply(x_c, torch.float32))
       if idx < len(self.dc_layers):
         want_pad = self.dtype if idx < nb - 1 else None
         res = ops.DataConsistency.apply(y, k0, m8, want_pad)
@@ -128,7 +132,7 @@ class RecNet(nn.Module):
         if self.return_intermediate_recs:
           recs.append(ops.ToNCHW.apply(x_c, 2))
       else:
-        x_c = _Slice2.apply(y)
+        x_c = y if y.shape[3] == 2 else _Slice2.apply(y)
         if idx < nb - 1:
           x_pad = _CastPad.apply(x_c, self.dtype)
     out = ops.ToNCHW.apply(x_c, 2)

@@ -166,7 +166,9 @@ typedef struct csmri_convblock_desc {
   const float* bias[3];
   float slope;
   void* act[2]; int act_pix_stride[2];
-  void* out; int out_dtype; int out_pix_stride;
+  void* out; int out_dtype; int out_pix_stride;       /* [B,H,W,8] (out_pix_stride >= 8), or out_pix_stride == 2 with
+                                                         fp32: the dense interleaved complex image [B,H,W,2] that
+                                                         DataConsistencyInKspace.perform (myfft.py:145-163) consumes */
 } csmri_convblock_desc;
 int csmri_convblock_fused_supported(const csmri_convblock_desc* d);
 int csmri_convblock_fused_fwd(const csmri_convblock_desc* d, void* stream);

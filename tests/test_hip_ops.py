@@ -481,6 +481,25 @@ def test_convblock_fused_equals_per_layer_path(hip, shape):
   err = rel_l2(from_dev_nhwc(yf, 2), r)
   print('convblock fused %s vs oracle rel_l2 %.3e' % (shape, err))
   assert err < 1e-2
+  # dense complex output ([B,H,W,2] fp32, what RecNet hands to the DC layer): same values as channels 0,1 of the
+  # padded output and the same gradients from a 2-channel output gradient, fused and per layer
+  for fused in (True, False):
+    ops.FUSED_CONVBLOCK = fused
+    try:
+      params = [(torch.nn.Parameter(wt.clone().cuda()), torch.nn.Parameter(bi.clone().cuda())) for wt, bi in zip(ws, bs)]
+      plan = [(ops.ConvLayer(wp, bp, 1, (1, 1, 1, 1), 'zero', torch.bfloat16), 0.01 if i < 2 else 1.0)
+              for i, (wp, bp) in enumerate(params)]
+      xd = to_dev_nhwc(x, torch.bfloat16).requires_grad_(True)
+      yc = ops.ConvActStack.apply(xd, plan, ('complex', torch.float32), *[t for pr in params for t in pr])
+      assert tuple(yc.shape) == (b, h, w, 2) and yc.dtype == torch.float32 and yc.is_contiguous()
+      assert torch.equal(yc.detach(), yf[..., :2])
+      yc.backward(to_dev_nhwc(gy, torch.float32)[..., :2].contiguous())
+      ops.join_wgrad_stream()
+      got = [xd.grad] + [t.grad for pr in params for t in pr]
+      for a, c in zip(got, gf):
+        assert torch.equal(a, c)
+    finally:
+      ops.FUSED_CONVBLOCK = True
 
 
 def test_layout_roundtrip(hip):
