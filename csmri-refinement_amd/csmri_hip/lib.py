@@ -90,6 +90,7 @@ class WGradDesc(C.Structure):
       ('dw', vp), ('db', vp),
       ('splitk', i32), ('slab', vp),
       ('accumulate', i32),
+      ('defer_finish', i32),
   ]
 
 
@@ -115,6 +116,7 @@ _SIGS = {
     'csmri_convblock_fused_fwd': (i32, [vp, vp]),
     'csmri_quantize_fp8': (i32, [i32, vp, vp, i64, vp, vp, vp]),
     'csmri_wgrad': (i32, [C.POINTER(WGradDesc), vp]),
+    'csmri_wgrad_finish_multi': (i32, [C.POINTER(WGradDesc), i32, vp]),
     'csmri_wgrad_slab_bytes': (sz, [C.POINTER(WGradDesc)]),
     'csmri_wgrad_suggest_splitk': (i32, [C.POINTER(WGradDesc)]),
     'csmri_wgrad_kernel_name': (i32, [C.POINTER(WGradDesc), C.c_char_p, i32]),

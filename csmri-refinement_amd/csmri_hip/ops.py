@@ -589,8 +589,20 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
       label += ' B%d %dx%d->%dx%d Cin%d Cout%d k%d s%d up%d refl%d sk%d' % (
           b, h, w, ho, wo, layer.cin_p, layer.cout_p, layer.kh, layer.stride, int(layer.upsample),
           int(layer.border == BORDER_REFLECT), d.splitk)
+    # the slab reduction of every layer of this backward pass in ONE launch at its end (csmri_wgrad_finish_multi)
+    # instead of one or two small launches behind each main kernel -- when somebody will flush the queue (the
+    # end-of-backward callback) and nobody needs this gradient earlier (data parallelism starts a bucket per layer)
+    fq = _WGRAD['finish']
+    want = WGRAD_FINISH_MULTI == '1' or (WGRAD_FINISH_MULTI == 'auto' and _WGRAD['stream'] is None)
+    defer = want and PROFILE is None and GRAD_READY_HOOK is None and WGRAD_STREAMS <= 1 and _ensure_flush_callback()
+    if defer and any(e[0].dw == d.dw for e in fq):
+      _finish_wgrads()                     # a second weight gradient of the same layer: its accumulation comes after
+    d.defer_finish = int(bool(defer))
     with _Timed(label, 2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw):
       lib.call('csmri_wgrad', C.byref(d), stream())
+    if defer:
+      fq.append((d, slab, wgt.grad, layer.bias.grad if layer.bias is not None else None,
+                 torch.cuda.current_stream()))
 
   if _WGRAD['stream'] is None:
     launch()
@@ -614,14 +626,11 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
   ev = torch.cuda.Event()
   ev.record(torch.cuda.current_stream())
   q = _WGRAD['deferred']
-  if not q:
-    # whatever is still held back when this backward pass ends is issued then (autograd engine callback): a caller
-    # that reads .grad after backward() + synchronize / join_wgrad_stream() sees every launch, as without deferral
-    try:
-      torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_wgrad)
-    except RuntimeError:            # not inside a backward pass (direct call): no deferral
-      _issue_deferred_wgrad((ev, launch, (x0, x1, gy), layer))
-      return
+  # whatever is still held back when this backward pass ends is issued then (autograd engine callback): a caller
+  # that reads .grad after backward() + synchronize / join_wgrad_stream() sees every launch, as without deferral
+  if not _ensure_flush_callback():      # not inside a backward pass (direct call): no deferral
+    _issue_deferred_wgrad((ev, launch, (x0, x1, gy), layer))
+    return
   q.append((ev, launch, (x0, x1, gy), layer))
   if WGRAD_FLUSH_EVERY > 0:
     # Release point every few layers.  tools/graph_dep_probe.py: in a replayed hipGraph a side-stream node captured
@@ -696,17 +705,52 @@ def _issue_deferred_wgrad(d):
     GRAD_READY_HOOK(layer)
 
 
+def _ensure_flush_callback():
+  """Register _flush_deferred_wgrad to run when the current backward pass ends (once per pass).  False outside a
+  backward pass: nothing would flush, the caller must not hold anything back."""
+  if _WGRAD['callback']:
+    return True
+  try:
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_wgrad)
+  except RuntimeError:
+    return False
+  _WGRAD['callback'] = True
+  return True
+
+
+def _finish_wgrads():
+  """The deferred slab reductions of the weight gradients issued so far, one launch (on the stream they ran on)."""
+  fq = _WGRAD['finish']
+  if not fq:
+    return
+  st = fq[0][4]
+  arr = (lib.WGradDesc * len(fq))()
+  for i, e in enumerate(fq):
+    assert e[4] == st
+    C.memmove(C.byref(arr[i]), C.byref(e[0]), C.sizeof(lib.WGradDesc))
+  with torch.cuda.stream(st):
+    lib.call('csmri_wgrad_finish_multi', arr, len(fq), st.cuda_stream)
+  del fq[:]
+
+
 def _flush_deferred_wgrad():
   q = _WGRAD['deferred']
   _WGRAD['since'] = 0
+  _WGRAD['callback'] = False
   while q:
     _issue_deferred_wgrad(q.pop(0))
+  _finish_wgrads()
 
 
 WGRAD_DEFER = int(os.environ.get('CSMRI_WGRAD_DEFER', '2'))     # A/B knob: weight-gradient launches held back (0 = none)
+# one slab-reduction launch per backward pass: 'auto' = when the weight gradients run on the main stream (RecNet MSE
+# step: 30 launches of 12-16 us in a strictly serial step, +9.5 %); with the side stream of the GAN step the per-layer
+# reductions read their slab while it is still in the Infinity Cache and the single launch measured 1 % slower
+WGRAD_FINISH_MULTI = os.environ.get('CSMRI_WGRAD_FINISH_MULTI', 'auto')       # A/B knob: auto | 1 | 0
 WGRAD_FLUSH_EVERY = int(os.environ.get('CSMRI_WGRAD_FLUSH_EVERY', '0'))   # A/B knob: release the held-back launches every N layers
 WGRAD_STREAMS = int(os.environ.get('CSMRI_WGRAD_STREAMS', '1'))  # A/B knob: side streams the layers alternate between
-_WGRAD = {'stream': None, 'pending': [], 'deferred': [], 'extra': [], 'next': 0, 'since': 0}
+_WGRAD = {'stream': None, 'pending': [], 'deferred': [], 'extra': [], 'next': 0, 'since': 0, 'finish': [],
+          'callback': False}
 
 
 def enable_wgrad_stream(on):

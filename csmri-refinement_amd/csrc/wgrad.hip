@@ -179,17 +179,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float* slab, int splitk, int Cout, int NK, int Cin,
-                                                            int KH, int KW, int Cout_real, int Cin_real, float* dw,
-                                                            int accumulate) {
+// Slab reductions.  The bodies are device functions over a virtual block index so that the single-layer kernels
+// (one launch per csmri_wgrad call) and the multi-layer finish kernel (one launch for all layers of a backward pass,
+// csmri_wgrad_finish_multi) run exactly the same arithmetic per output element.
+__device__ __forceinline__ void wgrad_scatter_body(float (*red)[33], long long vb, long long nvb, const float* slab,
+                                                   int splitk, int Cout, int NK, int Cin, int KH, int KW,
+                                                   int Cout_real, int Cin_real, float* dw, int accumulate) {
   // 32 consecutive slab elements x 8 split groups per workgroup: the reads of a split coalesce
   // (128-byte runs), the 8 groups keep 8x more loads in flight and are combined in fixed order;
   // the scattered fp32 write into [Cout][Cin][KH][KW] is the small side
-  __shared__ float red[8][33];
   const int e = threadIdx.x & 31, zg = threadIdx.x >> 5;
   const long long total = (long long)Cout_real * NK;
   const size_t zs = (size_t)Cout * NK;
-  for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
+  for (long long base = vb * 32; base < total; base += nvb * 32) {
     const long long i = base + e;
     float s0 = 0.f, s1 = 0.f;
     if (i < total) {
@@ -214,16 +216,21 @@ __global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float* slab, i
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float* slab, int splitk, int Cout, int NK, int Cin,
+                                                            int KH, int KW, int Cout_real, int Cin_real, float* dw,
+                                                            int accumulate) {
+  __shared__ float red[8][33];
+  wgrad_scatter_body(red, blockIdx.x, gridDim.x, slab, splitk, Cout, NK, Cin, KH, KW, Cout_real, Cin_real, dw,
+                     accumulate);
+}
 
 // Split-K sum + layout change [co][tap][ci] -> [co][ci][tap] through an LDS transpose so that
 // both the slab reads (64 consecutive channels) and the gradient writes (64*taps consecutive
 // floats) are coalesced.  One block per (co, 64-channel chunk); the z (split) loop is spread
 // over 4 thread groups and combined in a fixed order.
-__global__ __launch_bounds__(256) void wgrad_scatter_t_kernel(const float* slab, int splitk, int Cout, int NK,
-                                                              int Cin, int taps, int Cin_real, float* dw,
-                                                              int accumulate) {
-  __shared__ float tile[16][65];
-  const int co = blockIdx.x, ci0 = blockIdx.y * 64;
+__device__ __forceinline__ void wgrad_scatter_t_body(float (*tile)[65], int co, int ci0, const float* slab, int splitk,
+                                                     int Cout, int NK, int Cin, int taps, int Cin_real, float* dw,
+                                                     int accumulate) {
   const size_t zs = (size_t)Cout * NK;
   for (int t0 = 0; t0 < taps; t0 += 16) {
     const int nt = min(16, taps - t0);
@@ -246,6 +253,12 @@ __global__ __launch_bounds__(256) void wgrad_scatter_t_kernel(const float* slab,
     }
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(256) void wgrad_scatter_t_kernel(const float* slab, int splitk, int Cout, int NK,
+                                                              int Cin, int taps, int Cin_real, float* dw,
+                                                              int accumulate) {
+  __shared__ float tile[16][65];
+  wgrad_scatter_t_body(tile, blockIdx.x, blockIdx.y * 64, slab, splitk, Cout, NK, Cin, taps, Cin_real, dw, accumulate);
 }
 
 // bias gradient: column sums of dY, two deterministic stages
@@ -276,11 +289,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int dt, const char*
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int rows, int C, int C_real,
-                                                           float* db, int accumulate) {
+__device__ __forceinline__ void colsum_final_body(double (*red)[32], int vb, const float* partial, int rows, int C,
+                                                  int C_real, float* db, int accumulate) {
   // 32 channels x 8 row lanes per block; lanes combined in fixed order
-  __shared__ double red[8][32];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = vb * 32 + cl;
   double s = 0;
   if (c < C_real)
     for (int r = rl; r < rows; r += 8) s += partial[(size_t)r * C + c];
@@ -290,6 +302,40 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial,
     for (int l = 1; l < 8; ++l) s += red[l][cl];
     db[c] = accumulate ? db[c] + (float)s : (float)s;
   }
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int rows, int C, int C_real,
+                                                           float* db, int accumulate) {
+  __shared__ double red[8][32];
+  colsum_final_body(red, blockIdx.x, partial, rows, C, C_real, db, accumulate);
+}
+
+// One launch for the slab reductions (+ in-kernel bias partials) of up to WFINISH_MAX weight-gradient calls whose
+// main kernels ran with defer_finish: blockIdx.y = layer, blockIdx.x strides over that layer's virtual blocks.
+#define WFINISH_MAX 24
+struct WFinishItem {
+  const float* slab; float* dw; float* db; const float* part;
+  int splitk, Cout, NK, Cin, KH, KW, Cout_real, Cin_real, accumulate, part_rows;
+};
+struct WFinishTable { WFinishItem it[WFINISH_MAX]; int first[WFINISH_MAX + 1]; };   // first[i]: first block of item i
+__global__ __launch_bounds__(256) void wgrad_finish_multi_kernel(const WFinishTable T, int n) {
+  __shared__ double smem[(16 * 65 * sizeof(float) + sizeof(double) - 1) / sizeof(double)];
+  int li = 0;
+  while (li + 1 < n && (int)blockIdx.x >= T.first[li + 1]) ++li;        // (uniform per block)
+  const WFinishItem& t = T.it[li];
+  const int vb0 = blockIdx.x - T.first[li], nvb = T.first[li + 1] - T.first[li];
+  if (t.splitk <= 8) {          // big layers: bandwidth-bound transposing copy (wgrad_scatter_t_kernel)
+    const int nchunk = (t.Cin_real + 63) / 64;
+    for (int vb = vb0; vb < t.Cout_real * nchunk; vb += nvb)
+      wgrad_scatter_t_body((float (*)[65])smem, vb % t.Cout_real, (vb / t.Cout_real) * 64, t.slab, t.splitk, t.Cout,
+                           t.NK, t.Cin, t.KH * t.KW, t.Cin_real, t.dw, t.accumulate);
+  } else {                      // few outputs, many splits (wgrad_scatter_kernel)
+    wgrad_scatter_body((float (*)[33])smem, vb0, nvb, t.slab, t.splitk, t.Cout, t.NK, t.Cin, t.KH, t.KW,
+                       t.Cout_real, t.Cin_real, t.dw, t.accumulate);
+  }
+  if (t.db)
+    for (int vb = vb0; vb < (t.Cout_real + 31) / 32; vb += nvb)
+      colsum_final_body((double (*)[32])smem, vb, t.part, t.part_rows, t.Cout, t.Cout_real, t.db, t.accumulate);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1132,6 +1178,21 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   }
 #undef WG
   if (rc != CSMRI_OK) return rc;
+  if (d->defer_finish) {
+    // the slab reduction (and the patch kernels' bias partials) are left to csmri_wgrad_finish_multi; the bias
+    // gradient of the other kernels is a column sum over dY, which may not outlive this call: done now
+    if (d->db && !patch) {
+      float* part = d->slab + (size_t)p.splitk * d->Cout * p.NK;
+      int rows = cdiv(p.M, 512); if (rows > DB_ROWS) rows = DB_ROWS; if (rows < 1) rows = 1;
+      hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows), dim3(256), 0, st, d->dtype, p.dy, p.dyps,
+                         (long long)p.M, d->Cout, part);
+      CSMRI_LAUNCH_CHECK();
+      hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout_real + 31) / 32), dim3(256), 0, st, part, rows,
+                         d->Cout, d->Cout_real, d->db, d->accumulate);
+      CSMRI_LAUNCH_CHECK();
+    }
+    return CSMRI_OK;
+  }
   if (p.splitk <= 8) {        // big layers: bandwidth-bound transposing copy
     hipLaunchKernelGGL(wgrad_scatter_t_kernel, dim3(d->Cout_real, (d->Cin_real + 63) / 64), dim3(256), 0, st,
                        d->slab, p.splitk, d->Cout, p.NK, d->Cin, d->KH * d->KW, d->Cin_real, d->dw,
@@ -1157,6 +1218,44 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
     CSMRI_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d->Cout_real + 31) / 32), dim3(256), 0, st, part, rows,
                        d->Cout, d->Cout_real, d->db, d->accumulate);
+    CSMRI_LAUNCH_CHECK();
+  }
+  return CSMRI_OK;
+}
+
+// The deferred part of up to n csmri_wgrad calls made with defer_finish = 1 (same descriptors, slabs still alive), as
+// ONE launch per WFINISH_MAX layers: the per-layer slab reductions are 5-20 us launches that otherwise sit one behind
+// each main kernel in the serial tail of a backward pass.  Same arithmetic per element as the single-layer kernels.
+// Two descriptors of one call must not share dw (their read-modify-writes would race): the caller finishes the
+// earlier one first.
+extern "C" int csmri_wgrad_finish_multi(const csmri_wgrad_desc* descs, int n, void* stream) {
+  CSMRI_CHECK_ARG(descs && n > 0);
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += WFINISH_MAX) {
+    const int m = n - i0 < WFINISH_MAX ? n - i0 : WFINISH_MAX;
+    WFinishTable T;
+    int total_blocks = 0;
+    for (int i = 0; i < m; ++i) {
+      const csmri_wgrad_desc* d = descs + i0 + i;
+      CSMRI_CHECK_ARG(d->dw && d->slab && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0);
+      for (int j = 0; j < i; ++j) CSMRI_CHECK_ARG(descs[i0 + j].dw != d->dw);
+      WFinishItem& t = T.it[i];
+      t.splitk = d->splitk > 0 ? d->splitk : 1;
+      t.Cout = d->Cout; t.NK = d->KH * d->KW * d->Cin; t.Cin = d->Cin; t.KH = d->KH; t.KW = d->KW;
+      t.Cout_real = d->Cout_real; t.Cin_real = d->Cin_real; t.accumulate = d->accumulate;
+      t.slab = d->slab; t.dw = d->dw;
+      const bool patch = wpatch_eligible(d);
+      t.db = patch ? d->db : nullptr;                  // (other kernels: bias gradient already written by csmri_wgrad)
+      t.part = d->slab + (size_t)t.splitk * d->Cout * t.NK; t.part_rows = t.splitk;
+      long long nb = t.splitk <= 8 ? (long long)t.Cout_real * ((t.Cin_real + 63) / 64)
+                                   : ((long long)t.Cout_real * t.NK + 31) / 32;
+      if (nb > 1024) nb = 1024;                        // the bodies stride over the rest
+      if (nb < 1) nb = 1;
+      T.first[i] = total_blocks;
+      total_blocks += (int)nb;
+    }
+    T.first[m] = total_blocks;
+    hipLaunchKernelGGL(wgrad_finish_multi_kernel, dim3(total_blocks), dim3(256), 0, st, T, m);
     CSMRI_LAUNCH_CHECK();
   }
   return CSMRI_OK;

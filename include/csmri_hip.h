@@ -207,9 +207,16 @@ typedef struct csmri_wgrad_desc {
   float* db;                 /* fp32 [Cout_real] accumulated into, or NULL */
   int splitk; float* slab;   /* [splitk][CoutPad][KH*KW*Cin] fp32 */
   int accumulate;            /* 0: overwrite dw/db, 1: add */
+  int defer_finish;          /* 1: leave the slab reduction into dw (and the patch kernels' bias partials) to
+                                csmri_wgrad_finish_multi; the slab must stay alive until then */
 } csmri_wgrad_desc;
 
 int csmri_wgrad(const csmri_wgrad_desc* d, void* stream);
+/* the deferred slab reductions of n csmri_wgrad calls (their descriptors, by value, in call order) in one launch per
+ * 24 layers: a backward pass (reference adversarial_runner.py:314-320 `loss.backward()`) ends with one reduction
+ * launch instead of one or two small launches behind every layer's weight-gradient kernel.  No two descriptors may
+ * share dw. */
+int csmri_wgrad_finish_multi(const csmri_wgrad_desc* descs, int n, void* stream);
 size_t csmri_wgrad_slab_bytes(const csmri_wgrad_desc* d);
 int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d);
 /* name of the kernel instance csmri_wgrad launches for d, as profilers print it (for reports/tests) */

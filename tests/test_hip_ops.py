@@ -229,6 +229,50 @@ def test_maxpool(hip, dtype):
   assert torch.equal(from_dev_nhwc(xd.grad, 16), xr.grad)
 
 
+def test_wgrad_finish_multi_equals_per_layer_reductions(hip, monkeypatch):
+  """csmri_wgrad_finish_multi (one launch for the slab reductions of every layer of a backward pass) against the
+  per-layer reductions inside csmri_wgrad: bit-identical weight and bias gradients -- patch kernels (bias partials in
+  the slab), row kernels (transposing reduction, bias by column sums), accumulation onto existing gradients, and a
+  layer used twice in one backward pass (the queue is flushed in between)."""
+  ops = hip.ops
+  specs = [(2, 32, 3, 128, 128), (32, 32, 3, 128, 128), (32, 2, 3, 128, 128), (64, 128, 4, 32, 32), (128, 256, 4, 16, 16)]
+
+  def run(mode):
+    monkeypatch.setattr(ops, 'WGRAD_FINISH_MULTI', mode)
+    gen = torch.Generator().manual_seed(33)
+    grads, log = [], []
+    layers, xs = [], []
+    for cin, cout, k, h, w in specs:
+      wt = torch.nn.Parameter((torch.randn(cout, cin, k, k, generator=gen) * 0.05).cuda())
+      bi = torch.nn.Parameter((torch.randn(cout, generator=gen) * 0.1).cuda())
+      wt.grad = torch.full_like(wt, 0.25)                      # accumulate onto something
+      bi.grad = torch.full_like(bi, -0.5)
+      pads = (1, 1, 1, 1) if k == 3 else (1, 2, 1, 2)
+      layers.append(ops.ConvLayer(wt, bi, 1, pads, 'zero', torch.bfloat16))
+      xs.append(to_dev_nhwc(torch.randn(8, cin, h, w, generator=gen), torch.bfloat16).requires_grad_(True))
+    ops.LAUNCH_LOG = log
+    try:
+      outs = [ops.ConvAct.apply(x, None, l.weight, l.bias, l, 0.2, None) for l, x in zip(layers, xs)]
+      outs.append(ops.ConvAct.apply(xs[1].detach() * 0.5, None, layers[1].weight, layers[1].bias, layers[1], 0.2, None))
+      total = sum((o.float() * o.float()).mean() for o in outs)
+      total.backward()
+      ops.join_wgrad_stream()
+      torch.cuda.synchronize()
+    finally:
+      ops.LAUNCH_LOG = None
+    for l in layers:
+      grads += [l.weight.grad.clone(), l.bias.grad.clone()]
+    return grads, [e[1] for e in log if e[0] == 'wgrad']
+  g0, k0 = run('0')
+  g1, k1 = run('1')
+  assert k0 == k1 and any('wpatch' in k for k in k0) and any('wgrad_glds' in k for k in k0), k0
+  for a, b in zip(g0, g1):
+    assert torch.equal(a, b)
+  g2, _ = run('auto')                               # 'auto' without a side stream = '1'
+  for a, b in zip(g0, g2):
+    assert torch.equal(a, b)
+
+
 def test_pack_group_repack_equals_single_layer_pack(hip):
   """csmri_pack_weight_multi (one launch for every layer of a network after an optimizer step; vectorised path for
   full 64-channel 4x4 tiles, generic path otherwise) against csmri_pack_weight layer by layer: bit-identical packed
