@@ -1350,7 +1350,7 @@ class Fft2d(torch.autograd.Function):
     return fft2(g.contiguous(), not ctx.inverse, True), None
 
 
-def dc_raw(x, k0, mask_u8, pad_dtype=None):
+def dc_raw(x, k0, mask_u8, pad_dtype=None, out_fp32=False):
   """x: interleaved complex fp32 [B,H,W,2] or channels 0,1 of a [B,H,W,8] fp32
   conv output; k0: dense [B,H,W,2]; mask uint8 [B,H,W].  Returns (out [B,H,W,2]
   fp32, channel-padded copy [B,H,W,8] of pad_dtype or None)."""
@@ -1362,7 +1362,11 @@ def dc_raw(x, k0, mask_u8, pad_dtype=None):
   out_pad = None
   if pad_dtype is not None:
     out_pad = torch.empty(b, h, w, 8, dtype=pad_dtype, device=x.device)
-  if x.dtype == torch.bfloat16:       # bf16 image storage (k0 stays fp32): the "bf16 cFFT" of config 5
+  if x.dtype == torch.bfloat16 and out_fp32:      # bf16 input (a padded gradient), fp32 arithmetic and result
+    out = torch.empty(b, h, w, 2, dtype=torch.float32, device=x.device)
+    lib.call('csmri_dc_in_bf16', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
+             ptr(out_pad), dt_of(out_pad) if out_pad is not None else 0, b, h, w, stream())
+  elif x.dtype == torch.bfloat16:     # bf16 image storage (k0 stays fp32): the "bf16 cFFT" of config 5
     lib.call('csmri_dc_bf16', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
              ptr(out_pad), dt_of(out_pad) if out_pad is not None else 0, b, h, w, stream())
   else:
@@ -1373,33 +1377,38 @@ def dc_raw(x, k0, mask_u8, pad_dtype=None):
 
 class DataConsistency(torch.autograd.Function):
   """out = orthoIFFT2((1-m) orthoFFT2(x) + k0); backward = adjoint (k0 := 0).
-  x may be the fp32 [B,H,W,8] output of a conv block (channels 0,1 are read in
-  place).  Returns out fp32 [B,H,W,2] and, if pad_dtype is given, the same result
-  as a channel-padded [B,H,W,8] tensor (the next conv block's input layout)."""
+  x: the dense complex fp32 [B,H,W,2] output of a conv block, or channels 0,1 of a [B,H,W,8] one (read in place).
+  Returns out fp32 [B,H,W,2] and, if pad_dtype is given, the same result as a channel-padded [B,H,W,8] tensor (the
+  next conv block's input layout).  BOTH outputs are differentiable views of the one result: the gradient of the
+  padded copy (what the next block's data-gradient kernel writes, bf16) goes through the adjoint as it is
+  (csmri_dc_in_bf16), without a conversion to the dense fp32 layout first."""
 
   @staticmethod
   def forward(ctx, x, k0, mask_u8, pad_dtype):
     out, out_pad = dc_raw(x, k0, mask_u8, pad_dtype)
     ctx.save_for_backward(mask_u8)
     ctx.cx, ctx.xdt = x.shape[3], x.dtype
-    # (without this autograd fills a zero gradient for the non-differentiable padded copy on every backward:
-    # a 67 MB fill per DC layer at batch 64)
-    ctx.set_materialize_grads(False)
+    ctx.set_materialize_grads(False)       # (no zero fills for whichever of the two outputs is unused)
     if out_pad is None:
       return out
-    ctx.mark_non_differentiable(out_pad)
     return out, out_pad
 
   @staticmethod
-  def backward(ctx, g, *unused):
-    if g is None:
+  def backward(ctx, g, gpad=None):
+    if g is None and gpad is None:
       return None, None, None, None
     mask_u8, = ctx.saved_tensors
+    if g is None and gpad.dtype == torch.bfloat16 and ctx.xdt == torch.float32 and is_nhwc(gpad):
+      gx, gp = dc_raw(gpad, None, mask_u8, ctx.xdt if ctx.cx == 8 else None, out_fp32=True)
+      return (gp if ctx.cx == 8 else gx), None, None, None
+    if gpad is not None:                   # both outputs used (or an unusual dtype): sum in the dense layout
+      gp2 = copy_channels(as_nhwc(gpad), 2, ctx.xdt)
+      g = gp2 if g is None else as_nhwc(g).to(ctx.xdt) + gp2
     g = as_nhwc(g)
     if g.dtype != ctx.xdt:
       g = copy_channels(g, 2, ctx.xdt)
-    gx, gpad = dc_raw(g, None, mask_u8, ctx.xdt if ctx.cx == 8 else None)
-    return (gpad if ctx.cx == 8 else gx), None, None, None
+    gx, gp = dc_raw(g, None, mask_u8, ctx.xdt if ctx.cx == 8 else None)
+    return (gp if ctx.cx == 8 else gx), None, None, None
 
 
 # ----------------------------------------------------------------------------

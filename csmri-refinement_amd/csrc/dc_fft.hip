@@ -190,7 +190,7 @@ template <int IO> __device__ __forceinline__ void stc(void* p, size_t complex_id
 // passes 1 and 3 (and the row halves of csmri_fft2): 1-D transforms along W, one per wave (two for W = 32).
 //   INV = false: src natural order with pixel stride src_ps floats -> dst natural order (dense)
 //   INV = true : src dense natural order -> dst dense natural order (+ optional channel-padded copy), x scale
-template <int LOGN, bool INV, int IO>
+template <int LOGN, bool INV, int IO, int IO_IN = IO>
 __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const void* __restrict__ src, int src_ps,
                                                              void* __restrict__ dst, void* out_pad, int out_pad_dt,
                                                              int rows, float scale) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const void* __restr
   const int kbase = C::R * rev_bits(l, C::LOGL);      // first of the lane's R consecutive frequencies
   if (!INV) {
 #pragma unroll
-    for (int q = 0; q < C::R; ++q) v[q] = ldc<IO>(src, (base + l + C::L * q) * (size_t)src_ps);
+    for (int q = 0; q < C::R; ++q) v[q] = ldc<IO_IN>(src, (base + l + C::L * q) * (size_t)src_ps);
     fft_dif<LOGN>(v, tw, lane);
     if (!live) return;
 #pragma unroll
@@ -323,20 +323,20 @@ static int log2_in_range(int n) {
   return -1;
 }
 
-template <int LOGN, bool INV, int IO>
+template <int LOGN, bool INV, int IO, int IO_IN = IO>
 static int launch_rows(const void* src, int src_ps, void* dst, void* out_pad, int out_pad_dt, int rows,
                        float scale, hipStream_t st) {
   constexpr int per_wg = (DC_THREADS / 64) * FftCfg<LOGN>::TPW;
-  hipLaunchKernelGGL((dc_rows_kernel<LOGN, INV, IO>), dim3(cdiv(rows, per_wg)), dim3(DC_THREADS), 0, st,
+  hipLaunchKernelGGL((dc_rows_kernel<LOGN, INV, IO, IO_IN>), dim3(cdiv(rows, per_wg)), dim3(DC_THREADS), 0, st,
                      src, src_ps, dst, out_pad, out_pad_dt, rows, scale);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
-template <int IO>
+template <int IO, int IO_IN = IO>
 static int rows_pass(int logw, bool inv, const void* src, int src_ps, void* dst, void* out_pad, int out_pad_dt,
                      int rows, float scale, hipStream_t st) {
 #define ROWS(LW) (inv ? launch_rows<LW, true, IO>(src, src_ps, dst, out_pad, out_pad_dt, rows, scale, st) \
-                      : launch_rows<LW, false, IO>(src, src_ps, dst, out_pad, out_pad_dt, rows, scale, st))
+                      : launch_rows<LW, false, IO, IO_IN>(src, src_ps, dst, out_pad, out_pad_dt, rows, scale, st))
   switch (logw) {
     case 5: return ROWS(5); case 6: return ROWS(6); case 7: return ROWS(7); case 8: return ROWS(8); case 9: return ROWS(9);
   }
@@ -373,7 +373,7 @@ extern "C" size_t csmri_dc_work_bytes(int B, int H, int W) {
   return 0;  // the three passes run in place on `out`
 }
 
-template <int IO>
+template <int IO, int IO_IN = IO>
 static int dc_passes(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, void* out, void* out_pad,
                      int out_pad_dtype, int B, int H, int W, hipStream_t st) {
   CSMRI_CHECK_ARG(x && mask && out && B > 0 && x_pix_stride >= 2 && x_pix_stride % 2 == 0);
@@ -381,7 +381,7 @@ static int dc_passes(const void* x, int x_pix_stride, const float* k0, const uin
   if (lh < 0 || lw < 0) return CSMRI_E_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)k0 | (uintptr_t)out_pad) & 15) return CSMRI_E_ALIGN;
   const float scale = 1.0f / sqrtf((float)H * (float)W);
-  int rc = rows_pass<IO>(lw, false, x, x_pix_stride, out, nullptr, 0, B * H, 1.0f, st);
+  int rc = rows_pass<IO, IO_IN>(lw, false, x, x_pix_stride, out, nullptr, 0, B * H, 1.0f, st);
   if (rc != CSMRI_OK) return rc;
   rc = cols_pass<0, IO>(lh, out, (const float2*)k0, mask, B, W, scale, nullptr, 0, st);
   if (rc != CSMRI_OK) return rc;
@@ -397,6 +397,15 @@ extern "C" int csmri_dc(const float* x, int x_pix_stride, const float* k0, const
 extern "C" int csmri_dc_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, void* out,
                              void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream) {
   return dc_passes<CSMRI_BF16>(x, x_pix_stride, k0, mask, out, out_pad, out_pad_dtype, B, H, W, (hipStream_t)stream);
+}
+
+// fp32 arithmetic and output, the input image read as bf16 (channels 0,1 of a bf16 tensor with pixel stride
+// x_pix_stride): the DC adjoint applied directly to the channel-padded bf16 gradient a convolution's
+// data-gradient kernel wrote, without a conversion pass in between
+extern "C" int csmri_dc_in_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, float* out,
+                                void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream) {
+  return dc_passes<CSMRI_F32, CSMRI_BF16>(x, x_pix_stride, k0, mask, out, out_pad, out_pad_dtype, B, H, W,
+                                           (hipStream_t)stream);
 }
 
 // The forward model that produces a training sample from a (complex) image, on the device:

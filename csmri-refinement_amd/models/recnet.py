@@ -125,8 +125,7 @@ class RecNet(nn.Module):
         want_pad = self.dtype if idx < nb - 1 else None
         res = ops.DataConsistency.apply(y, k0, m8, want_pad)
         if want_pad is not None:
-          x_c, x_pad_next = res
-          x_pad = _PadAlias.apply(x_c, x_pad_next)
+          x_c, x_pad = res                 # both differentiable (ops.DataConsistency)
         else:
           x_c = res
         if self.return_intermediate_recs:
@@ -139,21 +138,6 @@ class RecNet(nn.Module):
     if self.return_intermediate_recs:
       return {'pred': out, 'reconstructions': recs}
     return out
-
-
-class _PadAlias(torch.autograd.Function):
-  """The DC kernel writes its result twice: fp32 complex and channel-padded in the
-  conv dtype.  This node ties the padded copy to the fp32 result for autograd:
-  grad(x_c) = first two channels of grad(padded)."""
-
-  @staticmethod
-  def forward(ctx, x_c, x_pad):
-    ctx.dt = x_c.dtype
-    return x_pad.view_as(x_pad)
-
-  @staticmethod
-  def backward(ctx, g):
-    return ops.copy_channels(g, 2, ctx.dt), None
 
 
 class _CastPad(torch.autograd.Function):

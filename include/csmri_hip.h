@@ -278,6 +278,11 @@ int csmri_fft2(const float* x, float* out, int B, int H, int W, int inverse, int
 int csmri_fft2_bf16(const void* x, void* out, int B, int H, int W, int inverse, int ortho, void* stream);
 int csmri_dc_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, void* out,
                   void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream);
+/* csmri_dc (fp32 arithmetic, intermediate and output) with the input image read as bf16, x_pix_stride in bf16
+ * elements: the adjoint of DataConsistencyInKspace.perform (myfft.py:145-163 under autograd, k0 = NULL) applied
+ * straight to the channel-padded bf16 gradient of the next conv block's input. */
+int csmri_dc_in_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, float* out,
+                     void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream);
 
 /* layout converters (H2D boundary: batch dict tensors are NCHW fp32,
  * training/base_runner.py:29-41) */
