@@ -143,6 +143,24 @@ def test_image_pool_semantics():
     assert torch.equal(ra, rb), step
 
 
+def test_image_pool_query_into_preallocated_output():
+  """ImagePool.query(..., out=) (the runner hands the fake half of the [fake; real] discriminator batch): same
+  result and pool state as the plain query, written into the given tensor (host formulation here; the device
+  formulation is csmri_image_pool_exchange, tests/test_hip_ops.py)."""
+  import random
+  from utils.image_pool import ImagePool
+  random.seed(11)
+  a, b = ImagePool(3), ImagePool(3)
+  for step in range(5):
+    x = torch.arange(2 * 4, dtype=torch.float32).reshape(2, 1, 2, 2) + 10 * step
+    dec = a.decide(2)
+    buf = torch.full((4, 1, 2, 2), -1.0)
+    ra = a.query(x, dec, out=buf[:2])
+    rb = b.query(x, list(dec))
+    assert ra.data_ptr() == buf.data_ptr() and torch.equal(buf[:2], rb) and float(buf[2:].max()) == -1.0
+    assert torch.equal(a.buffer, b.buffer) and a.count == b.count
+
+
 def test_lr_schedulers_match_torch_closed_forms():
   """training/lr_schedulers.py (FlatAdam has no torch optimizer to hand to torch's schedulers) against
   torch.optim.lr_scheduler.MultiStepLR / LambdaLR driven the way the reference drives them

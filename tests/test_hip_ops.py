@@ -273,6 +273,29 @@ def test_wgrad_finish_multi_equals_per_layer_reductions(hip, monkeypatch):
     assert torch.equal(a, b)
 
 
+def test_flat_adam_lazy_zero_only_skips_kernel_written_gradients(hip):
+  """FlatAdam.lazy_zero: zero_grad() only MARKS the gradients the library's kernels write (they overwrite on their
+  first launch); a parameter whose gradient torch autograd accumulates (the refinement wrapper's scale) is still
+  zeroed, and a marked gradient nobody wrote is zeroed in apply() before the update."""
+  from training.optimizers import FlatAdam      # (the package directory is on sys.path: tests/conftest.py)
+  w = torch.nn.Parameter(torch.randn(8, 8, 3, 3).cuda())
+  s = torch.nn.Parameter(torch.ones(1).cuda())
+  opt = FlatAdam([w, s], lr=1e-3)
+  opt.lazy_zero = True
+  w.grad.fill_(3.0); s.grad.fill_(5.0)
+  opt.zero_grad()                              # nothing known about the writers yet: everything zeroed
+  assert float(w.grad.abs().max()) == 0.0 and float(s.grad.abs().max()) == 0.0
+  w._kernel_grad = True                        # (what ops.conv_wgrad sets on the weights it writes)
+  w.grad.fill_(3.0); s.grad.fill_(5.0)
+  opt.zero_grad()
+  assert getattr(w, '_grad_fresh', False) and float(w.grad.min()) == 3.0          # marked, not touched
+  assert float(s.grad.abs().max()) == 0.0 and not getattr(s, '_grad_fresh', False)
+  before = w.detach().clone()
+  opt.apply()                                  # no kernel wrote w.grad: it counts as zero, w must not move
+  torch.cuda.synchronize()
+  assert float(w.grad.abs().max()) == 0.0 and torch.equal(w.detach(), before)
+
+
 def test_pack_group_repack_equals_single_layer_pack(hip):
   """csmri_pack_weight_multi (one launch for every layer of a network after an optimizer step; vectorised path for
   full 64-channel 4x4 tiles, generic path otherwise) against csmri_pack_weight layer by layer: bit-identical packed
