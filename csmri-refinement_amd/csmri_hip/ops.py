@@ -706,15 +706,14 @@ def _issue_deferred_wgrad(d):
 
 
 def _ensure_flush_callback():
-  """Register _flush_deferred_wgrad to run when the current backward pass ends (once per pass).  False outside a
-  backward pass: nothing would flush, the caller must not hold anything back."""
-  if _WGRAD['callback']:
-    return True
+  """Register _flush_deferred_wgrad to run when the current backward pass ends.  False outside a backward pass:
+  nothing would flush, the caller must not hold anything back."""
+  # Registered on EVERY call (the callback is idempotent and costs a Python call): a "registered for this pass" flag
+  # would survive a backward pass that raised before its callbacks ran and silently disable the flush of the next one.
   try:
     torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_wgrad)
   except RuntimeError:
     return False
-  _WGRAD['callback'] = True
   return True
 
 
@@ -736,7 +735,6 @@ def _finish_wgrads():
 def _flush_deferred_wgrad():
   q = _WGRAD['deferred']
   _WGRAD['since'] = 0
-  _WGRAD['callback'] = False
   while q:
     _issue_deferred_wgrad(q.pop(0))
   _finish_wgrads()
@@ -749,8 +747,7 @@ WGRAD_DEFER = int(os.environ.get('CSMRI_WGRAD_DEFER', '2'))     # A/B knob: weig
 WGRAD_FINISH_MULTI = os.environ.get('CSMRI_WGRAD_FINISH_MULTI', 'auto')       # A/B knob: auto | 1 | 0
 WGRAD_FLUSH_EVERY = int(os.environ.get('CSMRI_WGRAD_FLUSH_EVERY', '0'))   # A/B knob: release the held-back launches every N layers
 WGRAD_STREAMS = int(os.environ.get('CSMRI_WGRAD_STREAMS', '1'))  # A/B knob: side streams the layers alternate between
-_WGRAD = {'stream': None, 'pending': [], 'deferred': [], 'extra': [], 'next': 0, 'since': 0, 'finish': [],
-          'callback': False}
+_WGRAD = {'stream': None, 'pending': [], 'deferred': [], 'extra': [], 'next': 0, 'since': 0, 'finish': []}
 
 
 def enable_wgrad_stream(on):
