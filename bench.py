@@ -15,8 +15,11 @@ N>1 is launched by the driver as torch.distributed.run with one rank per GPU (RC
   MSE loss on 64 slices/GPU of 256x256: 5 conv blocks + 5 data-consistency layers forward, their
   adjoints backward, Adam.
 
-SURVEY 8(d): the batch arrives from PINNED HOST memory; its H2D copy is issued on a copy stream and is
-inside the timed region (the copy of batch t+1 runs under step t).  Rank 0 prints ONE JSON line.
+The batches are resident in HBM when the timed region starts (8 distinct batches cycled); --host-input is the
+PCIe-inclusive A/B: pinned host batches whose H2D copy is issued on a copy stream inside the timed region (the
+copy of batch t+1 runs under step t; DESIGN.md section 6 holds that rate).  After the W warm-up steps the replay
+settles for --settle-s seconds (untimed), then EXACTLY K steps are timed.  Rank 0 prints ONE JSON line; on the
+default invocation (c3, bf16, one GPU) it also carries `other_configs`: short legs of C2 and C5.
 
 Extra legs (rank 0, outside the timed region):
   roofline      HIP-event brackets around every conv-library launch over instrumented eager steps of the
@@ -63,11 +66,17 @@ def parse():
   p.add_argument('--no-overlap', action='store_true', help='keep the VGG branch on the main stream')
   p.add_argument('--cpu-all-threads', action='store_true',
                  help='also time the CPU baseline at os.cpu_count() threads (256 on the GPU box: ~3 min per step)')
-  p.add_argument('--device-resident', action='store_true',
-                 help='A/B: batches already in HBM (no H2D in the timed region)')
+  p.add_argument('--host-input', action='store_true',
+                 help='A/B: batches start in pinned host memory, H2D on a copy stream INSIDE the timed region '
+                      '(default: batches resident in HBM when the timed region starts, as the metric is defined)')
+  p.add_argument('--settle-s', type=float, default=0.6,
+                 help='untimed graph-replay settling after the W warm-up steps, seconds (0 = none)')
+  p.add_argument('--no-other-configs', action='store_true',
+                 help='skip the short C2 and C5 legs attached to the default (c3, bf16, N=1) line')
   a = p.parse_args()
   if a.batch <= 0:
     a.batch = DEFAULT_BATCH[a.config]
+  a.other_cpu_fast = False
   return a
 
 
@@ -223,13 +232,13 @@ def psnr_probe_c3(runner, host_batch, scale):
   return O.psnr_batch(pred, host_batch['target']), O.psnr_batch(want['pred'], host_batch['target'])
 
 
-def cpu_baseline_c2(runner, host_batch, sample_b=16, steps=3, all_threads=False):
+def cpu_baseline_c2(runner, host_batch, sample_b=16, steps=3, all_threads=False, fast=False):
   sys.path.insert(0, os.path.join(ROOT, 'oracle'))
   import torch
   import csmri_oracle as O
   out, psnr = {}, None
   batch = {k: v[:sample_b].clone() for k, v in host_batch.items()}
-  for threads in _thread_counts(all_threads):
+  for threads in ([min(32, os.cpu_count() or 1)] if fast else _thread_counts(all_threads)):
     torch.set_num_threads(threads)
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in runner.model.state_dict().items()}
     opt = O.make_adam(P.values(), 2e-4, 0.9, 0.999)
@@ -318,29 +327,25 @@ def roofline(runner, loader_factory, dtype, steps=2, config='c3'):
   return rl, table, conv_ms, hbm
 
 
-def main():
-  args = parse()
+def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=True, want_cpu=True, min_timed_s=0.0):
+  """One measured leg: build the runner of `config`, W warm-up steps, settle, EXACTLY `steps` timed steps between
+  barrier + synchronize pairs, then (outside the timed region) the roofline brackets and the CPU-oracle legs.
+  Returns the JSON line's dict on rank 0 (None elsewhere)."""
   import torch
-  from training import distributed as dist_utils
-  ws = dist_utils.init_from_env()
-  rank = dist_utils.rank()
-  local = int(os.environ.get('LOCAL_RANK', '0'))
-  torch.cuda.set_device(local if torch.cuda.device_count() > local else 0)
-  assert ws == max(1, args.gpus) or ws == 1, (ws, args.gpus)
-
   from data.synthetic import synth_batch, synth_batch_radial
-  runner, conf = build_runner(args.config, args.dtype, args.batch)
-  size = 512 if args.config == 'c5' else SIZE
-  if args.config == 'c5':
-    host_batches = [synth_batch_radial(args.batch, size, size, spokes=C5_SPOKES, seed=conf.seed + 97 * rank + 100000 * i)
+  runner, conf = build_runner(config, dtype, batch)
+  size = 512 if config == 'c5' else SIZE
+  if config == 'c5':
+    host_batches = [synth_batch_radial(batch, size, size, spokes=C5_SPOKES, seed=conf.seed + 97 * rank + 100000 * i)
                     for i in range(N_HOST_BATCHES)]
   else:
-    host_batches = [synth_batch(args.batch, size, size, acc=4, seed=conf.seed + 97 * rank + 100000 * i)
+    host_batches = [synth_batch(batch, size, size, acc=4, seed=conf.seed + 97 * rank + 100000 * i)
                     for i in range(N_HOST_BATCHES)]
   dev = torch.device('cuda', torch.cuda.current_device())
+  resident = not args.host_input
 
   def loader_factory(n):
-    return PinnedHostLoader(host_batches, n, dev, resident=args.device_resident)
+    return PinnedHostLoader(host_batches, n, dev, resident=resident)
 
   def request(loader, volatile=False):      # batches come off the loader as this rank's shard, on the device
     try:
@@ -350,34 +355,49 @@ def main():
       return None
   runner._request_data = request
 
-  gan = args.config in ('c3', 'c5')
+  gan = config in ('c3', 'c5')
+  no_graphs = args.no_graphs
   if gan:
     runner.overlap_streams = not args.no_overlap
     runner.prefetch_pretrained = not (args.no_prefetch or args.no_overlap)
-    if not args.no_graphs:
-      # capture the step once (3 eager steps inside); the timed region replays hipGraphs
-      try:
-        runner.enable_graphs({k: v.to(dev) for k, v in host_batches[0].items()})
-      except Exception as e:            # keep the measurement alive: eager launches, same kernels
-        sys.stderr.write('bench: hipGraph capture failed (%r); running eager\n' % (e,))
-        runner.disable_graphs()
-        args.no_graphs = True
-  elif not args.no_graphs and ws == 1:
+  if not no_graphs and (gan or ws == 1):
+    # capture the step once (eager warm-up steps inside); the timed region replays hipGraphs
     try:
       runner.enable_graphs({k: v.to(dev) for k, v in host_batches[0].items()})
-    except Exception as e:
+    except Exception as e:            # keep the measurement alive: eager launches, same kernels
       sys.stderr.write('bench: hipGraph capture failed (%r); running eager\n' % (e,))
       runner.disable_graphs()
-      args.no_graphs = True
+      no_graphs = True
   else:
-    args.no_graphs = True
-  if args.warmup > 0:
-    runner.train_epoch(loader_factory(args.warmup), 1, steps_per_train_summary=10 ** 9)
+    no_graphs = True
+  if warmup > 0:
+    runner.train_epoch(loader_factory(warmup), 1, steps_per_train_summary=10 ** 9)
   torch.cuda.synchronize()
+  # Settling (untimed, after the W warm-up steps): the first replays after a capture run below the steady rate
+  # (clock ramp, allocator and pack caches), which a 20-step timed region reads as -7 %.  Replay until SETTLE_S of
+  # wall time has passed, in chunks, so every rank runs the same number of steps.
+  settle_steps = 0
+  if args.settle_s > 0:
+    t_s = time.perf_counter()
+    est = None
+    while True:
+      n_chunk = 10 if est is None else max(1, min(200, int((args.settle_s - (time.perf_counter() - t_s)) / est)))
+      t_c = time.perf_counter()
+      runner.train_epoch(loader_factory(n_chunk), 1, steps_per_train_summary=10 ** 9)
+      torch.cuda.synchronize()
+      settle_steps += n_chunk
+      est = max(1e-4, (time.perf_counter() - t_c) / n_chunk)
+      done = torch.tensor([1.0 if time.perf_counter() - t_s >= args.settle_s else 0.0], device=dev)
+      if ws > 1:
+        torch.distributed.all_reduce(done, op=torch.distributed.ReduceOp.MIN)     # all ranks leave together
+      if float(done.item()) > 0:
+        break
+  if min_timed_s > 0 and settle_steps > 0:
+    steps = max(steps, int(min_timed_s / est) + 1)
   if ws > 1:
     torch.distributed.barrier()
   torch.cuda.synchronize()
-  timed_loader = loader_factory(args.steps)          # buffers and streams exist before the clock starts
+  timed_loader = loader_factory(steps)          # buffers and streams exist before the clock starts
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   losses, metrics = runner.train_epoch(timed_loader, 1, steps_per_train_summary=10 ** 9)
@@ -394,43 +414,45 @@ def main():
   # the instrumented roofline pass trains too (its steps all-reduce): every rank takes part
   prefetch_on = bool(getattr(runner, 'prefetch_pretrained', False))
   rl_out = None
-  if not args.no_roofline:
-    rl_out = roofline(runner, loader_factory, args.dtype, config=args.config)
+  if want_roofline:
+    rl_out = roofline(runner, loader_factory, dtype, config=config)
   if ws > 1:
     torch.distributed.barrier()
   if rank != 0:
-    return
-  slices = ws * args.batch * args.steps
+    return None
+  slices = ws * batch * steps
   value = slices / dt
-  gf = C5_GFLOP_PER_SLICE if args.config == 'c5' else (GAN_GFLOP_PER_SLICE if gan else C2_GFLOP_PER_SLICE)
+  gf = C5_GFLOP_PER_SLICE if config == 'c5' else (GAN_GFLOP_PER_SLICE if gan else C2_GFLOP_PER_SLICE)
   if gan:
     workload = ('C3/C4 2-refinement GAN step: frozen RecNet(3,3,32)+3 DC, UNET, CNNDiscriminator, '
-                'VGG19 loss, Adam x2; 256x256, 4x Cartesian, %d slices/GPU' % args.batch)
+                'VGG19 loss, Adam x2; 256x256, 4x Cartesian, %d slices/GPU' % batch)
     metric = 'train slices/sec, 256x256 GAN refinement step'
-    if args.config == 'c5':
+    if config == 'c5':
       workload = ('C5 data format: the 2-refinement GAN step at 512x512, golden-angle radial undersampling '
-                  '(%d spokes), %d slices/GPU, bf16 convolutions + fp32 FFT (the fp8 variant is not built)'
-                  % (C5_SPOKES, args.batch))
+                  '(%d spokes), %d slices/GPU, %s' % (C5_SPOKES, batch,
+                  'fp8 forward products where eligible + bf16-storage FFT' if dtype == 'fp8' else
+                  'bf16 convolutions + fp32 FFT'))
       metric = 'train slices/sec, 512x512 radial GAN refinement step'
-    mode = 'eager' if args.no_graphs else ('hipGraph replay (one graph per step)' if ws == 1 else
-                                           'hipGraph replay (4 segments, collectives eager)')
+    mode = 'eager' if no_graphs else ('hipGraph replay (one graph per step)' if ws == 1 else
+                                      'hipGraph replay (4 segments, collectives eager between them)')
   else:
     workload = ('C2 RecNet(5 blocks,3 convs,32 filters)+5 DC MSE training step incl. DC adjoints, Adam; '
-                '256x256, 4x Cartesian, %d slices/GPU' % args.batch)
+                '256x256, 4x Cartesian, %d slices/GPU' % batch)
     metric = 'train slices/sec, 256x256 RecNet (5-cascade DC-CNN) MSE step'
-    mode = 'eager' if args.no_graphs else 'hipGraph replay (one graph per step)'
+    mode = 'eager' if no_graphs else 'hipGraph replay (one graph per step)'
   line = {
       'metric': metric, 'value': round(value, 2), 'unit': 'slices/s',
-      'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup,
-      'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-      'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-      'input': 'HBM-resident batches (A/B mode)' if args.device_resident else
+      'n_gpus': ws, 'steps': steps, 'warmup': warmup,
+      'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+      'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+      'input': 'batches resident in HBM when the timed region starts (%d distinct batches cycled)' % N_HOST_BATCHES
+               if resident else
                'pinned host batches, H2D on a copy stream inside the timed region (%d distinct batches cycled)'
                % N_HOST_BATCHES,
-      'timed_region_s': round(dt, 3),
+      'timed_region_s': round(dt, 3), 'settle_steps': settle_steps,
       'prefetch': 'frozen RecNet forward of batch t+1 on a side stream during step t' if prefetch_on else None,
       'launch_mode': mode,
-      'config': {'workload': workload, 'per_gpu_batch': args.batch, 'global_batch': ws * args.batch,
+      'config': {'workload': workload, 'per_gpu_batch': batch, 'global_batch': ws * batch,
                  'parallelism': 'dp%d' % ws, 'image': [size, size]},
       'algorithmic_tflops': round(value * gf / 1e3, 2),
       'final_losses': {k: round(v.value, 5) for k, v in losses.items()},
@@ -444,22 +466,26 @@ def main():
     line['roofline_hbm'] = hbm
     line['conv_kernels'] = table
     line['conv_ms_per_step'] = round(conv_ms, 3)
-  if ws == 1 and not args.no_cpu_baseline:
+  if ws == 1 and want_cpu:
     # fresh runner with the same seed = same initial weights as the HIP run started from
-    ref_runner, _ = build_runner(args.config, args.dtype, args.batch)
+    ref_runner, _ = build_runner(config, dtype, batch)
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     if gan:
-      line['cpu_baseline'] = cpu_baseline_c3(ref_runner, host_batches[0], all_threads=args.cpu_all_threads)
+      if config == 'c3' or not args.other_cpu_fast:
+        line['cpu_baseline'] = cpu_baseline_c3(ref_runner, host_batches[0], all_threads=args.cpu_all_threads)
       # the 0.01 dB criterion where the U-Net contributes (scale preset; the reference starts at scale = 0
       # where pred == pretrained, reported beside it)
-      for tag, sc in (('', 0.02), ('_scale0p25', 0.25), ('_scale0', 0.0)):
+      probes = (('', 0.02), ('_scale0p25', 0.25), ('_scale0', 0.0)) if config == 'c3' else (('', 0.02),)
+      for tag, sc in probes:
         ph, pc = psnr_probe_c3(ref_runner, host_batches[0], sc)
         line['psnr_hip_db' + tag], line['psnr_cpu_db' + tag] = round(ph, 5), round(pc, 5)
         line['psnr_delta_db' + tag] = round(abs(ph - pc), 5)
       line['psnr_probe'] = ('generator forward (train-mode BatchNorm) on batch 0, initial weights, RefinementWrapper.scale '
                             'preset to 0.02 (headline psnr_delta_db), 0.25 and 0 (the reference\'s initial value)')
     else:
-      base, psnr_cpu = cpu_baseline_c2(ref_runner, host_batches[0], all_threads=args.cpu_all_threads)
+      fast = args.other_cpu_fast and config != args.config
+      base, psnr_cpu = cpu_baseline_c2(ref_runner, host_batches[0], all_threads=args.cpu_all_threads,
+                                       steps=1 if fast else 3, fast=fast)
       line['cpu_baseline'] = base
       with torch.no_grad():
         ref_runner.model.train()
@@ -468,7 +494,45 @@ def main():
         ph = O.psnr_batch(ref_runner.model(d0['inp'], d0['kspace'], d0['mask']).float().cpu(), host_batches[0]['target'][:16])
       line['psnr_hip_db'], line['psnr_cpu_db'] = round(ph, 5), round(psnr_cpu, 5)
       line['psnr_delta_db'] = round(abs(ph - psnr_cpu), 5)
-    line['gpu_over_cpu'] = round(value / line['cpu_baseline']['value'], 1)
+    if 'cpu_baseline' in line:
+      line['gpu_over_cpu'] = round(value / line['cpu_baseline']['value'], 1)
+    del ref_runner
+  del runner
+  import gc
+  gc.collect()
+  torch.cuda.empty_cache()
+  return line
+
+
+def main():
+  args = parse()
+  import torch
+  from training import distributed as dist_utils
+  ws = dist_utils.init_from_env()
+  rank = dist_utils.rank()
+  local = int(os.environ.get('LOCAL_RANK', '0'))
+  torch.cuda.set_device(local if torch.cuda.device_count() > local else 0)
+  assert ws == max(1, args.gpus) or ws == 1, (ws, args.gpus)
+  line = run_leg(args, args.config, args.dtype, args.batch, args.steps, args.warmup, ws, rank,
+                 want_roofline=not args.no_roofline, want_cpu=not args.no_cpu_baseline)
+  if rank != 0:
+    return
+  if ws == 1 and args.config == 'c3' and args.dtype == 'bf16' and not args.no_other_configs:
+    # BASELINE configs 2 and 5 in front of the driver: short legs of their own (warm-up, settling, >= 0.5 s timed),
+    # attached to the ONE JSON line.  Their CPU-oracle legs are cut to the PSNR probe (+ one timed step for C2).
+    args.other_cpu_fast = True
+    others = []
+    for cfg in ('c2', 'c5'):
+      try:
+        o = run_leg(args, cfg, 'bf16', DEFAULT_BATCH[cfg], 20, 5, 1, 0, want_roofline=not args.no_roofline,
+                    want_cpu=not args.no_cpu_baseline, min_timed_s=0.5)
+        keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'settle_steps', 'ms_per_step', 'dtype', 'config',
+                'algorithmic_tflops', 'launch_mode', 'input', 'roofline', 'roofline_hbm', 'psnr_delta_db',
+                'psnr_hip_db', 'psnr_cpu_db', 'cpu_baseline', 'final_losses')
+        others.append({k: o[k] for k in keep if k in o})
+      except Exception as e:                      # the headline must survive a failing side leg
+        others.append({'config': {'workload': cfg}, 'error': repr(e)})
+    line['other_configs'] = others
   print(json.dumps(line))
 
 

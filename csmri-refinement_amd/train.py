@@ -52,6 +52,7 @@ def main(argv=None):
   import utils
   from utils.config import Configuration
   from utils.checkpoints import restore_checkpoint, save_checkpoint
+  from utils.checkpoint_paths import get_periodic_checkpoint_path
   from models.utils import set_default_compute_dtype
   from training import build_runner
   from training import distributed as dist_utils
@@ -92,7 +93,8 @@ def main(argv=None):
                    ', '.join('%s: %s' % kv for kv in metrics.items()))
       if args.run_dir:
         os.makedirs(args.run_dir, exist_ok=True)
-        save_checkpoint(os.path.join(args.run_dir, 'checkpoint_ep{}.pth'.format(epoch)), conf, runner, epoch)
+        # the stored epoch is the NEXT one to train (reference train.py:286-296 save_periodic_checkpoint(..., epoch + 1))
+        save_checkpoint(get_periodic_checkpoint_path(args.run_dir, epoch), conf, runner, epoch + 1)
   return 0
 
 

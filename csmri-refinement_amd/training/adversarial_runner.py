@@ -143,12 +143,14 @@ class AdversarialRunner(BaseRunner):
     if gen_optimizer is not None and hasattr(gen_optimizer, 'lazy_zero') and \
         os.environ.get('CSMRI_LAZY_ZERO_G', '1') == '1':                             # A/B knob
       gen_optimizer.lazy_zero = True       # (the wrapper's scale, an autograd-accumulated gradient, is still zeroed)
-    if dist_utils.world_size() > 1 and gen_optimizer is not None and disc_optimizer is not None:
-      # data parallelism: a sub-bucket of gradients leaves as soon as the backward has issued its last layer
+    self._grad_hook = None
+    if dist_utils.exchange_active() and gen_optimizer is not None and disc_optimizer is not None:
+      # data parallelism: a sub-bucket of gradients leaves as soon as the backward has issued its last layer.  The
+      # hook is installed around this runner's own steps only (_hooked), never process-wide
       def _ready(layer, opts=(disc_optimizer, gen_optimizer)):
         for o in opts:
           o.grad_ready(layer)
-      ops.GRAD_READY_HOOK = _ready
+      self._grad_hook = _ready
     self.train_gen_metric_fns = train_gen_metric_fns or {}
     self.train_disc_metric_fns = train_disc_metric_fns or {}
     self.val_metric_fns = val_metric_fns or {}
@@ -247,8 +249,12 @@ class AdversarialRunner(BaseRunner):
     """zero_grad; backward; all-reduce; Adam (reference :314-320)."""
     total = self._weighted_total(losses, weights)
     optimizer.zero_grad()
-    total.backward()
-    ops.join_wgrad_stream()
+    ops.GRAD_READY_HOOK = self._grad_hook
+    try:
+      total.backward()
+      ops.join_wgrad_stream()
+    finally:
+      ops.GRAD_READY_HOOK = None
     optimizer.start_allreduce()
     optimizer.step()
     return total.detach()
@@ -268,7 +274,7 @@ class AdversarialRunner(BaseRunner):
     batch = st['batch']
     if self.vgg_early is None:
       env = os.environ.get('CSMRI_VGG_EARLY')          # A/B knob
-      self.vgg_early = (env == '1') if env in ('0', '1') else dist_utils.world_size() == 1
+      self.vgg_early = (env == '1') if env in ('0', '1') else not dist_utils.exchange_active()
     gen_inp = self.train_model_input_fn(batch)
     st['gen_inp0'] = gen_inp[0]
     # Where the look-ahead (frozen RecNet of batch t+1) is ISSUED matters as much as what it overlaps with: a hipGraph
@@ -391,7 +397,7 @@ class AdversarialRunner(BaseRunner):
     if not st.get('_pf_pending'):
       return
     from training import distributed as dist_utils
-    last = int(os.environ.get('CSMRI_PF_JOIN', '4' if dist_utils.world_size() == 1 else '1'))   # A/B knob
+    last = 1 if dist_utils.exchange_active() else 4
     if seg >= last:
       torch.cuda.current_stream().wait_stream(self._pf_stream)
       st['_pf_pending'] = False
@@ -597,14 +603,18 @@ class AdversarialRunner(BaseRunner):
     st['vec'] = torch.stack(vec)
 
   def _run_segments_eager(self, st):
-    self._seg1(st)
-    self.disc_optimizer.start_allreduce()
-    self._seg2(st)
-    self.disc_optimizer.wait_allreduce()
-    self._seg3(st)
-    self.gen_optimizer.start_allreduce()
-    self.gen_optimizer.wait_allreduce()
-    self._seg4(st)
+    ops.GRAD_READY_HOOK = self._grad_hook        # (sub-buckets start from inside the backward passes)
+    try:
+      self._seg1(st)
+      self.disc_optimizer.start_allreduce()
+      self._seg2(st)
+      self.disc_optimizer.wait_allreduce()
+      self._seg3(st)
+      self.gen_optimizer.start_allreduce()
+      self.gen_optimizer.wait_allreduce()
+      self._seg4(st)
+    finally:
+      ops.GRAD_READY_HOOK = None
 
   def enable_graphs(self, example_batch, warmup=3):
     """Capture the four segments as hipGraphs (shared memory pool) for this batch shape.
@@ -646,7 +656,7 @@ class AdversarialRunner(BaseRunner):
     gc_was_enabled = gc.isenabled()
     gc.disable()
     from training import distributed as dist_utils
-    if dist_utils.world_size() == 1:
+    if not dist_utils.exchange_active():
       # no collectives between the segments on a single GPU: one graph, three launch gaps fewer
       def whole(st_):
         for seg in (self._seg1, self._seg2, self._seg3, self._seg4):
@@ -656,6 +666,7 @@ class AdversarialRunner(BaseRunner):
       segments = (self._seg1, self._seg2, self._seg3, self._seg4)
     prio = int(os.environ.get('CSMRI_PRIO_MAIN', '0'))
     cap_stream = ops.named_stream('capture', prio)
+    ops.GRAD_READY_HOOK = self._grad_hook        # same launch plan as the eager steps (the hook itself is a no-op while capturing)
     try:
       for seg in segments:
         g = torch.cuda.CUDAGraph()
@@ -669,6 +680,7 @@ class AdversarialRunner(BaseRunner):
         pool.external_plan = False
       raise
     finally:
+      ops.GRAD_READY_HOOK = None
       if gc_was_enabled:
         gc.enable()
     self._graph = {'graphs': graphs, 'static': static, 'static_next': static_next, 'static_pre': static_pre,

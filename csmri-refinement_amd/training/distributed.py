@@ -61,6 +61,19 @@ def _backend():
   return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
 
 
+# Tests (tests/test_distributed_gpu.py): run the complete exchange machinery -- comm stream, library pack / reduce /
+# unpack kernels, the two RCCL collectives, the four-segment graphed step -- on ONE rank of the real 'nccl' backend,
+# where every early-out below would otherwise skip it.  Set by the test (or CSMRI_FORCE_EXCHANGE=1), never by the product.
+FORCE_EXCHANGE = bool(os.environ.get('CSMRI_FORCE_EXCHANGE'))
+
+
+def exchange_active():
+  """True when gradient buckets have to be exchanged: more than one rank (or the single-rank test mode)."""
+  if world_size() > 1:
+    return True
+  return FORCE_EXCHANGE and dist.is_available() and dist.is_initialized()
+
+
 class GradBucket(object):
   """Gradient exchange of one model: its flat fp32 gradient buffer, cut into SUB-BUCKETS (contiguous element
   ranges, listed in the order the backward finishes them) that are exchanged independently so the first ones
@@ -68,16 +81,19 @@ class GradBucket(object):
 
   Transport per sub-bucket (``payload``):
     'bf16'  (default with more than one rank) reduce-scatter + all-gather written out over the DIRECT
-            collectives: cast the range to bf16, all_to_all the N chunks (every pair of GPUs talks over its own
-            xGMI link: all 7 links of an MI355X carry 1/8 of the bytes each, where a ring would push everything
-            over one link per direction), SUM THE N RECEIVED bf16 CHUNKS IN fp32 on the owning rank, round once,
-            all_gather the reduced chunks, widen back into the fp32 buffer.  Half the bytes of an fp32
-            all-reduce, and no rank-count-dependent chain of bf16 roundings: every element is
+            collectives: csmri_bucket_pack_bf16 (fp32 -> bf16, RNE) -> all_to_all of the N chunks (every pair of
+            GPUs talks over its own xGMI link: all 7 links of an MI355X carry 1/8 of the bytes each, where a ring
+            would push everything over one link per direction) -> csmri_bucket_reduce (the N received chunks summed
+            in fp32 on the owning rank, rounded once) -> all_gather of the reduced chunks ->
+            csmri_bucket_unpack_bf16 back into the fp32 buffer.  2 collectives + 3 library launches, half the bytes
+            of an fp32 all-reduce, and no rank-count-dependent chain of bf16 roundings: every element is
             bf16(sum_r bf16(g_r)) with the sum carried in fp32.
     'fp32'  dist.all_reduce on the range (exact sums; CSMRI_GRAD_PAYLOAD=fp32).
   All device work of an exchange runs on a communication stream behind an event recorded when start() is
   called; wait() only makes the caller's stream wait for the exchanges' end events (the host never blocks
-  on the nccl backend).  The 1/N of the mean is returned by wait() and folded into the fused Adam kernel."""
+  on the nccl backend).  The 1/N of the mean is returned by wait() and folded into the fused Adam kernel.
+  When nothing has been started early (graph mode: the collectives sit between the captured segments), start()
+  exchanges the whole buffer as ONE range: 2 collectives + 3 launches per model and step."""
 
   def __init__(self, flat_grad, splits=None, payload=None):
     self.flat = flat_grad
@@ -90,26 +106,26 @@ class GradBucket(object):
     self.payload = payload or os.environ.get('CSMRI_GRAD_PAYLOAD', 'bf16')
     assert self.payload in ('bf16', 'fp32')
     self._started = [False] * len(self.splits)
-    self._done = [None] * len(self.splits)        # end-of-exchange events (device tensors) / None
+    self._done = []                               # end-of-exchange events of the exchanges in flight
     self._stage = {}
     self._stream = None
+    self.exchanges = 0                            # exchanges issued so far (tests)
 
-  # -- one sub-bucket ----------------------------------------------------------------------------------
-  def _buffers(self, i, world):
-    a, b = self.splits[i]
+  # -- one range ---------------------------------------------------------------------------------------
+  def _buffers(self, a, b, world):
     per = ((b - a + world - 1) // world + 7) // 8 * 8
-    key = (i, world)
+    key = (a, b, world)
     if key not in self._stage:
       dev = self.flat.device
-      self._stage[key] = (torch.zeros(world * per, dtype=torch.bfloat16, device=dev),
+      self._stage[key] = (torch.empty(world * per, dtype=torch.bfloat16, device=dev),
                           torch.empty(world * per, dtype=torch.bfloat16, device=dev),
                           torch.empty(per, dtype=torch.bfloat16, device=dev))
     return (per,) + self._stage[key]
 
-  def _exchange(self, i):
+  def _exchange(self, a, b):
     world = world_size()
-    a, b = self.splits[i]
     view = self.flat[a:b]
+    self.exchanges += 1
     host_hop = _backend() == 'gloo' and view.is_cuda     # functional tests: several ranks on one GPU over gloo
     if self.payload == 'fp32':
       if host_hop:
@@ -119,58 +135,78 @@ class GradBucket(object):
       else:
         dist.all_reduce(view, op=dist.ReduceOp.SUM)
       return
-    per, send, recv, mine = self._buffers(i, world)
-    send[:b - a].copy_(view)                              # fp32 -> bf16 (RNE); the padded tail stays zero
+    per, send, recv, mine = self._buffers(a, b, world)
+    n = b - a
+    if view.is_cuda:
+      from csmri_hip import lib
+      st = torch.cuda.current_stream().cuda_stream
+      lib.call('csmri_bucket_pack_bf16', view.data_ptr(), n, send.data_ptr(), world * per, st)
+    else:                                                # CPU tensors (gloo unit tests of the arithmetic)
+      send[:n].copy_(view)
+      send[n:].zero_()
     if host_hop:
       s_h, r_h = send.cpu(), torch.empty(world * per, dtype=torch.bfloat16)
       dist.all_to_all_single(r_h, s_h)
       recv.copy_(r_h)
+    elif world == 1 and not view.is_cuda:
+      recv.copy_(send)
     else:
       dist.all_to_all_single(recv, send)
-    mine.copy_(recv.view(world, per).float().sum(0))      # the N contributions to my chunk, summed in fp32
+    if view.is_cuda:
+      lib.call('csmri_bucket_reduce', recv.data_ptr(), world, per, mine.data_ptr(), st)
+    else:
+      mine.copy_(recv.view(world, per).float().sum(0))   # the N contributions to my chunk, summed in fp32
     if host_hop:
       g_h = torch.empty(world * per, dtype=torch.bfloat16)
       dist.all_gather_into_tensor(g_h, mine.cpu())
       send.copy_(g_h)
     else:
       dist.all_gather_into_tensor(send, mine)
-    view.copy_(send[:b - a])                              # bf16 -> fp32
-    send[b - a:].zero_()
+    if view.is_cuda:
+      lib.call('csmri_bucket_unpack_bf16', send.data_ptr(), n, view.data_ptr(), st)
+    else:
+      view.copy_(send[:n])
+
+  def _issue(self, a, b):
+    if not self.flat.is_cuda:
+      self._exchange(a, b)
+      return
+    if self._stream is None:
+      self._stream = torch.cuda.Stream()
+    ready = torch.cuda.Event()
+    ready.record()
+    self._stream.wait_event(ready)
+    with torch.cuda.stream(self._stream):
+      self._exchange(a, b)
+      done = torch.cuda.Event()
+      done.record(self._stream)
+    self._done.append(done)
 
   def start(self, i=None):
     """Begin the exchange of sub-bucket i (all not yet started ones when None).  The gradients of the range
     must have been ISSUED on the calling stream (or on streams it has joined)."""
-    if world_size() <= 1:
+    if not exchange_active():
+      return
+    if i is None and not any(self._started):
+      self._started = [True] * len(self.splits)
+      self._issue(0, self.flat.numel())                 # nothing left early: one exchange for the whole buffer
       return
     todo = [j for j in range(len(self.splits)) if not self._started[j]] if i is None else [i]
     for j in todo:
       if self._started[j]:
         continue
       self._started[j] = True
-      if not self.flat.is_cuda:
-        self._exchange(j)
-        continue
-      if self._stream is None:
-        self._stream = torch.cuda.Stream()
-      ready = torch.cuda.Event()
-      ready.record()
-      self._stream.wait_event(ready)
-      with torch.cuda.stream(self._stream):
-        self._exchange(j)
-        done = torch.cuda.Event()
-        done.record(self._stream)
-      self._done[j] = done
+      self._issue(*self.splits[j])
 
   def wait(self):
     """Make the caller's stream wait for every started exchange; returns the factor the summed gradient
     must be scaled by (1/world)."""
-    if world_size() > 1:
+    if exchange_active():
       self.start()                                        # anything nobody started early
-      for j, ev in enumerate(self._done):
-        if ev is not None:
-          torch.cuda.current_stream().wait_event(ev)
-        self._done[j] = None
-        self._started[j] = False
+      for ev in self._done:
+        torch.cuda.current_stream().wait_event(ev)
+      self._done = []
+      self._started = [False] * len(self.splits)
     return 1.0 / world_size()
 
 

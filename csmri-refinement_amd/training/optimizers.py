@@ -94,8 +94,8 @@ class FlatAdam(object):
     j = self._first_param_of_split.get(id(layer.weight))
     if j is None or torch.cuda.is_current_stream_capturing():
       return
-    from training.distributed import world_size
-    if world_size() <= 1:
+    from training.distributed import exchange_active
+    if not exchange_active():
       return
     side = ops._WGRAD['stream']
     if side is not None:

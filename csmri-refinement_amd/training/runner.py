@@ -2,7 +2,6 @@
 
 _train_step: zero_grad -> forward -> criteria -> weighted sum -> backward (which runs
 the adjoint of every data-consistency layer) -> all-reduce -> fused Adam."""
-import os
 
 import torch
 
@@ -57,9 +56,9 @@ class Runner(BaseRunner):
     self.loss_weights = self._get_loss_weights(loss_weights or {}, self.criteria)
     self.optimizer = optimizer
     self.lr_scheduler = lr_scheduler
-    if optimizer is not None and dist_utils.world_size() > 1:
-      from csmri_hip import ops
-      ops.GRAD_READY_HOOK = optimizer.grad_ready
+    # data parallelism: a sub-bucket of gradients leaves as soon as the backward has issued its last layer.  The hook
+    # is installed for the duration of this runner's own backward only (_step_body), never process-wide
+    self._grad_hook = optimizer.grad_ready if optimizer is not None and dist_utils.exchange_active() else None
     self.train_metric_fns = train_metric_fns or {}
     self.val_metric_fns = val_metric_fns or {}
     self.train_model_input_fn = self._get_model_input_fn(model, train_input_batch_transform)
@@ -88,12 +87,29 @@ class Runner(BaseRunner):
     return 'Model:\n' + str(self.model)
 
   def epoch_beginning(self, epoch):               # reference training/runner.py:140-142
+    lr = self._lr()
     if is_pre_epoch_scheduler(self.lr_scheduler):
       self.lr_scheduler.step()
+    self._after_lr_change(lr)
 
   def epoch_finished(self, epoch):                # reference training/runner.py:144-146
+    lr = self._lr()
     if is_post_epoch_scheduler(self.lr_scheduler):
       self.lr_scheduler.step()
+    self._after_lr_change(lr)
+
+  def _lr(self):
+    return self.optimizer.param_groups[0]['lr'] if self.optimizer is not None else None
+
+  def _after_lr_change(self, old_lr):
+    """The learning rate is a launch argument of the fused Adam kernel, i.e. baked into the captured hipGraph:
+    capture again when a scheduler moved it (as AdversarialRunner._after_lr_change does).  No warm-up steps: the
+    re-capture must not train."""
+    G = getattr(self, '_graph', None)
+    if G is not None and self._lr() != old_lr:
+      example = {k: v.clone() for k, v in G['static'].items()}
+      self.disable_graphs()
+      self.enable_graphs(example, warmup=0)
 
   def predict(self, batch):
     return self.model(*self.train_model_input_fn(batch, use_batch_transform=False))
@@ -108,19 +124,24 @@ class Runner(BaseRunner):
       losses.append(criterion(out, batch))
     total = torch.sum(torch.stack(losses) * self.loss_weights)
     from csmri_hip import ops
-    # weight gradients on a side stream next to the data-gradient chain, as in the adversarial runner?  Measured on
-    # C2 (batch 64, every kernel fills the chip and is HBM-bound): 10.37 vs 8.5 ms -- co-running only adds contention.
-    # Off; CSMRI_RUNNER_WGRAD_STREAM=1 to try it on small batches.
-    ops.enable_wgrad_stream(total.is_cuda and os.environ.get('CSMRI_RUNNER_WGRAD_STREAM', '0') == '1')
-    total.backward()
-    ops.join_wgrad_stream()
+    # weight gradients stay on the main stream here (a side stream as in the adversarial runner measured 10.37 vs
+    # 8.5 ms on C2: at batch 64 every kernel fills the chip and is HBM-bound, co-running only adds contention)
+    ops.enable_wgrad_stream(False)
+    ops.GRAD_READY_HOOK = self._grad_hook
+    try:
+      total.backward()
+      ops.join_wgrad_stream()
+    finally:
+      ops.GRAD_READY_HOOK = None
     return names, [l.detach() for l in losses], total.detach(), out
 
   def enable_graphs(self, example_batch, warmup=2):
     """Capture the whole step (reference training/runner.py:154-178) as ONE hipGraph for this batch shape and
     replay it per step: the RecNet step is ~150 short launches and eager issue leaves the GPU idle between
-    them.  Single process only (with data parallelism the gradient exchange sits between backward and Adam)."""
-    assert dist_utils.world_size() == 1, 'graph mode of the standard runner is single-GPU'
+    them.  Single process only (with data parallelism the gradient exchange sits between backward and Adam).
+    ``warmup`` eager steps run first (allocator / pack caches); they are REAL optimizer updates on the example
+    batch -- pass warmup=0 (after at least one eager step elsewhere) when that matters."""
+    assert not dist_utils.exchange_active(), 'graph mode of the standard runner is single-GPU'
     static = {k: v.detach().clone() for k, v in example_batch.items()}
     self._set_train()
     from csmri_hip import ops as _ops

@@ -76,8 +76,9 @@ class ImagePool(object):
 
   # -- device side (fixed shape) -------------------------------------------------
   def apply_plan(self, x, out=None):
-    if x.is_cuda:
-      # one launch (csmri_image_pool_exchange) instead of three gathers, two selects and a scatter
+    if x.is_cuda and x.shape[0] <= 64 and (x[0].numel() * x.element_size()) % 16 == 0:
+      # one launch (csmri_image_pool_exchange: at most 64 images of a multiple of 16 bytes) instead of three
+      # gathers, two selects and a scatter; larger per-GPU batches take the index_select path below
       from csmri_hip import ops
       return ops.image_pool_exchange(x, self.buffer, self._idx, out)
     kind, pidx, xidx, wslot, wsrc = self._idx.unbind(0)

@@ -479,6 +479,21 @@ int csmri_adam_dev(float* p, const float* g, float* m, float* v, long long n, fl
 int csmri_image_pool_exchange(const void* x, void* pool, void* out, const long long* plan, int n,
                               long long bytes_per_image, void* stream);
 
+/* Gradient-bucket transport of the data-parallel step (replaces the gradient reduction of the reference's
+ * nn.DataParallel wrapper, utils/custom_data_parallel.py:26-35 and utils/__init__.py:59-68).  A sub-bucket
+ * g[0..n) of a model's flat fp32 gradient buffer travels as bf16 over two RCCL collectives issued by the host
+ * side (training/distributed.py GradBucket: all_to_all of the `world` chunks, all_gather of the reduced chunks):
+ *   csmri_bucket_pack_bf16    send[i] = bf16(g[i]) (RNE) for i < n, 0 for n <= i < n_padded (n_padded % 8 == 0,
+ *                             = world * per: rank r's chunk is send[r*per .. (r+1)*per))
+ *   csmri_bucket_reduce       mine[j] = bf16( sum_{r < world} float(recv[r*per + j]) ), the sum carried in fp32
+ *                             in rank order (per % 8 == 0): every element of the result is
+ *                             bf16(sum_r bf16(g_r)) whatever the rank count
+ *   csmri_bucket_unpack_bf16  g[i] = float(src[i]) for i < n
+ * All pointers 16-byte aligned device memory; launches are asynchronous on `stream`. */
+int csmri_bucket_pack_bf16(const float* g, long long n, void* send, long long n_padded, void* stream);
+int csmri_bucket_reduce(const void* recv, int world, long long per, void* mine, void* stream);
+int csmri_bucket_unpack_bf16(const void* src, long long n, float* g, void* stream);
+
 /* misc */
 int csmri_fill_f32(float* p, long long n, float v, void* stream);
 int csmri_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream);

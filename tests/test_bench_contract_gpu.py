@@ -1,4 +1,4 @@
-"""bench.py prints ONE JSON line with the contract's keys (short run, no CPU baseline leg)."""
+"""bench.py prints ONE JSON line with the contract's keys (short runs, no CPU-timing legs)."""
 import json
 import os
 import subprocess
@@ -10,23 +10,59 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
+KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+        'vs_baseline', 'dtype', 'data', 'config', 'roofline')
 
-def test_bench_json_line_schema():
-  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2',
-                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=ROOT)
-  assert out.returncode == 0, out.stderr[-2000:]
+
+def _one_line(out):
+  assert out.returncode == 0, out.stderr[-3000:]
   lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
   assert len(lines) == 1, out.stdout[-2000:]
-  d = json.loads(lines[0])
-  for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-            'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+  return json.loads(lines[0])
+
+
+def _check_headline(d, steps, warmup):
+  for k in KEYS:
     assert k in d, k
-  assert d['unit'] == 'slices/s' and d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 2
+  assert d['unit'] == 'slices/s' and d['n_gpus'] == 1 and d['steps'] == steps and d['warmup'] == warmup
   assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
   assert d['dtype'] == 'bf16' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
-  assert abs(d['value'] - 8 * 3 / (d['ms_per_step'] * 3e-3)) < 0.02 * d['value']
+  assert abs(d['value'] - 8 * steps / (d['ms_per_step'] * steps * 1e-3)) < 0.02 * d['value']
+  assert 'resident in HBM' in d['input']
   rl = d['roofline']
   for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
     assert k in rl, k
   assert rl['bound'] == 'mfma' and rl['unit'] == 'TFLOP/s' and rl['peak'] == 2500.0
   assert abs(rl['frac'] - rl['achieved'] / rl['peak']) < 1e-3 and 0.0 < rl['frac'] < 1.0
+
+
+def test_bench_json_line_schema_with_other_configs():
+  """The default invocation: the C3 headline plus short C2 and C5 legs (`other_configs`)."""
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2',
+                        '--no-cpu-baseline', '--settle-s', '0.2'], capture_output=True, text=True, timeout=1200,
+                       cwd=ROOT)
+  d = _one_line(out)
+  _check_headline(d, 3, 2)
+  others = d['other_configs']
+  assert len(others) == 2 and not any('error' in o for o in others), others
+  c2, c5 = others
+  assert 'C2' in c2['config']['workload'] and 'C5' in c5['config']['workload']
+  for o in others:
+    for k in ('config', 'value', 'ms_per_step', 'dtype', 'roofline', 'roofline_hbm'):
+      assert k in o, k
+    assert o['dtype'] == 'bf16' and o['value'] > 0 and o['steps'] * o['ms_per_step'] >= 450.0    # >= 0.5 s timed (10 % slack)
+    b = o['config']['per_gpu_batch']
+    assert abs(o['value'] - b / (o['ms_per_step'] * 1e-3)) < 0.02 * o['value']
+
+
+def test_bench_under_torch_distributed_run_single_rank():
+  """How the driver launches N > 1, with one process: the same line comes out."""
+  port = 29400 + os.getpid() % 100
+  out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '2',
+                        '--no-cpu-baseline', '--no-other-configs', '--settle-s', '0.2'],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+  d = _one_line(out)
+  _check_headline(d, 3, 2)
+  assert d['config']['parallelism'] == 'dp1' and 'one graph per step' in d['launch_mode']

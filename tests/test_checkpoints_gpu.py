@@ -142,3 +142,41 @@ def test_resume_from_a_checkpoint_written_by_the_reference(tmp_path):
     # second Adam step: every parameter moved by ~lr; agreement to a small fraction of that
     assert float((dd > 2e-5 * max(1.0, float(v.abs().max()))).float().mean()) < 0.02, k
     assert float(dd.max()) < 4.1e-4 * max(1.0, float(v.abs().max())), (k, float(dd.max()))
+
+
+def test_train_cli_periodic_checkpoint_resumes_at_the_next_epoch(tmp_path):
+  """train.py stores the NEXT epoch in its periodic checkpoints, under the reference's file name
+  (reference train.py:286-296), so `--resume` continues AFTER the last finished epoch: two epochs, then a resumed run
+  whose first epoch is 3 and whose Adam step counter continues where the first run stopped."""
+  import glob
+  import logging
+  import train
+  from utils.checkpoints import restore_checkpoint
+  from training import build_runner
+  from utils.config import Configuration
+  conf = os.path.join(PKG, 'configs', '1-recnet.json')
+  run = str(tmp_path / 'run')
+  over = ['--conf', 'num_epochs=2', 'steps_per_epoch=2', 'image_size=64', 'batch_size=2', 'compute_dtype=fp32']
+  assert train.main(['-c', '0', '--run-dir', run] + over + [conf]) == 0
+  files = sorted(glob.glob(os.path.join(run, 'periodic-chkpt_*.pth')))
+  assert len(files) == 2 and files[0].endswith('_1.pth') and files[1].endswith('_2.pth'), files
+  ck = torch.load(files[1], map_location='cpu', weights_only=False)
+  assert ck['epoch'] == 3                                      # saved_epoch + 1
+  c = Configuration.from_json(conf)
+  c.update({'batch_size': '2'})
+  runner = build_runner(c, 'standard', '0', 'train')
+  state = restore_checkpoint(files[1], runner, '0')
+  assert state['start_epoch'] == 3 and runner.optimizer.step_count == 4
+  # the resumed CLI run trains epoch 3 only (num_epochs=3) and writes exactly one more checkpoint
+  records = []
+  h = logging.Handler()
+  h.emit = lambda rec: records.append(rec.getMessage())
+  logging.getLogger().addHandler(h)
+  try:
+    over3 = ['--conf', 'num_epochs=3', 'steps_per_epoch=2', 'image_size=64', 'batch_size=2', 'compute_dtype=fp32']
+    assert train.main(['-c', '0', '--run-dir', run, '--resume', files[1]] + over3 + [conf]) == 0
+  finally:
+    logging.getLogger().removeHandler(h)
+  epochs = [m.split(':')[0] for m in records if m.startswith('Epoch ')]
+  assert epochs == ['Epoch 3'], epochs
+  assert len(glob.glob(os.path.join(run, 'periodic-chkpt_*_3.pth'))) == 1

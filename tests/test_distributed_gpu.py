@@ -213,3 +213,196 @@ def test_two_ranks_match_the_data_parallel_oracle(payload):
       assert err < (2e-2 if payload == 'fp32' else 3e-2) and (gr.numel() == 1 or cos > 0.9995), (tag, k, err, cos)
   print('2-rank averaged gradients vs data-parallel oracle (%s payload): worst rel_l2 %.3e; D sub-buckets %s'
         % (payload, worst, got[0][3]))
+
+
+# ---------------------------------------------------------------------------------------------
+# The real RCCL backend ('nccl'), one rank: the exchange machinery end to end on device collectives
+# ---------------------------------------------------------------------------------------------
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [1, 2, 8])
+@pytest.mark.parametrize('n', [8, 1000, 4099, 1 << 20])
+def test_bucket_kernels_match_the_torch_arithmetic(world, n):
+  """csmri_bucket_pack_bf16 / _reduce / _unpack_bf16 against the torch expressions they replace
+  (cast, .float().sum(0) rounded once, widen): bit-exact, including ragged tails and the zeroed pad."""
+  from csmri_hip import lib
+  dev = torch.device('cuda', 0)
+  g = torch.Generator(device='cpu').manual_seed(n + world)
+  x = (torch.randn(n, generator=g) * 3).to(dev)
+  per = ((n + world - 1) // world + 7) // 8 * 8
+  send = torch.full((world * per,), 7.0, dtype=torch.bfloat16, device=dev)      # stale content must not survive
+  st = torch.cuda.current_stream().cuda_stream
+  lib.call('csmri_bucket_pack_bf16', x.data_ptr(), n, send.data_ptr(), world * per, st)
+  want = torch.zeros(world * per, dtype=torch.bfloat16, device=dev)
+  want[:n] = x.to(torch.bfloat16)
+  assert torch.equal(send.view(torch.int16), want.view(torch.int16))
+  recv = (torch.randn(world, per, generator=g) * 3).to(torch.bfloat16).to(dev)
+  mine = torch.empty(per, dtype=torch.bfloat16, device=dev)
+  lib.call('csmri_bucket_reduce', recv.data_ptr(), world, per, mine.data_ptr(), st)
+  acc = torch.zeros(per, dtype=torch.float32, device=dev)
+  for r in range(world):                                   # rank order, fp32
+    acc += recv[r].float()
+  assert torch.equal(mine.view(torch.int16), acc.to(torch.bfloat16).view(torch.int16))
+  out = torch.full((n + 3,), -1.0, device=dev)
+  lib.call('csmri_bucket_unpack_bf16', send.data_ptr(), n, out.data_ptr(), st)
+  assert torch.equal(out[:n], want[:n].float()) and bool((out[n:] == -1.0).all())
+  assert lib.raw('csmri_bucket_pack_bf16')(x.data_ptr() + 4, n, send.data_ptr(), world * per, None) == -2   # CSMRI_E_ALIGN
+
+
+class _NoHostSync(object):
+  """Inside the block every host-blocking torch call raises: the exchange must stay asynchronous."""
+
+  NAMES = [(torch.cuda, 'synchronize'), (torch.cuda.Stream, 'synchronize'), (torch.cuda.Event, 'synchronize'),
+           (torch.Tensor, 'cpu'), (torch.Tensor, 'item'), (torch.Tensor, 'tolist')]
+
+  def __enter__(self):
+    self.saved = [(o, n, getattr(o, n)) for o, n in self.NAMES]
+
+    def boom(*a, **k):
+      raise AssertionError('host-blocking call inside the gradient exchange')
+    for o, n, _ in self.saved:
+      setattr(o, n, boom)
+
+  def __exit__(self, *exc):
+    for o, n, f in self.saved:
+      setattr(o, n, f)
+    return False
+
+
+def _nccl_world1_worker(port, q):
+  sys.path.insert(0, PKG)
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                    HSA_ENABLE_IPC_MODE_LEGACY='0')
+  os.environ.pop('CSMRI_DIST_BACKEND', None)
+  import random
+  import torch.distributed as dist
+  torch.cuda.set_device(0)
+  dist.init_process_group(backend='nccl', init_method='env://', world_size=1, rank=0)
+  assert dist.get_backend() == 'nccl'
+  from training import distributed as D
+  res = {}
+  dev = torch.device('cuda', 0)
+  # -- 1. GradBucket alone: both payloads, sub-buckets and the merged range -------------------------------
+  assert not D.exchange_active()
+  D.FORCE_EXCHANGE = True
+  assert D.exchange_active() and D.world_size() == 1
+  gen = torch.Generator().manual_seed(3)
+  g0 = (torch.randn(300000 + 4, generator=gen) * 1e-2).to(dev)
+  for payload in ('bf16', 'fp32'):
+    for early in (False, True):
+      flat = g0.clone()
+      b = D.GradBucket(flat, splits=[(200000, 300004), (0, 200000)], payload=payload)
+      with _NoHostSync():
+        if early:
+          b.start(0)                         # a sub-bucket leaves from inside the backward
+        b.start()
+        scale = b.wait()
+      torch.cuda.synchronize()
+      want = g0.to(torch.bfloat16).float() if payload == 'bf16' else g0
+      assert scale == 1.0 and torch.equal(flat, want), (payload, early, float((flat - want).abs().max()))
+      assert b.exchanges == (2 if early else 1), (payload, early, b.exchanges)
+  res['bucket'] = 'ok'
+  # -- 2. the training step: dp1 vs forced exchange (eager, both payloads) and the 4-segment graphed step --
+  import csmri_hip  # noqa: F401
+  from utils.config import Configuration
+  from models.utils import set_default_compute_dtype
+  from training import build_runner
+  import utils
+  from data.synthetic import synth_batch
+  set_default_compute_dtype('bf16')
+
+  def make(payload):
+    os.environ['CSMRI_GRAD_PAYLOAD'] = payload
+    conf = Configuration.from_json(os.path.join(PKG, 'configs', '2-refinement.json'))
+    conf.batch_size = 2
+    conf.vgg_loss = {'seed': 19}
+    g, d = conf.generator_model, conf.discriminator_model
+    g['pretrained_model']['num_filters'] = 8
+    g['learnable_model']['encode_filters'] = [8, 16, 32]
+    g['learnable_model']['decode_filters'] = [16, 8]
+    d['num_filters_per_layer'] = [8, 16, 32, 64, 64, 64]
+    utils.set_random_seeds(conf.seed)
+    return build_runner(conf, 'adversarial', '0', 'train')
+
+  batch = {k: v.to(dev) for k, v in synth_batch(2, 128, 128, acc=4, seed=11).items()}
+
+  class Loader(list):
+    batch_size = 2
+
+  def run(runner, steps=2, graphs=False):
+    torch.manual_seed(7)
+    random.seed(7)
+    runner.overlap_streams = bool(graphs)
+    if graphs:
+      runner.enable_graphs(batch)
+    per_step = []
+    for _ in range(steps):
+      losses, _ = runner.train_epoch(Loader([batch]), 1)
+      per_step.append({k: float(v.value) for k, v in losses.items()})
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().float().reshape(-1) for net in (runner.disc, runner.gen)
+                      for p in net.parameters() if p.requires_grad]).cpu()
+    return per_step, flat
+
+  D.FORCE_EXCHANGE = False
+  la, pa = run(make('bf16'))                                 # dp1: no exchange at all
+  D.FORCE_EXCHANGE = True
+  r32 = make('fp32')
+  l32, p32 = run(r32)                                        # forced, exact payload: must be the dp1 run bit for bit
+  assert r32.disc_optimizer.bucket.exchanges >= 2 and r32.gen_optimizer.bucket.exchanges >= 2
+  assert l32 == la and torch.equal(p32, pa), 'fp32 exchange at world 1 changed the run'
+  r16 = make('bf16')
+  l16, p16 = run(r16)
+  assert l16[0] == la[0], (l16[0], la[0])                    # step 1's losses precede the first exchange
+  for k, v in la[1].items():
+    assert abs(l16[1][k] - v) <= 2e-2 * max(1.0, abs(v)), (k, l16[1][k], v)
+  assert not torch.equal(p16, pa) and float((p16 - pa).abs().max()) < 1e-3
+  res['eager'] = 'ok'
+  rg = make('bf16')
+  orig_start, orig_wait = D.GradBucket.start, D.GradBucket.wait
+
+  def guarded_start(self, i=None):
+    with _NoHostSync():
+      return orig_start(self, i)
+
+  def guarded_wait(self):
+    with _NoHostSync():
+      return orig_wait(self)
+  lg, pg = None, None
+  D.GradBucket.start, D.GradBucket.wait = guarded_start, guarded_wait
+  try:
+    lg, pg = run(rg, steps=3, graphs=True)
+  finally:
+    D.GradBucket.start, D.GradBucket.wait = orig_start, orig_wait
+  assert len(rg._graph['graphs']) == 4, len(rg._graph['graphs'])     # collectives sit BETWEEN captured segments
+  # 3 eager warm-up steps inside enable_graphs start D's two sub-buckets from the backward (2-3 exchanges each);
+  # every replayed step exchanges each model's buffer as ONE range
+  d_ex, g_ex = rg.disc_optimizer.bucket.exchanges, rg.gen_optimizer.bucket.exchanges
+  assert g_ex == 3 + 3 and 3 + 3 <= d_ex <= 3 * len(rg.disc_optimizer.bucket.splits) + 3, (d_ex, g_ex)
+  assert all(abs(v) < 1e4 and v == v for step in lg for v in step.values()) and torch.isfinite(pg).all()
+  assert float((pg - pa).abs().max()) < 5e-3
+  # every gradient the Adam kernels consumed went through the bf16 transport
+  fg = rg.disc_optimizer.flat_g
+  assert torch.equal(fg, fg.to(torch.bfloat16).float())
+  res['graphs'] = 'ok'
+  dist.barrier()
+  dist.destroy_process_group()
+  q.put(res)
+
+
+@pytest.mark.gpu
+def test_nccl_backend_forced_exchange_world1():
+  """the gradient exchange on the REAL device collectives.  One rank of the 'nccl' (= RCCL)
+  backend with training.distributed.FORCE_EXCHANGE: GradBucket (both payloads, early sub-buckets and the merged
+  range) returns bf16(g) / g bit for bit without a single host-blocking call between start() and wait(); the eager
+  step with the exact payload equals the dp1 run bit for bit; the graphed step becomes four hipGraph segments with
+  the collectives between them."""
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  p = ctx.Process(target=_nccl_world1_worker, args=(29700 + os.getpid() % 90, q))
+  p.start()
+  p.join(900)
+  assert p.exitcode == 0, p.exitcode
+  assert q.get(timeout=10) == {'bucket': 'ok', 'eager': 'ok', 'graphs': 'ok'}

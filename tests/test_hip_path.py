@@ -1187,3 +1187,43 @@ def test_recnet_runner_graph_replay_equals_eager(env):
   for (k, p), (_, q) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
     assert torch.equal(p, q), k
   assert a.optimizer.step_count == b.optimizer.step_count == 5
+
+
+def test_recnet_runner_graph_mode_follows_the_lr_scheduler(env):
+  """the learning rate is a launch argument of the captured Adam kernel, so the standard Runner
+  re-captures its hipGraph when a scheduler moves it (Runner._after_lr_change).  Graph mode + a multistep schedule
+  (decay at epochs 1 and 2, factor 0.1 -- large enough that a stale rate cannot hide) equals the eager run over
+  3 epochs bit for bit: losses, learning rates, parameters."""
+  Configuration, set_dtype = env
+  from training import build_runner
+  set_dtype('bf16')
+
+  def make():
+    conf = recnet_conf(Configuration, 2, 'bf16')
+    conf.optimizer.update(lr_scheduler='multistep', decay_steps=[1, 2], decay_factor=0.1, learning_rate=2e-3)
+    torch.manual_seed(5)
+    return build_runner(conf, 'standard', '0', 'train')
+  batches = [{k: v.cuda() for k, v in O.synth_batch(2, 64, 64, acc=4, seed=90 + i).items()} for i in range(2)]
+
+  def run(graphs):
+    r = make()
+    r._set_train()
+    r._step_body(batches[0])            # one eager step first in BOTH runs (the capture needs warm caches)
+    r.optimizer.step()
+    if graphs:
+      r.enable_graphs(batches[0], warmup=0)
+    out, lrs = [], []
+    for epoch in (1, 2, 3):
+      r.epoch_beginning(epoch)
+      lrs.append(r.optimizer.param_groups[0]['lr'])
+      losses, _ = r.train_epoch(Loader(batches), epoch)
+      r.epoch_finished(epoch)
+      out.append({k: v.value for k, v in losses.items()})
+    torch.cuda.synchronize()
+    return out, lrs, [p.detach().clone() for p in r.model.parameters()], r
+  (la, lra, pa, _), (lb, lrb, pb, rb) = run(False), run(True)
+  assert lra == lrb and abs(lra[0] - 2e-4) < 1e-12 and abs(lra[1] - 2e-5) < 1e-12 and abs(lra[2] - 2e-5) < 1e-12, lra
+  assert getattr(rb, '_graph', None) is not None
+  assert la == lb, (la, lb)
+  for p, q in zip(pa, pb):
+    assert torch.equal(p, q)
