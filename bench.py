@@ -387,7 +387,8 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
       torch.cuda.synchronize()
       settle_steps += n_chunk
       est = max(1e-4, (time.perf_counter() - t_c) / n_chunk)
-      done = torch.tensor([1.0 if time.perf_counter() - t_s >= args.settle_s else 0.0], device=dev)
+      # (at least two chunks: the first one holds the slow first replays and would spoil `est`)
+      done = torch.tensor([1.0 if time.perf_counter() - t_s >= args.settle_s and settle_steps > 10 else 0.0], device=dev)
       if ws > 1:
         torch.distributed.all_reduce(done, op=torch.distributed.ReduceOp.MIN)     # all ranks leave together
       if float(done.item()) > 0:

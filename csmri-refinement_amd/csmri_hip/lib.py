@@ -109,9 +109,6 @@ _SIGS = {
                                 C.POINTER(i64), C.POINTER(i32), vp]),
     'csmri_pack_weight_multi': (i32, [vp, i32, vp]),
     'csmri_absmax': (i32, [i32, vp, i64, vp, vp]),
-    'csmri_bn_small_eligible': (i32, [i32, i32, i32, i32, i32]),
-    'csmri_bn_small_fwd': (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, f32, f32, vp, vp, f32, vp, vp, vp, vp, i32, vp]),
-    'csmri_bn_small_bwd': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, vp]),
     'csmri_convblock_fused_supported': (i32, [vp]),
     'csmri_convblock_fused_fwd': (i32, [vp, vp]),
     'csmri_quantize_fp8': (i32, [i32, vp, vp, i64, vp, vp, vp]),

@@ -302,7 +302,6 @@ class PackGroup(object):
     return True
 
 
-WGRAD_FIRST = bool(os.environ.get('CSMRI_WGRAD_FIRST'))     # A/B knob: issue weight gradients before data gradients
 FOLD_WINDOW = True      # reflection dgrads: centre written in place + border-only halo fold
 PROFILE_SHAPES = False  # tools: append the problem shape to gconv labels
 PROFILE = None        # bench.py sets this to a list to collect per-launch HIP event timings
@@ -594,7 +593,7 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
     # end-of-backward callback) and nobody needs this gradient earlier (data parallelism starts a bucket per layer)
     fq = _WGRAD['finish']
     want = WGRAD_FINISH_MULTI == '1' or (WGRAD_FINISH_MULTI == 'auto' and _WGRAD['stream'] is None)
-    defer = want and PROFILE is None and GRAD_READY_HOOK is None and WGRAD_STREAMS <= 1 and _ensure_flush_callback()
+    defer = want and PROFILE is None and GRAD_READY_HOOK is None and _ensure_flush_callback()
     if defer and any(e[0].dw == d.dw for e in fq):
       _finish_wgrads()                     # a second weight gradient of the same layer: its accumulation comes after
     d.defer_finish = int(bool(defer))
@@ -632,20 +631,8 @@ def conv_wgrad(layer, x0, x1, gy, accumulate=True):
     _issue_deferred_wgrad((ev, launch, (x0, x1, gy), layer))
     return
   q.append((ev, launch, (x0, x1, gy), layer))
-  if WGRAD_FLUSH_EVERY > 0:
-    # Release point every few layers.  tools/graph_dep_probe.py: in a replayed hipGraph a side-stream node captured
-    # right behind its producer (the producer's FIRST successor) starts when the producer ends and the main chain
-    # continues on another queue after a short hop; captured any later it starts only when the producer's whole chain
-    # of first successors has ended.  So the held-back launches are released together, the first one made the first
-    # successor of the main stream's newest node: the main chain pays one hop per release instead of one per layer,
-    # and the weight gradients run next to the following layers instead of piling up behind the backward.
-    _WGRAD['since'] += 1
-    if _WGRAD['since'] >= WGRAD_FLUSH_EVERY:
-      _WGRAD['since'] = 0
-      _side_stream_of(layer).wait_stream(torch.cuda.current_stream())
-      while q:
-        _issue_deferred_wgrad(q.pop(0))
-    return
+  # (Releasing the held-back launches every N layers as the first successor of the chain's newest node, and two or
+  # three weight-gradient streams, were measured slower the more they overlapped with the chain: DESIGN 9.0.)
   while len(q) > WGRAD_DEFER:
     _issue_deferred_wgrad(q.pop(0))
 
@@ -675,20 +662,8 @@ def _mark_pending(side):
 
 
 def _side_stream_of(layer):
-  """The side stream of a layer's weight-gradient launches: fixed per layer (its accumulations stay ordered),
-  layers alternate between the WGRAD_STREAMS streams in order of first use (one layer's slab reduce then runs
-  under the next layer's main kernel)."""
-  k = getattr(layer, '_wgrad_stream', None)
-  if k is None:
-    k = layer._wgrad_stream = _WGRAD['next']
-    _WGRAD['next'] += 1
-  if WGRAD_STREAMS <= 1:
-    return _WGRAD['stream']
-  extra = _WGRAD['extra']
-  while len(extra) < WGRAD_STREAMS - 1:
-    extra.append(named_stream('wgrad%d' % (len(extra) + 1)))
-  k %= WGRAD_STREAMS
-  return _WGRAD['stream'] if k == 0 else extra[k - 1]
+  """The side stream of the weight-gradient launches: ONE for all layers, so a layer's accumulations stay ordered."""
+  return _WGRAD['stream']
 
 
 def _issue_deferred_wgrad(d):
@@ -734,20 +709,17 @@ def _finish_wgrads():
 
 def _flush_deferred_wgrad():
   q = _WGRAD['deferred']
-  _WGRAD['since'] = 0
   while q:
     _issue_deferred_wgrad(q.pop(0))
   _finish_wgrads()
 
 
-WGRAD_DEFER = int(os.environ.get('CSMRI_WGRAD_DEFER', '2'))     # A/B knob: weight-gradient launches held back (0 = none)
+WGRAD_DEFER = 2       # weight-gradient launches held back behind the data-gradient chain (0 = none); +7 % on C3
 # one slab-reduction launch per backward pass: 'auto' = when the weight gradients run on the main stream (RecNet MSE
 # step: 30 launches of 12-16 us in a strictly serial step, +9.5 %); with the side stream of the GAN step the per-layer
 # reductions read their slab while it is still in the Infinity Cache and the single launch measured 1 % slower
-WGRAD_FINISH_MULTI = os.environ.get('CSMRI_WGRAD_FINISH_MULTI', 'auto')       # A/B knob: auto | 1 | 0
-WGRAD_FLUSH_EVERY = int(os.environ.get('CSMRI_WGRAD_FLUSH_EVERY', '0'))   # A/B knob: release the held-back launches every N layers
-WGRAD_STREAMS = int(os.environ.get('CSMRI_WGRAD_STREAMS', '1'))  # A/B knob: side streams the layers alternate between
-_WGRAD = {'stream': None, 'pending': [], 'deferred': [], 'extra': [], 'next': 0, 'since': 0, 'finish': []}
+WGRAD_FINISH_MULTI = 'auto'       # auto | '1' | '0' (tests set it)
+_WGRAD = {'stream': None, 'pending': [], 'deferred': [], 'finish': []}
 
 
 def enable_wgrad_stream(on):
@@ -802,8 +774,6 @@ class ConvAct(torch.autograd.Function):
       gy = gy.to(layer.dtype)
     g = act_bwd(gy, y, ctx.act_slope) if ctx.act_slope != 1.0 else gy
     gx0 = gx1 = None                  # data gradient first, weight gradient second (see ConvBnAct._finish_backward)
-    if ctx.w_req and WGRAD_FIRST:
-      conv_wgrad(layer, x0, x1, g)
     if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
       gx = conv_dgrad(layer, g, ctx.in_hw)
       if x1 is None:
@@ -811,15 +781,14 @@ class ConvAct(torch.autograd.Function):
       else:
         gx0, gx1 = gx[..., :ctx.c0], gx[..., ctx.c0:]
     if ctx.w_req:
-      if not WGRAD_FIRST:
-        conv_wgrad(layer, x0, x1, g)
+      conv_wgrad(layer, x0, x1, g)
       if GRAD_READY_HOOK is not None and not _wgrad_deferred_mode():
         GRAD_READY_HOOK(layer)
     return gx0, gx1, None, None, None, None, None
 
 
-# RecNet conv blocks of the supported shape run as one launch (csmri_convblock_fused_fwd); env knob for A/B runs
-FUSED_CONVBLOCK = not os.environ.get('CSMRI_NO_FUSED_CONVBLOCK')
+# RecNet conv blocks of the supported shape run as one launch (csmri_convblock_fused_fwd); tests turn it off for A/B
+FUSED_CONVBLOCK = True
 
 
 def convblock_fused_forward(x, plan, out_dtype_last, need_acts, out_complex=False):
@@ -930,8 +899,6 @@ class ConvActStack(torch.autograd.Function):
       xin = saved[i]
       in_hw = (xin.shape[1], xin.shape[2])
       g_out = g                          # data gradient first, weight gradient second (see ConvBnAct._finish_backward)
-      if ctx.w_req[i] and WGRAD_FIRST:
-        conv_wgrad(layer, xin, None, g_out)
       if i > 0:
         prev_slope = plan[i - 1][1]
         g = conv_dgrad(layer, g_out, in_hw, g_src=xin if prev_slope != 1.0 else None, g_slope=prev_slope)
@@ -940,8 +907,7 @@ class ConvActStack(torch.autograd.Function):
       else:
         g = None
       if ctx.w_req[i]:
-        if not WGRAD_FIRST:
-          conv_wgrad(layer, xin, None, g_out)
+        conv_wgrad(layer, xin, None, g_out)
         if GRAD_READY_HOOK is not None and not _wgrad_deferred_mode():
           GRAD_READY_HOOK(layer)
     return (g, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
@@ -961,25 +927,9 @@ class BNState(object):
     self.eps, self.momentum = eps, momentum
 
 
-# one-launch BatchNorm forward / backward for small layers (csmri_bn_small_*): correct and tested, measured slower
-# on the step than the three-launch sequences, hence opt-in
-BN_SMALL = bool(os.environ.get('CSMRI_BN_SMALL'))
-
-
 def _bn_forward(y, stats, bn, c_real, slope, training, dropmask, groups=1):
   b, h, w, cp = y.shape
   dev = y.device
-  if BN_SMALL and training and stats is None and lib.raw('csmri_bn_small_eligible')(dt_of(y), b, h * w, cp, groups):
-    # small layer: statistics, running-statistics update and normalise + activation in one launch
-    mean = torch.empty(groups, cp, dtype=torch.float32, device=dev)
-    invstd = torch.empty(groups, cp, dtype=torch.float32, device=dev)
-    snap = torch.empty(2, cp, dtype=torch.float32, device=dev)
-    z = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
-    lib.call('csmri_bn_small_fwd', dt_of(y), y.data_ptr(), y.stride(2), z.data_ptr(), z.stride(2), b, h * w, cp,
-             c_real, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum, bn.running_mean.data_ptr(),
-             bn.running_var.data_ptr(), float(slope), ptr(dropmask), mean.data_ptr(), invstd.data_ptr(),
-             snap.data_ptr(), groups, stream())
-    return z, mean, invstd, snap
   if training:
     if stats is None:
       rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups, cp)
@@ -1061,13 +1011,6 @@ class ConvBnAct(torch.autograd.Function):
       acc_affine = 0
       bn.weight._grad_fresh = False
       bn.bias._grad_fresh = False
-    if BN_SMALL and lib.raw('csmri_bn_small_eligible')(dt_of(y), b, h * w, cp, groups):
-      lib.call('csmri_bn_small_bwd', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
-               gy.data_ptr(), gy.stride(2), b, h * w, cp, layer.cout, mean.data_ptr(), invstd.data_ptr(),
-               bn.weight.data_ptr(), float(ctx.slope), ptr(dropmask), snap.data_ptr(),
-               bn.weight.grad.data_ptr() if want_affine else 0, bn.bias.grad.data_ptr() if want_affine else 0,
-               acc_affine, groups, stream())
-      return ConvBnAct._finish_backward(ctx, gy, x0, x1, want_affine)
     rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups, cp)
     partial = torch.empty(rows + groups, 2, cp, dtype=torch.float32, device=dev)
     lib.call('csmri_bn_bwd_reduce', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
@@ -1089,8 +1032,6 @@ class ConvBnAct(torch.autograd.Function):
     # cross-queue hand-off (~10 us in the kernel trace): with the weight gradient issued first, every layer's
     # data gradient paid it (tools/trace_timeline.py).
     gx0 = gx1 = None
-    if want_affine and WGRAD_FIRST:
-      conv_wgrad(layer, x0, x1, gy)
     if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
       gx = conv_dgrad(layer, gy, ctx.in_hw)
       if x1 is None:
@@ -1098,8 +1039,7 @@ class ConvBnAct(torch.autograd.Function):
       else:
         gx0, gx1 = gx[..., :ctx.c0], gx[..., ctx.c0:]
     if want_affine:
-      if not WGRAD_FIRST:
-        conv_wgrad(layer, x0, x1, gy)
+      conv_wgrad(layer, x0, x1, gy)
       if GRAD_READY_HOOK is not None and not _wgrad_deferred_mode():
         GRAD_READY_HOOK(layer)
     return gx0, gx1, None, None, None, None, None, None, None, None, None
@@ -1133,9 +1073,6 @@ def maxpool2_bwd(gy, arg, shape, g_src=None, g_slope=1.0, g_add=None):
   lib.call('csmri_maxpool2_bwd', dt_of(gy), gy.data_ptr(), gy.stride(2), arg.data_ptr(),
            gx.data_ptr(), gx.stride(2), b, h, w, c, stream())
   return gx
-
-
-POOL_ACT_FUSED = os.environ.get('CSMRI_NO_POOL_ACT_FUSED') is None   # A/B knob
 
 
 class MaxPool2(torch.autograd.Function):
@@ -1258,7 +1195,7 @@ class FrozenConvStackPair(torch.autograd.Function):
           g = conv_dgrad(layer, gp, ctx.shapes[i])
       else:
         prev = plan[i - 1] if i > 0 else None
-        if POOL_ACT_FUSED and prev is not None and prev[0] == 'conv' and prev[2] != 1.0 and \
+        if prev is not None and prev[0] == 'conv' and prev[2] != 1.0 and \
             saved[i - 1].dtype == g.dtype:
           # the pool's producer is an activated conv: its derivative rides on the un-pooling pass
           g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i], g_src=saved[i - 1][:b], g_slope=prev[2])

@@ -341,210 +341,3 @@ extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, 
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
-
-// ---------------------------------------------------------------------------------------------------------------
-// Small layers (late discriminator: 512-1024 channels on 16 x 16 / 8 x 8 maps, 1-4 MB per tensor): the three
-// launches of the streaming path (statistics, finalize, normalise -- or reduce, finalize, apply) are each shorter
-// than the gap between two dependent launches.  Here ONE launch does all of it: a workgroup owns a slab of 16
-// channels and walks the pixels of every group twice (the second pass re-reads from L2); the running statistics
-// (forward) and the dgamma / dbeta sums (backward) are updated group after group inside that workgroup, i.e. in
-// the order separate calls would have used.  Reductions: per-thread fp32 partial sums over <= 128 pixels, then
-// double precision through the wave (shuffles) and across the four waves (fixed order): deterministic.
-// ---------------------------------------------------------------------------------------------------------------
-#define BNS_CS 16                                   // channels per workgroup (32 B of a bf16 pixel)
-__device__ __forceinline__ void bns_reduce8(double (&s)[8], double* red /* [4][4][8] */, int cv, int wave) {
-  // threads: cv = t & 3 (channel vector), pixel lane = t >> 2: sum over the 16 pixel lanes of a wave, then the waves
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-#pragma unroll
-    for (int o = 4; o < 64; o <<= 1) s[k] += __shfl_xor(s[k], o);
-  }
-  __syncthreads();                                  // (previous use of `red` is over)
-  if ((threadIdx.x & 63) < 4) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[(wave * 4 + cv) * 8 + k] = s[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 8; ++k) s[k] = red[(0 * 4 + cv) * 8 + k] + red[(1 * 4 + cv) * 8 + k] + red[(2 * 4 + cv) * 8 + k] + red[(3 * 4 + cv) * 8 + k];
-}
-
-template <int DT>
-__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const void* __restrict__ y, int yps, void* __restrict__ z, int zps,
-                                                           int Bg, int HW, int C, int C_real, int groups,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, float momentum, float* rmean, float* rvar,
-                                                           float slope, const float* __restrict__ drop,
-                                                           float* mean_out, float* invstd_out, float* snap) {
-  __shared__ double red[4 * 4 * 8];
-  const int cv = threadIdx.x & 3, pl = threadIdx.x >> 2, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * BNS_CS + cv * 4;
-  const int npix = Bg * HW;
-  float ga[4], be[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const bool ok = c + q < C_real;
-    ga[q] = ok ? gamma[c + q] : 0.f; be[q] = ok ? beta[c + q] : 0.f;
-    if (snap && pl == 0) { snap[c + q] = ga[q]; snap[C + c + q] = be[q]; }
-  }
-  for (int g = 0; g < groups; ++g) {
-    const long long pbase = (long long)g * npix;
-    f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f}, b = a;
-#pragma unroll 4
-    for (int p = pl; p < npix; p += 64) {
-      const f32x4_t v = ld4<DT>(y, (pbase + p) * yps + c);
-      a += v; b += v * v;
-    }
-    double s[8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { s[q] = a[q]; s[4 + q] = b[q]; }
-    bns_reduce8(s, red, cv, wave);
-    float mu[4], sc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double m = s[q] / npix;
-      double var = s[4 + q] / npix - m * m;
-      if (var < 0) var = 0;
-      const float is = (float)(1.0 / sqrt(var + (double)eps));
-      mu[q] = (float)m; sc[q] = c + q < C_real ? is * ga[q] : 0.f;
-      if (pl == 0) {
-        mean_out[g * C + c + q] = (float)m; invstd_out[g * C + c + q] = is;
-        if (rmean && c + q < C_real) {
-          const double unbiased = npix > 1 ? var * npix / (npix - 1) : var;
-          rmean[c + q] = (1.f - momentum) * rmean[c + q] + momentum * (float)m;
-          rvar[c + q] = (1.f - momentum) * rvar[c + q] + momentum * (float)unbiased;
-        }
-      }
-      if (!(c + q < C_real)) mu[q] = 0.f;
-    }
-#pragma unroll 4
-    for (int p = pl; p < npix; p += 64) {
-      const f32x4_t v = ld4<DT>(y, (pbase + p) * yps + c);
-      f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f}, o;
-      if (drop) dm = *(const f32x4_t*)(drop + (size_t)((pbase + p) / HW) * C + c);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float t = v[q] - mu[q];
-        t = t * sc[q] + be[q];
-        t = t < 0.f ? t * slope : t;
-        o[q] = t * dm[q];
-      }
-      st4<DT>(z, (pbase + p) * zps + c, o);
-    }
-  }
-}
-
-// small-layer criterion shared by forward and backward: few enough bytes per 16-channel slab that one workgroup
-// walks them in a few microseconds, enough slabs to occupy a useful part of the chip.
-// MEASURED (bench.py, C3): the one-launch form is SLOWER on the step, 6.92 vs 6.87 ms -- 32-64 workgroups walking
-// their slabs serially take longer than three short chip-wide launches that overlap with their neighbours -- so the
-// host side leaves it off (ops.BN_SMALL / CSMRI_BN_SMALL=1 to opt in); kept as the tested answer to "fold the
-// finalize kernels" of the round-1 review.
-extern "C" int csmri_bn_small_eligible(int dtype, int B, int HW, int C, int groups) {
-  if (!bn_channels_ok(C) || C < 512 || groups < 1 || B % groups) return 0;
-  const long long slab_bytes = (long long)B * HW * BNS_CS * (dtype == CSMRI_BF16 ? 2 : 4);
-  return slab_bytes <= 160 * 1024;
-}
-
-extern "C" int csmri_bn_small_fwd(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride, int B, int HW,
-                                  int C, int C_real, const float* gamma, const float* beta, float eps, float momentum,
-                                  float* running_mean, float* running_var, float slope, const float* dropmask,
-                                  float* mean, float* invstd, float* affine_snap, int groups, void* stream) {
-  CSMRI_CHECK_ARG(y && z && gamma && beta && mean && invstd && groups >= 1 && B > 0 && B % groups == 0 && HW > 0);
-  if (!csmri_bn_small_eligible(dtype, B, HW, C, groups) && !(bn_channels_ok(C) && C % BNS_CS == 0)) return CSMRI_E_UNSUPPORTED;
-  if (C % BNS_CS) return CSMRI_E_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
-  const int Bg = B / groups;
-#define BNS_F(DT_) hipLaunchKernelGGL(bn_small_fwd_kernel<DT_>, dim3(C / BNS_CS), dim3(256), 0, st, y, y_pix_stride, z, z_pix_stride, Bg, HW, C, C_real, groups, gamma, beta, eps, momentum, running_mean, running_var, slope, dropmask, mean, invstd, affine_snap)
-  if (dtype == CSMRI_BF16) BNS_F(CSMRI_BF16); else BNS_F(CSMRI_F32);
-#undef BNS_F
-  CSMRI_LAUNCH_CHECK();
-  return CSMRI_OK;
-}
-
-// backward: dy = gamma*invstd*(d - mean(d) - xhat*mean(d*xhat)), d = dz*drop*lrelu'(z), z's sign recomputed from y and
-// the forward's affine snapshot (as the RECOMP variants above); dgamma / dbeta accumulated over the groups in order
-template <int DT>
-__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const void* __restrict__ dz, int dzps, const void* __restrict__ y, int yps,
-                                                           void* __restrict__ dy, int dyps, int Bg, int HW, int C, int C_real,
-                                                           int groups, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           float slope, const float* __restrict__ drop,
-                                                           const float* __restrict__ snap, float* dgamma, float* dbeta,
-                                                           int accumulate) {
-  __shared__ double red[4 * 4 * 8];
-  const int cv = threadIdx.x & 3, pl = threadIdx.x >> 2, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * BNS_CS + cv * 4;
-  const int npix = Bg * HW;
-  const float inv_count = 1.0f / ((float)Bg * (float)HW);
-  float acc1[4] = {0.f, 0.f, 0.f, 0.f}, acc2[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int g = 0; g < groups; ++g) {
-    const long long pbase = (long long)g * npix;
-    const f32x4_t mu = *(const f32x4_t*)(mean + g * C + c), is = *(const f32x4_t*)(invstd + g * C + c);
-    const f32x4_t fsc = is * *(const f32x4_t*)(snap + c), fbe = *(const f32x4_t*)(snap + C + c);
-    f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f}, b = a;
-#pragma unroll 4
-    for (int p = pl; p < npix; p += 64) {
-      const f32x4_t gg = ld4<DT>(dz, (pbase + p) * dzps + c), yy = ld4<DT>(y, (pbase + p) * yps + c);
-      const f32x4_t zz = (yy - mu) * fsc + fbe;
-      f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
-      if (drop) dm = *(const f32x4_t*)(drop + (size_t)((pbase + p) / HW) * C + c);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float d = gg[q] * (zz[q] > 0.f ? 1.f : slope) * dm[q];
-        a[q] += d;
-        b[q] += d * (yy[q] - mu[q]) * is[q];
-      }
-    }
-    double s[8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { s[q] = a[q]; s[4 + q] = b[q]; }
-    bns_reduce8(s, red, cv, wave);
-    float gs[4], m1[4], m2[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float t1 = (float)s[q], t2 = (float)s[4 + q];
-      acc1[q] += t1; acc2[q] += t2;
-      gs[q] = c + q < C_real ? gamma[c + q] * is[q] : 0.f;
-      m1[q] = t1 * inv_count; m2[q] = t2 * inv_count;
-    }
-#pragma unroll 4
-    for (int p = pl; p < npix; p += 64) {
-      const f32x4_t gg = ld4<DT>(dz, (pbase + p) * dzps + c), yy = ld4<DT>(y, (pbase + p) * yps + c);
-      const f32x4_t zz = (yy - mu) * fsc + fbe;
-      f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f}, o;
-      if (drop) dm = *(const f32x4_t*)(drop + (size_t)((pbase + p) / HW) * C + c);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float d = gg[q] * (zz[q] > 0.f ? 1.f : slope) * dm[q];
-        const float xh = (yy[q] - mu[q]) * is[q];
-        o[q] = gs[q] * (d - m1[q] - xh * m2[q]);
-      }
-      st4<DT>(dy, (pbase + p) * dyps + c, o);
-    }
-  }
-  if (pl == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (c + q < C_real) {
-        if (dbeta) dbeta[c + q] = (accumulate ? dbeta[c + q] : 0.f) + acc1[q];
-        if (dgamma) dgamma[c + q] = (accumulate ? dgamma[c + q] : 0.f) + acc2[q];
-      }
-  }
-}
-
-extern "C" int csmri_bn_small_bwd(int dtype, const void* dz, int dz_pix_stride, const void* y, int y_pix_stride, void* dy,
-                                  int dy_pix_stride, int B, int HW, int C, int C_real, const float* mean,
-                                  const float* invstd, const float* gamma, float slope, const float* dropmask,
-                                  const float* affine_snap, float* dgamma, float* dbeta, int accumulate, int groups,
-                                  void* stream) {
-  CSMRI_CHECK_ARG(dz && y && dy && mean && invstd && gamma && affine_snap && groups >= 1 && B > 0 && B % groups == 0);
-  if (!bn_channels_ok(C) || C % BNS_CS) return CSMRI_E_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
-  const int Bg = B / groups;
-#define BNS_B(DT_) hipLaunchKernelGGL(bn_small_bwd_kernel<DT_>, dim3(C / BNS_CS), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, dy, dy_pix_stride, Bg, HW, C, C_real, groups, mean, invstd, gamma, slope, dropmask, affine_snap, dgamma, dbeta, accumulate)
-  if (dtype == CSMRI_BF16) BNS_B(CSMRI_BF16); else BNS_B(CSMRI_F32);
-#undef BNS_B
-  CSMRI_LAUNCH_CHECK();
-  return CSMRI_OK;
-}

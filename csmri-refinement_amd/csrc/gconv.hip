@@ -274,7 +274,6 @@ extern "C" size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d) {
 
 extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   { csmri_gconv_desc t = *d; t.splitk = 1; if (tconv_eligible(&t) || pconv_eligible(&t)) return 1; }
-  if (gconv8p_eligible(d)) return gconv8p_splitk(d);
   if (gconv_glds256_eligible(d)) return gconv_glds256_splitk(d);
   GConfig c = pick_config(d);
   if (gconv_glds_eligible(d)) { c.BM = 128; c.BN = gconv_glds_bn(d); }
@@ -358,7 +357,6 @@ static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
   auto lg2 = [](long long v) { int s = 0; while ((1ll << s) < v) ++s; return (1ll << s) == v ? s : -1; };
   p.wo_shift = lg2(d->Wo); p.howo_shift = lg2((long long)d->Ho * d->Wo);
   if (p.wo_shift < 0 || p.howo_shift < 0) p.wo_shift = p.howo_shift = -1;
-  p.tap_inner = 0;
   p.dq0 = d->dtype == CSMRI_FP8 ? d->in_dequant : nullptr; p.dq1 = d->dtype == CSMRI_FP8 ? d->w_dequant : nullptr;
   p.dense_out = !d->out_halo && nclass == 1 && d->out_sy == 1 && d->out_sx == 1 && d->out_oy == 0 && d->out_ox == 0 &&
                 d->Hout_t == d->Ho && d->Wout_t == d->Wo;
@@ -384,7 +382,6 @@ extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int
   if (d->dtype == CSMRI_FP8) { gconv_fp8_kernel_name(d, buf, n); return CSMRI_OK; }
   if (pconv_eligible(d)) { snprintf(buf, n, "pconv_kernel<8>"); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
-  if (gconv8p_eligible(d)) { snprintf(buf, n, "gconv8p_kernel"); return CSMRI_OK; }
   if (gconv_glds256_eligible(d)) { snprintf(buf, n, "%s", gconv_glds256_name(d)); return CSMRI_OK; }
   if (gconv_glds_eligible(d)) { gconv_glds_kernel_name(d, buf, n); return CSMRI_OK; }
   GConfig c = pick_config(d);
@@ -417,8 +414,7 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
   if (pconv_eligible(d)) return pconv_launch(p, d, st);
   if (tconv_eligible(d)) return tconv_launch(p, d, st);
   if (gconv_glds_eligible(d)) {
-    rc = gconv8p_eligible(d) ? gconv8p_launch(p, d, st)
-         : gconv_glds256_eligible(d) ? gconv_glds256_launch(p, d, st) : gconv_glds_launch(p, d, st);
+    rc = gconv_glds256_eligible(d) ? gconv_glds256_launch(p, d, st) : gconv_glds_launch(p, d, st);
     if (rc != CSMRI_OK) return rc;
     if (p.splitk > 1 && !(d->flags & CSMRI_GCONV_DEFER_REDUCE)) return launch_reduce(p, st);
     return CSMRI_OK;

@@ -18,7 +18,6 @@ struct GParams {
   int wo_shift, howo_shift;   // log2(Wo), log2(Ho*Wo) when both are powers of two, else -1: m -> (b,oy,ox) by shifts
   int dense_out;              // output position index == m (no window / stride / offset / classes): no division at all
   int off32;                  // every input / output byte offset fits 32 bits
-  int tap_inner;              // gconv8p: K order (64-channel chunk, tap) instead of (tap, chunk)
   const float* dq0; const float* dq1;   // fp8 operands: device scalars whose product dequantises the accumulators
 };
 
@@ -65,10 +64,6 @@ int gconv_glds256_splitk(const csmri_gconv_desc* d);
 const char* gconv_glds256_name(const csmri_gconv_desc* d);
 int gconv_glds256_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 
-// gconv8p.hip
-int gconv8p_eligible(const csmri_gconv_desc* d);
-int gconv8p_splitk(const csmri_gconv_desc* d);
-int gconv8p_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 
 // gconv_fp8.hip
 int gconv_fp8_eligible(const csmri_gconv_desc* d);

@@ -7,11 +7,7 @@ list of L1(f_fake, f_real.detach()).  LSGAN/WGAN are not used by the hot-path
 configs and raise."""
 import torch.nn as nn
 
-import os
-
 from csmri_hip import ops
-
-_FM_MULTI = os.environ.get('CSMRI_FM_MULTI', '1') != '0'     # A/B knob
 
 
 def get_adversarial_loss(conf, loss_name, cuda, loss_type):
@@ -54,7 +50,7 @@ class FeatureMatchingLoss(nn.Module):
     ff, fr = out_disc_fake['features'], out_disc_real['features']
     chans = out_disc_fake['feature_channels']
     n = len(ff)
-    if n <= 16 and all(a.dtype == b.dtype for a, b in zip(ff, fr)) and _FM_MULTI:
+    if n <= 16 and all(a.dtype == b.dtype for a, b in zip(ff, fr)):
       # every layer's distance in one launch pair (and one backward launch)
       return ops.MultiMeanLoss.apply(self.kind, [self.sign / n] * n, list(chans), *ff,
                                      *[b.detach() for b in fr])

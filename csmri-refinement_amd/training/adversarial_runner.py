@@ -19,7 +19,6 @@ and the two VGG forwards run, and loss scalars stay on the device (one readback 
 logging interval instead of one blocking .data[0] per loss)."""
 from collections import OrderedDict
 import logging
-import os
 
 import torch
 
@@ -126,23 +125,17 @@ class AdversarialRunner(BaseRunner):
     self.gen_lr_scheduler, self.disc_lr_scheduler = gen_lr_scheduler, disc_lr_scheduler
     # a step of one network's optimizer leaves the packed weights of the other current
     from models.utils import trainable_pack_groups
-    self._group_epochs = os.environ.get('CSMRI_GROUP_EPOCH', '1') != '0'        # A/B knob
-    if not self._group_epochs:
-      pass
-    elif gen_optimizer is not None and hasattr(gen_optimizer, 'pack_groups'):
+    if gen_optimizer is not None and hasattr(gen_optimizer, 'pack_groups'):
       gen_optimizer.pack_groups = lambda: trainable_pack_groups(self.gen)
-    if self._group_epochs and disc_optimizer is not None and hasattr(disc_optimizer, 'pack_groups'):
+    if disc_optimizer is not None and hasattr(disc_optimizer, 'pack_groups'):
       disc_optimizer.pack_groups = lambda: trainable_pack_groups(self.disc)
     # every discriminator gradient is written by library kernels (conv / BatchNorm backward), so the fill of its
-    # 112 MB flat gradient buffer per step can be replaced by "the first write overwrites" (FlatAdam.lazy_zero).
-    # Measured: identical losses after 250 steps; nothing on the step while the weight gradients' hand-offs dominated
-    # the backward, 6.13 -> 6.04 ms once those were gone (the fill sits in front of D's backward on the main chain).
-    if disc_optimizer is not None and hasattr(disc_optimizer, 'lazy_zero') and \
-        os.environ.get('CSMRI_LAZY_ZERO', '1') == '1':                               # A/B knob
-      disc_optimizer.lazy_zero = True
-    if gen_optimizer is not None and hasattr(gen_optimizer, 'lazy_zero') and \
-        os.environ.get('CSMRI_LAZY_ZERO_G', '1') == '1':                             # A/B knob
-      gen_optimizer.lazy_zero = True       # (the wrapper's scale, an autograd-accumulated gradient, is still zeroed)
+    # 112 MB flat gradient buffer per step is replaced by "the first write overwrites" (FlatAdam.lazy_zero; identical
+    # losses after 250 steps, 6.13 -> 6.04 ms: the fill sat in front of D's backward on the main chain).  The
+    # generator likewise (the wrapper's scale, an autograd-accumulated gradient, is still zeroed).
+    for opt in (disc_optimizer, gen_optimizer):
+      if opt is not None and hasattr(opt, 'lazy_zero'):
+        opt.lazy_zero = True
     self._grad_hook = None
     if dist_utils.exchange_active() and gen_optimizer is not None and disc_optimizer is not None:
       # data parallelism: a sub-bucket of gradients leaves as soon as the backward has issued its last layer.  The
@@ -193,7 +186,7 @@ class AdversarialRunner(BaseRunner):
     self.prefetch_pretrained = False
     self._pf = None
     self._pf_stream = None
-    self.third_pass_early = os.environ.get('CSMRI_THIRD_EARLY', '1') != '0'   # with vgg_early (single GPU)
+    self.third_pass_early = True          # with vgg_early (single GPU)
     self._side_stream3 = None
     self._metric_stream = None
     self.vgg_early = None                 # None: decided at the first step (True on a single GPU)
@@ -273,18 +266,9 @@ class AdversarialRunner(BaseRunner):
   def _seg1(self, st):
     batch = st['batch']
     if self.vgg_early is None:
-      env = os.environ.get('CSMRI_VGG_EARLY')          # A/B knob
-      self.vgg_early = (env == '1') if env in ('0', '1') else not dist_utils.exchange_active()
+      self.vgg_early = not dist_utils.exchange_active()
     gen_inp = self.train_model_input_fn(batch)
     st['gen_inp0'] = gen_inp[0]
-    # Where the look-ahead (frozen RecNet of batch t+1) is ISSUED matters as much as what it overlaps with: a hipGraph
-    # replays its nodes in capture order at the host's enqueue rate, so ~35 look-ahead nodes in front of the U-Net
-    # forward kept the step's critical chain waiting for 0.3 ms at every step start (tools/trace_timeline.py).
-    # Measured (ms per step): start 6.83-6.85, after the generator forward 6.92-6.96, after D's forward 6.94, end of
-    # segment 1 (default) 6.72-6.75, segment 2 6.75, segment 3 6.99; the VGG fork issued after D's forward 7.10.
-    pf_at = os.environ.get('CSMRI_PF_FORK', 'end1')             # A/B knob: start | after_gen | after_dfwd | end1 | seg2 | seg3
-    if pf_at == 'start':
-      self._fork_prefetch(st)
     if st.get('pre_cur') is not None:
       st['pre_cur'].record_stream(torch.cuda.current_stream())   # produced on the prefetch stream
       out_gen = self.gen.forward_with_pre(*gen_inp, pre=st['pre_cur'])
@@ -292,15 +276,13 @@ class AdversarialRunner(BaseRunner):
       out_gen = self.gen(*gen_inp)
     st['out_gen'] = out_gen
     st['side_results'] = {}
-    vgg_at = os.environ.get('CSMRI_VGG_FORK', 'early')       # A/B knob: early | after_dfwd | after_dfwd_ev | after_din_ev
-    ev_gen = None
-    if vgg_at.endswith('_ev'):
-      ev_gen = torch.cuda.Event()
-      ev_gen.record(torch.cuda.current_stream())
-    if self.overlap_streams and self.vgg_early and vgg_at == 'early':
+    # ISSUE ORDER (a hipGraph replays its nodes in capture order at the host's enqueue rate, and only a node's
+    # first-issued successor stays on its hardware queue; measured alternatives: DESIGN 9.0): the VGG branch is forked
+    # right behind the generator (deferring it on an event costs 3-7 %), the third discriminator pass right behind the
+    # two D-phase passes, the look-ahead at the END of this segment (in front of the U-Net forward its ~35 nodes kept
+    # the critical chain waiting 0.3 ms at every step start).
+    if self.overlap_streams and self.vgg_early:
       self._fork_vgg(st, out_gen, batch)
-    if pf_at == 'after_gen':
-      self._fork_prefetch(st)
     pair = None
     tgt = batch['target']
     if self.batch_disc_passes and tgt.is_cuda and tgt.dim() == 4 and tgt.shape[1] == 2 and \
@@ -313,8 +295,6 @@ class AdversarialRunner(BaseRunner):
                                  pool_decisions=self.pool_decisions, **({} if pair is None else {'out': pair[:b]}))
     in_real = self.disc_input_fn(tgt, gen_inp[0], out_gen, is_real_input=True, detach=True,
                                  **({} if pair is None else {'out': pair[b:]}))
-    if self.overlap_streams and self.vgg_early and vgg_at == 'after_din_ev':
-      self._fork_vgg(st, out_gen, batch, ev_gen)
     if self.batch_disc_passes:
       # the two passes of reference :333-341 as ONE pass over [fake; real] with per-half BatchNorm
       # statistics and dropout draws (identical results, half the launches on D's small maps)
@@ -325,28 +305,13 @@ class AdversarialRunner(BaseRunner):
       out_real = self.disc(nhwc=in_real)
     st['out_disc_real'] = out_real
     st['out_disc_fake_early'] = None
-    if self.overlap_streams and self.vgg_early and vgg_at in ('after_dfwd', 'after_dfwd_ev'):
-      self._fork_vgg(st, out_gen, batch, ev_gen)
-    if pf_at == 'after_dfwd':
-      self._fork_prefetch(st)
-    third_at = os.environ.get('CSMRI_THIRD_FORK', 'early')           # A/B knob: early | after_loss_ev | after_dbwd_ev
-    ev_dfwd = None
     if self.overlap_streams and self.vgg_early and self.third_pass_early:
       # single GPU: the third D forward (reference :354-357; same D weights, it only has to
       # follow the two passes above for the BatchNorm running statistics) runs on its own stream
       # next to the D loss and backward below -- two chains of small kernels share the chip
       if self._side_stream3 is None:
         self._side_stream3 = ops.named_stream('third')
-      if third_at == 'early':
-        self._side_stream3.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._side_stream3):
-          st['out_disc_fake_early'] = self._third_disc_pass(st)
-      else:
-        ev_dfwd = torch.cuda.Event()
-        ev_dfwd.record(torch.cuda.current_stream())
-
-    def third_now():
-      self._side_stream3.wait_event(ev_dfwd)
+      self._side_stream3.wait_stream(torch.cuda.current_stream())
       with torch.cuda.stream(self._side_stream3):
         st['out_disc_fake_early'] = self._third_disc_pass(st)
     names, vals, disc_losses = [], [], []
@@ -357,12 +322,8 @@ class AdversarialRunner(BaseRunner):
       vals.append(loss.detach())
     total_disc = self._weighted_total(disc_losses, self.disc_loss_weights)
     self.disc_optimizer.zero_grad()
-    if ev_dfwd is not None and third_at == 'after_loss_ev':
-      third_now()
     ops.enable_wgrad_stream(self.overlap_streams)
     total_disc.backward()
-    if ev_dfwd is not None and third_at == 'after_dbwd_ev':
-      third_now()
     # (Joining D's weight-gradient stream only at D's Adam -- so that the look-ahead fork and the generator's losses
     # run next to the weight-gradient tail of D's backward -- measured 9 % slower on the bench and crashed the graph
     # replay of a small configuration inside the runtime: removed)
@@ -370,14 +331,11 @@ class AdversarialRunner(BaseRunner):
     names.append('disc_loss')
     vals.append(total_disc.detach())
     st['names'], st['vals'] = names, vals
-    if os.environ.get('CSMRI_VGG_BWD', 'late') == 'early':
-      self._vgg_backward_early(st)               # issued here: behind D's chain in the replay's enqueue order
     if st['side_results']:                       # a segment (graph) ends with every stream joined
       torch.cuda.current_stream().wait_stream(self._side_stream)
     if st['out_disc_fake_early'] is not None:
       torch.cuda.current_stream().wait_stream(self._side_stream3)
-    if pf_at == 'end1':
-      self._fork_prefetch(st)
+    self._fork_prefetch(st)
     self._join_prefetch(st, 1)
 
   def _fork_prefetch(self, st):
@@ -396,7 +354,6 @@ class AdversarialRunner(BaseRunner):
     with one graph per segment it is joined inside segment 1."""
     if not st.get('_pf_pending'):
       return
-    from training import distributed as dist_utils
     last = 1 if dist_utils.exchange_active() else 4
     if seg >= last:
       torch.cuda.current_stream().wait_stream(self._pf_stream)
@@ -409,76 +366,23 @@ class AdversarialRunner(BaseRunner):
     self.disc.set_wgrad(True)
     return out_fake
 
-  def _fork_vgg(self, st, out_gen, batch, event=None):
+  def _fork_vgg(self, st, out_gen, batch):
     """The VGG perceptual branch (big GEMMs) only needs the generator output: run it on a side
     stream next to chains of small kernels -- the discriminator passes and backward of segment 1
     on a single GPU (vgg_early), or the third D forward of segment 2 when segment 2 has to hide
     the D-bucket all-reduce.  Autograd replays the stream assignment in the backward, so the two
-    gradient chains into `pred` overlap as well."""
+    gradient chains into `pred` overlap as well.  (Cutting the branch's backward out of the generator backward and
+    issuing it earlier measured neutral to 6 % slower, DESIGN 9.0: removed.)"""
     if self._side_stream is None:
-      self._side_stream = ops.named_stream('vgg', int(os.environ.get('CSMRI_PRIO_VGG', '0')))
-    if event is not None:             # the branch only depends on the generator output (issue order: see _seg1)
-      self._side_stream.wait_event(event)
-    else:
-      self._side_stream.wait_stream(torch.cuda.current_stream())
-    cut = os.environ.get('CSMRI_VGG_BWD', 'late') != 'late' and torch.is_grad_enabled()     # A/B knob: seg3 | early | fork | late
+      self._side_stream = ops.named_stream('vgg')
+    self._side_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(self._side_stream):
       for name, criterion in self.gen_criteria.items():
         if name == 'VGG19':
-          src = self._vgg_cut(out_gen) if cut else None
-          if src is None:
-            st['side_results'][name] = criterion(out_gen, batch)
-            continue
-          # The branch hangs on a detached copy of the prediction: its backward does not have to wait for the
-          # generator backward (_vgg_backward_early), and the gradient it leaves joins there as a second root.
-          pred, leaf, out_cut = src
-          loss = criterion(out_cut, batch)
-          st['vgg_cut'] = (name, pred, leaf, loss)
-          st['side_results'][name] = loss.detach()
-    if st.get('vgg_cut') is not None and os.environ.get('CSMRI_VGG_BWD', 'late') == 'fork':
-      self._vgg_backward_early(st)
-
-  @staticmethod
-  def _vgg_cut(out_gen):
-    """(prediction tensor the criteria read, detached leaf, generator output with the leaf in its place)."""
-    if not isinstance(out_gen, dict):
-      if not out_gen.requires_grad:
-        return None
-      leaf = out_gen.detach().requires_grad_(True)
-      return out_gen, leaf, leaf
-    fast = out_gen.get('_nhwc')
-    out_cut = dict(out_gen)
-    if fast is not None and 'pred' in fast:
-      pred = fast['pred']
-      leaf = pred.detach().requires_grad_(True)
-      out_cut['_nhwc'] = dict(fast, pred=leaf)
-      out_cut.pop('pred', None)
-    else:
-      pred = out_gen['pred']
-      leaf = pred.detach().requires_grad_(True)
-      out_cut['pred'] = leaf
-    return (pred, leaf, out_cut) if pred.requires_grad else None
-
-  def _vgg_backward_early(self, st):
-    """Backward of the forked VGG branch, on its stream, as soon as its forward is done -- next to the discriminator
-    step instead of on the generator backward's critical chain: d(total_gen)/d(prediction) through the frozen
-    extractor depends on nothing but the branch's own forward and its (constant) loss weight.  The per-queue
-    timeline showed the branch's backward (0.8 ms of large data-gradient GEMMs) issued BEHIND the third
-    discriminator pass's backward (autograd runs the later-created branch first) with the U-Net backward waiting
-    for both.  Leaves st['vgg_grad'] = (prediction, gradient) for _seg3."""
-    cut = st.pop('vgg_cut', None)
-    if cut is None:
-      return
-    name, pred, leaf, loss = cut
-    idx = len(self.gen_adv_criteria) + list(self.gen_criteria.keys()).index(name)
-    with torch.cuda.stream(self._side_stream):
-      loss.backward(self.gen_loss_weights[idx].to(loss.dtype))
-    st['vgg_grad'] = (pred, leaf.grad)
+          st['side_results'][name] = criterion(out_gen, batch)
 
   def _seg2(self, st):
     batch, out_gen = st['batch'], st['out_gen']
-    if os.environ.get('CSMRI_PF_FORK', 'end1') == 'seg2':
-      self._fork_prefetch(st)
     forked_here = False
     if self.overlap_streams and not st['side_results']:
       self._fork_vgg(st, out_gen, batch)
@@ -499,8 +403,6 @@ class AdversarialRunner(BaseRunner):
       gen_losses.append(loss)
       st['names'].append('gen_loss_' + name)
       st['vals'].append(loss.detach())
-    if forked_here and os.environ.get('CSMRI_VGG_BWD', 'late') == 'early':
-      self._vgg_backward_early(st)
     if side and forked_here:
       torch.cuda.current_stream().wait_stream(self._side_stream)
     st['total_gen'] = self._weighted_total(gen_losses, self.gen_loss_weights)
@@ -532,11 +434,10 @@ class AdversarialRunner(BaseRunner):
     st['_metrics_pending'] = True
 
   def _seg3(self, st):
-    if os.environ.get('CSMRI_PF_FORK', 'end1') == 'seg3':
-      self._fork_prefetch(st)
-    metrics_at = os.environ.get('CSMRI_METRICS_FORK', 'late_ev')       # A/B knob: early | late_ev
+    # the training metrics only read forward results that are complete HERE (event); their ~20 launches are issued
+    # after the generator backward so that they do not sit in front of it in the replay's enqueue order (+0.5-1 %)
     ev_m = None
-    if metrics_at == 'late_ev' and self.overlap_streams:
+    if self.overlap_streams:
       ev_m = torch.cuda.Event()
       ev_m.record(torch.cuda.current_stream())
     else:
@@ -552,37 +453,13 @@ class AdversarialRunner(BaseRunner):
       self.disc_optimizer.apply()
     self.gen_optimizer.zero_grad()
     ops.enable_wgrad_stream(self.overlap_streams)
-    hook = None
-    if st.get('vgg_cut') is not None:
-      # The VGG branch's backward issued FIRST, on its own stream: it then runs next to D's Adam and the third pass's
-      # backward (a chain of small kernels) instead of behind them, and its gradient joins where the prediction's
-      # gradient is complete (tensor hook: the wait lands on the generator backward's stream at that point only).
-      self._side_stream.wait_stream(torch.cuda.current_stream())    # (joins the branch's stream into this segment's capture)
-      self._vgg_backward_early(st)
-      pred, g_vgg = st.pop('vgg_grad')
-      ev_v = torch.cuda.Event()
-      ev_v.record(self._side_stream)
-
-      def _join_vgg(g):
-        torch.cuda.current_stream().wait_event(ev_v)
-        g_vgg.record_stream(torch.cuda.current_stream())
-        return g + g_vgg.to(g.dtype)
-      hook = pred.register_hook(_join_vgg)
-    vg = st.pop('vgg_grad', None)
-    if vg is not None:
-      # the VGG branch's gradient (computed on its stream, joined at the end of its segment) enters as a second root
-      vg[1].record_stream(torch.cuda.current_stream())
-      torch.autograd.backward([st['total_gen'], vg[0]], [None, vg[1]])
-    else:
-      st['total_gen'].backward()
-    if hook is not None:
-      hook.remove()
+    st['total_gen'].backward()
     if ev_m is not None:
       self._fork_train_metrics(st, ev_m)
     ops.join_wgrad_stream()
     st['names'].append('gen_loss')
     st['vals'].append(st['total_gen'].detach())
-    if st.get('out_disc_fake_early') is not None and self._group_epochs:
+    if st.get('out_disc_fake_early') is not None:
       # D's forward-mode packs for the NEXT step, behind the third pass's backward on its stream
       # (next to the rest of the generator backward) instead of in front of the next D forward
       with torch.cuda.stream(self._side_stream3):
@@ -664,8 +541,7 @@ class AdversarialRunner(BaseRunner):
       segments = (whole,)
     else:
       segments = (self._seg1, self._seg2, self._seg3, self._seg4)
-    prio = int(os.environ.get('CSMRI_PRIO_MAIN', '0'))
-    cap_stream = ops.named_stream('capture', prio)
+    cap_stream = ops.named_stream('capture')
     ops.GRAD_READY_HOOK = self._grad_hook        # same launch plan as the eager steps (the hook itself is a no-op while capturing)
     try:
       for seg in segments:

@@ -99,8 +99,6 @@ class FlatAdam(object):
       return
     side = ops._WGRAD['stream']
     if side is not None:
-      for st in ops._WGRAD['extra']:             # layers alternate between several side streams: order them all
-        side.wait_stream(st)
       with torch.cuda.stream(side):
         self.bucket.start(j)
     else:

@@ -342,21 +342,6 @@ int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, const void*
                        float slope, const float* dropmask, const float* partial, int rows,
                        float* dgamma, float* dbeta, int accumulate, const float* affine_snap,
                        int groups, void* stream);
-/* Small layers (a 16-channel slab of the tensor <= 160 KiB, C >= 512: csmri_bn_small_eligible): the whole
- * training-mode forward (batch statistics, running-statistics update, normalise + LeakyReLU + dropout mask) or the
- * whole backward (both reductions, dgamma / dbeta, dy) in ONE launch -- same arithmetic contract as the three-launch
- * sequences above (reference nn.BatchNorm2d + nn.LeakyReLU + nn.Dropout2d, models/discriminators.py:137-172), a
- * different (still deterministic) summation order. */
-int csmri_bn_small_eligible(int dtype, int B, int HW, int C, int groups);
-int csmri_bn_small_fwd(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride, int B, int HW,
-                       int C, int C_real, const float* gamma, const float* beta, float eps, float momentum,
-                       float* running_mean, float* running_var, float slope, const float* dropmask,
-                       float* mean, float* invstd, float* affine_snap, int groups, void* stream);
-int csmri_bn_small_bwd(int dtype, const void* dz, int dz_pix_stride, const void* y, int y_pix_stride, void* dy,
-                       int dy_pix_stride, int B, int HW, int C, int C_real, const float* mean,
-                       const float* invstd, const float* gamma, float slope, const float* dropmask,
-                       const float* affine_snap, float* dgamma, float* dbeta, int accumulate, int groups,
-                       void* stream);
 
 /* elementwise activation fwd/bwd with optional bias (used where no BN) */
 int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const void* z, int z_pix_stride,

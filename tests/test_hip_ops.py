@@ -163,16 +163,11 @@ def test_conv_two_source_concat(hip, dtype):
 @pytest.mark.parametrize('shape', [(2, 16, 32, 64, 64, 1), (2, 64, 128, 8, 8, 1), (2, 8, 16, 64, 64, 2),
                                    (2, 8, 8, 32, 32, 1), (8, 32, 64, 32, 32, 2), (4, 64, 512, 16, 16, 2),
                                    (2, 32, 1024, 8, 8, 1)],
-                         ids=['stats_fused', 'stats_standalone', 'c16_s2', 'c8', 'c64_s2', 'one_launch_c512_s2',
-                              'one_launch_c1024'])
+                         ids=['stats_fused', 'stats_standalone', 'c16_s2', 'c8', 'c64_s2', 'small_c512_s2',
+                              'small_c1024'])
 def test_conv_bn_act(hip, dtype, shape):
   ops = hip.ops
   b, cin, cout, h, w, stride = shape
-  one_launch = cout >= 512     # exercise the (opt-in) single-launch small-layer kernels csmri_bn_small_fwd / _bwd
-  if one_launch:
-    assert hip.lib.raw('csmri_bn_small_eligible')(1 if dtype == torch.bfloat16 else 0, b, (h // stride) * (w // stride),
-                                                  cout, 1)
-  ops.BN_SMALL = one_launch
   g = torch.Generator().manual_seed(11)
   x = torch.randn(b, cin, h, w, generator=g)
   wt = torch.randn(cout, cin, 4, 4, generator=g) / math.sqrt(cin * 16)
@@ -207,7 +202,6 @@ def test_conv_bn_act(hip, dtype, shape):
   check('bn wgrad', layer.weight.grad.cpu(), wr.grad, lo)
   check('bn dgamma', bn.weight.grad.cpu(), gr.grad, lo)
   check('bn dbeta', bn.bias.grad.cpu(), br.grad, lo)
-  ops.BN_SMALL = False
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
