@@ -165,6 +165,7 @@ _SIGS = {
     'csmri_adam': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
     'csmri_adam_dev': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp]),
     'csmri_image_pool_exchange': (i32, [vp, vp, vp, vp, i32, i64, vp]),
+    'csmri_dropout2d_mask': (i32, [vp, i64, f32, vp, vp]),
     'csmri_bucket_pack_bf16': (i32, [vp, i64, vp, i64, vp]),
     'csmri_bucket_reduce': (i32, [vp, i32, i64, vp, vp]),
     'csmri_bucket_unpack_bf16': (i32, [vp, i64, vp, vp]),

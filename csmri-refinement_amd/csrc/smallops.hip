@@ -671,3 +671,44 @@ extern "C" int csmri_image_pool_exchange(const void* x, void* pool, void* out, c
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
+
+// ------------------------------------------------------------ Dropout2d masks ----
+// nn.Dropout2d(p) of the discriminator (reference models/discriminators.py:150-152) draws one Bernoulli(1 - p) per
+// (image, channel).  All masks of one forward pass are ONE launch: element i of the flat buffer is
+//   keep_i / (1 - p),  keep_i = [ uniform_i < 1 - p ],  uniform_i = (Philox4x32-10(counter = (i / 4, 0, call, call >> 32),
+//                                                                    key = seed)[i % 4] >> 8) * 2^-24
+// with (seed, call) in DEVICE memory (state[0], state[1]); the launch increments `call`, so a replayed hipGraph
+// draws fresh masks every replay and an eager run draws the very same sequence.  One workgroup: the state is read
+// by every thread before thread 0 bumps it (a barrier apart), no second launch.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned (&k)[2]) {
+  const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+  const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+  const unsigned n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
+  c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__global__ __launch_bounds__(1024) void dropout2d_mask_kernel(float* __restrict__ out, long long n, float p,
+                                                              unsigned long long* state) {
+  const unsigned long long seed = state[0], call = state[1];
+  __syncthreads();
+  if (threadIdx.x == 0) state[1] = call + 1;
+  const float keep_p = 1.f - p, scale = 1.f / (1.f - p);
+  for (long long g = threadIdx.x; g * 4 < n; g += blockDim.x) {
+    unsigned c[4] = {(unsigned)g, (unsigned)(g >> 32), (unsigned)call, (unsigned)(call >> 32)};
+    unsigned k[2] = {(unsigned)seed, (unsigned)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long i = g * 4 + e;
+      if (i < n) out[i] = (float)(c[e] >> 8) * (1.f / 16777216.f) < keep_p ? scale : 0.f;
+    }
+  }
+}
+extern "C" int csmri_dropout2d_mask(float* mask, long long n, float p, unsigned long long* state, void* stream) {
+  CSMRI_CHECK_ARG(mask && state && n > 0 && n <= (1ll << 24) && p >= 0.f && p < 1.f);
+  if ((uintptr_t)state & 7) return CSMRI_E_ALIGN;
+  hipLaunchKernelGGL(dropout2d_mask_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, n, p, state);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}

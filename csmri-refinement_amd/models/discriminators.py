@@ -13,7 +13,7 @@ count of each for the feature-matching loss."""
 import torch
 import torch.nn as nn
 
-from csmri_hip import ops
+from csmri_hip import ops, lib
 from models.utils import (ensure_pack_group, ConvParams, BNParams, same_padding, need_bias, default_compute_dtype,
                           COMPUTE_DTYPES)
 from models.weight_inits import initialize_weights
@@ -112,13 +112,20 @@ class CNNDiscriminator(nn.Module):
     return m.contiguous()
 
   def _draw_masks(self, b, device):
-    """All Dropout2d masks of one forward from a single bernoulli draw (3 launches, not 3 per
-    layer); one contiguous [B,C] view per dropout layer, in layer order."""
+    """All Dropout2d masks of one forward in ONE launch (csmri_dropout2d_mask: Philox4x32-10 keyed by a per-module
+    seed, the call counter in device memory so that a replayed hipGraph draws fresh masks); one contiguous [B,C]
+    view per dropout layer, in layer order.  The seed comes from torch's CPU generator at first use
+    (torch.manual_seed makes runs reproducible)."""
     cs = [f for _, bn, drop, f in self._layers if bn is not None and drop]
-    if self.injected_dropout or not cs or any(c % 8 for c in cs):
+    if self.injected_dropout or not cs or any(c % 8 for c in cs) or device.type != 'cuda':
       return None
-    p = self.dropout_prob
-    flat = torch.bernoulli(torch.full((b * sum(cs),), 1.0 - p, device=device)) / (1.0 - p)
+    st = getattr(self, '_rng_state', None)
+    if st is None or st.device != device:
+      seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+      st = self._rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+    n = b * sum(cs)
+    flat = torch.empty(n, dtype=torch.float32, device=device)
+    lib.call('csmri_dropout2d_mask', flat.data_ptr(), n, float(self.dropout_prob), st.data_ptr(), ops.stream())
     views, off = [], 0
     for c in cs:
       views.append(flat[off:off + b * c].view(b, c))

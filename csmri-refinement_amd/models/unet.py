@@ -69,9 +69,7 @@ class ConvEncodeUnit(nn.Module):
     for g in self._groups[1:]:
       x = g.run(x, None, self.training)
     if self.downsample:
-      if ops.POOL_ACT_FUSED:
-        return ops.MaxPool2Skip.apply(x)      # (pooled, skip): the two gradients meet inside the un-pooling pass
-      return ops.MaxPool2.apply(x), x
+      return ops.MaxPool2Skip.apply(x)        # (pooled, skip): the two gradients meet inside the un-pooling pass
     return x
 
 

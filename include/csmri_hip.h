@@ -464,6 +464,15 @@ int csmri_adam_dev(float* p, const float* g, float* m, float* v, long long n, fl
 int csmri_image_pool_exchange(const void* x, void* pool, void* out, const long long* plan, int n,
                               long long bytes_per_image, void* stream);
 
+/* nn.Dropout2d masks of one discriminator forward pass (reference models/discriminators.py:150-152: one
+ * Bernoulli(1 - p) draw per (image, channel), survivors scaled by 1 / (1 - p)), all dropout layers in ONE launch:
+ *   mask[i] = keep_i / (1 - p),  keep_i = [u_i < 1 - p],
+ *   u_i = (Philox4x32-10(counter = (i / 4, 0, call_lo, call_hi), key = (seed_lo, seed_hi))[i % 4] >> 8) * 2^-24
+ * state: DEVICE uint64[2] = {seed, call}; the launch increments `call` (hipGraph-replay safe: every replay draws
+ * new masks, and an eager run draws the same sequence).  The masks are APPLIED by csmri_bn_act / the BatchNorm
+ * backward (`dropmask`); tests inject masks there directly.  n <= 2^24. */
+int csmri_dropout2d_mask(float* mask, long long n, float p, unsigned long long* state, void* stream);
+
 /* Gradient-bucket transport of the data-parallel step (replaces the gradient reduction of the reference's
  * nn.DataParallel wrapper, utils/custom_data_parallel.py:26-35 and utils/__init__.py:59-68).  A sub-bucket
  * g[0..n) of a model's flat fp32 gradient buffer travels as bf16 over two RCCL collectives issued by the host

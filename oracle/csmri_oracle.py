@@ -598,6 +598,36 @@ class ImagePool(object):
 # --------------------------------------------------------------------------
 
 
+def philox4x32_10(counter, key):
+  """Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the generator behind
+  torch's / curand's Philox streams): counter uint32 [n,4], key uint32 [2] -> uint32 [n,4].  Restated in numpy for
+  the product's Dropout2d mask kernel (csmri_dropout2d_mask, include/csmri_hip.h), which the reference draws with
+  torch's RNG in nn.Dropout2d (models/discriminators.py:150-152)."""
+  import numpy as np
+  c = np.array(counter, dtype=np.uint64).reshape(-1, 4).copy()
+  k0, k1 = np.uint64(int(key[0])), np.uint64(int(key[1]))
+  M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+  for _ in range(10):
+    p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+    hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+    c = np.stack([hi1 ^ c[:, 1] ^ k0, lo1, hi0 ^ c[:, 3] ^ k1, lo0], 1)
+    k0, k1 = (k0 + np.uint64(0x9E3779B9)) & MASK, (k1 + np.uint64(0xBB67AE85)) & MASK
+  return c.astype(np.uint32)
+
+
+def dropout2d_mask(seed, call, n, p):
+  """The n mask values csmri_dropout2d_mask writes for state (seed, call): keep / (1 - p) with
+  keep = [(philox >> 8) * 2^-24 < 1 - p], element i from counter (i // 4, 0, call_lo, call_hi), lane i % 4."""
+  import numpy as np
+  g = (n + 3) // 4
+  idx = np.arange(g, dtype=np.uint64)
+  ctr = np.stack([idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32),
+                  np.full(g, call & 0xFFFFFFFF, dtype=np.uint64), np.full(g, call >> 32, dtype=np.uint64)], 1)
+  r = philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32)).reshape(-1)[:n]
+  u = (r >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+  return torch.from_numpy(np.where(u < np.float32(1.0 - p), np.float32(1.0 / (1.0 - p)), np.float32(0.0)))
+
+
 def make_adam(params, lr=2e-4, beta1=0.9, beta2=0.999):
   """training/optimizers.py:19-22 -> torch.optim.Adam (eps 1e-8)."""
   return torch.optim.Adam(list(params), lr, betas=(beta1, beta2))

@@ -880,3 +880,21 @@ def test_fft2_standalone_matches_numpy(hip, shape):
   gref = np.fft.ifft2((g[..., 0].cpu().numpy() + 1j * g[..., 1].cpu().numpy()).astype(np.complex128), norm='ortho')
   gg = xg.grad.cpu().numpy()
   assert np.abs((gg[..., 0] + 1j * gg[..., 1]) - gref).max() < 2e-6 * np.abs(gref).max() + 1e-7
+
+
+@pytest.mark.parametrize('n,p', [(4, 0.5), (40960, 0.5), (4099, 0.5), (1001, 0.2), (1 << 18, 0.75)])
+def test_dropout2d_mask_matches_the_philox_oracle_bit_for_bit(hip, n, p):
+  """csmri_dropout2d_mask (nn.Dropout2d draws of reference models/discriminators.py:150-152) against the oracle's
+  numpy Philox4x32-10 (pinned to the generator's published known-answer vectors on the CPU side): every mask value
+  equal, the call counter advances by one per launch, untouched memory behind the mask stays untouched."""
+  seed = 0x0123456789abcdef ^ n
+  st = torch.tensor([seed, 5], dtype=torch.int64, device='cuda')
+  out = torch.full((n + 5,), -3.0, device='cuda')
+  for call in (5, 6):
+    hip.lib.call('csmri_dropout2d_mask', out.data_ptr(), n, p, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert st.tolist() == [seed, call + 1]
+    want = O.dropout2d_mask(seed, call, n, p)
+    assert torch.equal(out[:n].cpu(), want), (n, p, call)
+    assert bool((out[n:] == -3.0).all())
+  assert hip.lib.raw('csmri_dropout2d_mask')(out.data_ptr(), n, 1.0, st.data_ptr(), None) == -1     # p < 1

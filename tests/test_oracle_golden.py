@@ -338,3 +338,22 @@ def test_f11_multi_update_steps_schedules_and_lr_schedulers():
   finally:
     O.UNET_CONF, O.DISC_CONF = orig_unet, orig_disc
     _patch_defaults()
+
+
+def test_philox4x32_10_known_answers_and_dropout_mask():
+  """The oracle's numpy Philox4x32-10 against the published known-answer vectors of the generator (Random123
+  kat_vectors: `philox4x32 10`), and the Dropout2d mask derived from it (what csmri_dropout2d_mask must write)."""
+  import numpy as np
+  kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+         ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+         ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+          (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+  for ctr, key, want in kat:
+    got = O.philox4x32_10([list(ctr)], key)[0]
+    assert tuple(int(x) for x in got) == want, (ctr, key, [hex(int(x)) for x in got])
+  m = O.dropout2d_mask(0x1234567890abcdef, 3, 40961, 0.5)
+  assert m.shape == (40961,) and set(m.unique().tolist()) == {0.0, 2.0} and abs(float(m.mean()) - 1.0) < 0.02
+  m2 = O.dropout2d_mask(0x1234567890abcdef, 4, 40961, 0.5)
+  assert not torch.equal(m, m2)                                  # the call counter decorrelates successive passes
+  m3 = O.dropout2d_mask(7, 0, 1000, 0.2)
+  assert set(np.round(m3.unique().numpy(), 5).tolist()) == {0.0, 1.25} and abs(float((m3 > 0).float().mean()) - 0.8) < 0.05
