@@ -171,6 +171,18 @@ def refresh_packs(model):
     ensure_pack_group(m).repack_stale()
 
 
+def prepare_packs_for_capture(model):
+  """Before a hipGraph capture: run every pack group's multi-layer re-pack once EAGERLY, so that its device-side
+  item table (built by a host-to-device copy at first use -- not allowed while a stream captures) exists."""
+  for m in model.modules():
+    if getattr(m, '_pack_group', None) is not None:
+      g = ensure_pack_group(m)
+      for mode in g.modes():
+        g.repack(mode)
+      if any(l._bias_pad is not None for l in g.layers):
+        g.refresh_biases()
+
+
 def freeze(module):
   for p in module.parameters():
     p.requires_grad = False

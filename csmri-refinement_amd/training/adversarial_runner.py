@@ -510,6 +510,9 @@ class AdversarialRunner(BaseRunner):
       for _ in range(warmup):
         self._run_segments_eager({'batch': static, 'batch_next': static_next, 'pre_cur': static_pre})
     torch.cuda.current_stream().wait_stream(side)
+    from models.utils import prepare_packs_for_capture
+    for net in (self.gen, self.disc):
+      prepare_packs_for_capture(net)
     torch.cuda.synchronize()
     pool = getattr(self.disc_input_fn, 'image_pool', None)
     bns = [m for net in (self.gen, self.disc) for m in net.modules() if hasattr(m, 'batches_tracked')]

@@ -152,6 +152,8 @@ class Runner(BaseRunner):
         self._step_body(static)
         self.optimizer.step()
     torch.cuda.current_stream().wait_stream(side)
+    from models.utils import prepare_packs_for_capture
+    prepare_packs_for_capture(self.model)
     torch.cuda.synchronize()
     import gc
     gc.collect()

@@ -247,7 +247,7 @@ def test_bucket_kernels_match_the_torch_arithmetic(world, n):
   out = torch.full((n + 3,), -1.0, device=dev)
   lib.call('csmri_bucket_unpack_bf16', send.data_ptr(), n, out.data_ptr(), st)
   assert torch.equal(out[:n], want[:n].float()) and bool((out[n:] == -1.0).all())
-  assert lib.raw('csmri_bucket_pack_bf16')(x.data_ptr() + 4, n, send.data_ptr(), world * per, None) == -2   # CSMRI_E_ALIGN
+  assert lib.raw('csmri_bucket_pack_bf16')(x.data_ptr() + 4, n, send.data_ptr(), world * per, None) == -3   # CSMRI_E_ALIGN
 
 
 class _NoHostSync(object):

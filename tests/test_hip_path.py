@@ -1165,8 +1165,9 @@ def test_recnet_runner_graph_mode_follows_the_lr_scheduler(env):
   def run(graphs):
     r = make()
     r._set_train()
-    r._step_body(batches[0])            # one eager step first in BOTH runs (the capture needs warm caches)
-    r.optimizer.step()
+    for _ in range(2):                  # eager steps first in BOTH runs (allocator / pack caches are warm at capture)
+      r._step_body(batches[0])
+      r.optimizer.step()
     if graphs:
       r.enable_graphs(batches[0], warmup=0)
     out, lrs = [], []

@@ -28,17 +28,5 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
   runner.train_epoch(Loader(batches[:1]), 1)
   torch.cuda.synchronize()
-agg = collections.Counter()
-dur = collections.Counter()
-for ev in prof.events():
-  if ev.name.startswith('aten::') and ev.device_time_total > 0 and not ev.cpu_children:
-    st = [f for f in (ev.stack or []) if 'site-packages' not in f and 'dist-packages' not in f and
-          'glue_trace' not in f and '<built-in' not in f]
-    key = (ev.name, ' <- '.join(s.split('/')[-1] for s in st[:3]) + ' shape=' + str(ev.input_shapes[:2] if ev.input_shapes else ''))
-    agg[key] += 1
-    dur[key] += ev.device_time_total
-tot = 0
-for k, v in sorted(agg.items(), key=lambda kv: -dur[kv[0]]):
-  print('%3d x %7.1f us  %-22s | %s' % (v, dur[k], k[0], k[1]))
-  tot += v
-print('total aten launches with device time:', tot)
+print(prof.key_averages(group_by_input_shape=True, group_by_stack_n=6).table(
+    sort_by='self_device_time_total', row_limit=90, max_name_column_width=60, max_src_column_width=110))
