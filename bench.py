@@ -381,7 +381,7 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
     t_s = time.perf_counter()
     est = None
     while True:
-      n_chunk = 10 if est is None else max(1, min(200, int((args.settle_s - (time.perf_counter() - t_s)) / est)))
+      n_chunk = 10 if est is None else max(10, min(200, int((args.settle_s - (time.perf_counter() - t_s)) / est)))
       t_c = time.perf_counter()
       runner.train_epoch(loader_factory(n_chunk), 1, steps_per_train_summary=10 ** 9)
       torch.cuda.synchronize()

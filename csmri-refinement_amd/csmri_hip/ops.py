@@ -278,12 +278,12 @@ class PackGroup(object):
       l._bias_pad = (_weight_epoch(l), l._bias_pad[1])
     return True
 
-  def repack(self, mode):
-    """Re-pack every member that already owns a pack of ``mode`` (buffers exist after the
-    first step).  Returns False if the table cannot be used (caller packs individually)."""
+  def ensure_table(self, mode):
+    """The device-side item table of ``mode``'s multi-layer re-pack (built by a host-to-device copy: must exist
+    before a stream capture that re-packs).  Returns (table, n) or None when no member owns a pack of that mode."""
     members = [l for l in self.layers if mode in l._packs]
     if not members:
-      return False
+      return None
     sig = tuple((id(l), l.weight.data_ptr(), l._packs[mode][1].data_ptr()) for l in members)
     tab = self._tables.get(mode)
     if tab is None or tab[0] != sig:
@@ -295,6 +295,15 @@ class PackGroup(object):
       host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
       tab = (sig, host.to(members[0].weight.device), len(members))
       self._tables[mode] = tab
+    return tab, members
+
+  def repack(self, mode):
+    """Re-pack every member that already owns a pack of ``mode`` (buffers exist after the
+    first step).  Returns False if the table cannot be used (caller packs individually)."""
+    got = self.ensure_table(mode)
+    if got is None:
+      return False
+    tab, members = got
     lib.call('csmri_pack_weight_multi', tab[1].data_ptr(), tab[2], stream())
     for l in members:
       e = l._packs[mode]

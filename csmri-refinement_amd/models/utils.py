@@ -172,15 +172,14 @@ def refresh_packs(model):
 
 
 def prepare_packs_for_capture(model):
-  """Before a hipGraph capture: run every pack group's multi-layer re-pack once EAGERLY, so that its device-side
-  item table (built by a host-to-device copy at first use -- not allowed while a stream captures) exists."""
+  """Before a hipGraph capture: make sure the device-side item table of every pack group's multi-layer re-pack exists
+  (it is built by a host-to-device copy at first use -- not allowed while a stream captures).  Freshness of the
+  packs is left as it is: the captured step re-packs exactly where an eager step would."""
   for m in model.modules():
     if getattr(m, '_pack_group', None) is not None:
       g = ensure_pack_group(m)
       for mode in g.modes():
-        g.repack(mode)
-      if any(l._bias_pad is not None for l in g.layers):
-        g.refresh_biases()
+        g.ensure_table(mode)
 
 
 def freeze(module):

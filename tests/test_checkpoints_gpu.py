@@ -157,7 +157,7 @@ def test_train_cli_periodic_checkpoint_resumes_at_the_next_epoch(tmp_path):
   conf = os.path.join(PKG, 'configs', '1-recnet.json')
   run = str(tmp_path / 'run')
   over = ['--conf', 'num_epochs=2', 'steps_per_epoch=2', 'image_size=64', 'batch_size=2', 'compute_dtype=fp32']
-  assert train.main(['-c', '0', '--run-dir', run] + over + [conf]) == 0
+  assert train.main([conf, '-c', '0', '--run-dir', run] + over) == 0
   files = sorted(glob.glob(os.path.join(run, 'periodic-chkpt_*.pth')))
   assert len(files) == 2 and files[0].endswith('_1.pth') and files[1].endswith('_2.pth'), files
   ck = torch.load(files[1], map_location='cpu', weights_only=False)
@@ -174,7 +174,7 @@ def test_train_cli_periodic_checkpoint_resumes_at_the_next_epoch(tmp_path):
   logging.getLogger().addHandler(h)
   try:
     over3 = ['--conf', 'num_epochs=3', 'steps_per_epoch=2', 'image_size=64', 'batch_size=2', 'compute_dtype=fp32']
-    assert train.main(['-c', '0', '--run-dir', run, '--resume', files[1]] + over3 + [conf]) == 0
+    assert train.main([conf, '-c', '0', '--run-dir', run, '--resume', files[1]] + over3) == 0
   finally:
     logging.getLogger().removeHandler(h)
   epochs = [m.split(':')[0] for m in records if m.startswith('Epoch ')]

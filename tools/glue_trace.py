@@ -28,5 +28,15 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
   runner.train_epoch(Loader(batches[:1]), 1)
   torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True, group_by_stack_n=6).table(
-    sort_by='self_device_time_total', row_limit=90, max_name_column_width=60, max_src_column_width=110))
+rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=8)
+        if (e.key.startswith('aten::') or 'Memcpy' in e.key or 'Memset' in e.key) and e.self_device_time_total > 0]
+rows.sort(key=lambda e: -e.self_device_time_total)
+tot_n = tot_t = 0
+for e in rows:
+  st = [f for f in (e.stack or []) if 'site-packages' not in f and 'dist-packages' not in f and 'glue_trace' not in f
+        and '<built-in' not in f]
+  print('%3d x %8.1f us  %-28s %-40s | %s' % (e.count, e.self_device_time_total, e.key, str(e.input_shapes)[:40],
+                                            ' <- '.join(x.split('/')[-1] for x in st[:4])))
+  tot_n += e.count
+  tot_t += e.self_device_time_total
+print('total aten launches with device time: %d, %.1f us' % (tot_n, tot_t))
