@@ -394,7 +394,7 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
       if float(done.item()) > 0:
         break
   if min_timed_s > 0 and settle_steps > 0:
-    steps = max(steps, int(min_timed_s / est) + 1)
+    steps = max(steps, int(1.35 * min_timed_s / est) + 1)     # (est includes per-chunk sync overhead: margin)
   if ws > 1:
     torch.distributed.barrier()
   torch.cuda.synchronize()
