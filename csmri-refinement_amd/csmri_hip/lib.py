@@ -48,6 +48,7 @@ class GConvDesc(C.Structure):
       ('out_halo', vp), ('halo_pix_stride', i32), ('win_y0', i32), ('win_x0', i32), ('win_h', i32),
       ('win_w', i32),
       ('in_dequant', vp), ('w_dequant', vp),
+      ('cin_real', i32), ('cout_real', i32),
   ]
 
 

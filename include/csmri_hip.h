@@ -110,6 +110,10 @@ typedef struct csmri_gconv_desc {
    * weights) whose product multiplies the fp32 accumulators before the epilogue; NULL = 1.  The fp8
    * variant needs Cin % 128 == 0, c0 % 16 == 0, Cout % 64 == 0, pixel strides % 16 == 0. */
   const float* in_dequant; const float* w_dequant;
+  /* real (un-padded) channel counts of the K and N sides, 0 = unknown.  1 selects the thin-layer kernels
+   * (discriminator first layer and its data gradient, U-Net head, discriminator final conv): same result, the
+   * seven pad channels are simply not multiplied. */
+  int cin_real, cout_real;
 } csmri_gconv_desc;
 #define CSMRI_GCONV_DEFER_REDUCE 1
 

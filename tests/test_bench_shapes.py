@@ -166,8 +166,13 @@ def test_bench_layer_vs_oracle_bf16(hip, case):
 
 
 def test_dispatch_variants_are_all_exercised():
-  """Every kernel family of the conv library is reached by at least one bench shape above (and has
-  therefore been compared with the oracle); a dispatch change that strands a family fails here."""
+  """Every kernel instance the BENCHMARKED step launches (the `conv_kernels` table of the committed bench line,
+  profiles/r03_bench_n1.json: keys are the instance names rocprofv3 prints) has been reached by a bench shape above,
+  i.e. has been compared with the oracle; a dispatch change that strands an instance, or a bench line taken with a
+  build whose instances these shapes no longer reach, fails here."""
+  import json
+  import os
+  from conftest import ROOT
   if len(SEEN) < len(CASES):
     pytest.skip('runs after the full parametrized set')
   names = sorted(set(e[1] for v in SEEN.values() for e in v))
@@ -175,7 +180,13 @@ def test_dispatch_variants_are_all_exercised():
   fam = set(n.split('<')[0].replace('void ', '') for n in names)
   splitk = any(e[2] > 1 and e[0] == 'gconv' for v in SEEN.values() for e in v)
   assert splitk, 'no split-K convolution among the bench shapes'
-  # families that must carry bench layers; a new family should be added here when it ships
-  need = {'tconv_kernel', 'gconv_kernel'}
+  need = {'tconv_kernel', 'gconv_kernel', 'gconv_glds_kernel', 'gconv_glds256_kernel', 'pconv_kernel', 'thin_in1_kernel',
+          'thin_out1_kernel', 'wpatch_kernel', 'wgrad_glds_row_kernel', 'wthin_in1_kernel', 'wthin_out_kernel'}
   assert need <= fam, (need - fam, fam)
-  assert any(f.startswith('wgrad') for f in fam)
+  path = os.path.join(ROOT, 'profiles', 'r03_bench_n1.json')
+  assert os.path.exists(path), 'commit the bench line of this build as profiles/r03_bench_n1.json'
+  table = json.load(open(path))['conv_kernels']
+  # second stages / fused blocks that are not csmri_gconv / csmri_wgrad main kernels (covered by tests/test_hip_ops.py)
+  other = {'gconv_reduce_kernel', 'convblock_fwd_kernel'}
+  missing = sorted(k for k in table if k not in other and k not in names)
+  assert not missing, 'bench launches kernel instances no bench-shape case reaches: %s' % missing
