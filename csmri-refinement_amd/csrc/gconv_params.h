@@ -41,10 +41,8 @@ __device__ __forceinline__ OutPos gconv_out_pos(const GParams& p, int b, int ty,
   return o;
 }
 
-// thin.hip: one real channel on the K side (thin_in1) or on the N side (thin_out1)
-int thin_in1_eligible(const csmri_gconv_desc* d);
+// thin.hip: one real channel on the N side
 int thin_out1_eligible(const csmri_gconv_desc* d);
-int thin_in1_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 int thin_out1_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 void thin_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
 

@@ -1012,17 +1012,14 @@ static int wpatch_launch(const WParams& p, const csmri_wgrad_desc* d, hipStream_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Thin layers (one real channel on one side; see thin.hip): weight gradients as streaming reductions on the vector
-// unit.  The MFMA kernels above spend a 16-wide tile side on one channel and a 16-byte gather per tap: 60 us for
-// the discriminator's first layer (50 MB of operands), 49 us for the U-Net head (42 MB), 63 us for the
-// discriminator's final conv (3 MB).  Both kernels leave slabs [z][Cout][NK] and one bias-gradient partial row per
-// z behind them, i.e. they plug into the slab reduction (wgrad_scatter / csmri_wgrad_finish_multi) like wpatch.
-//
-//   wthin_in1   Cin_real = 1 (KH = KW = 4): a thread owns (pixel lane, 8 output channels) and keeps the 16 x 8 sums in
-//               registers over its pixel range: one 16-byte dY load + 16 input scalars (shared by the 8 threads of
-//               a pixel) per pixel; pixel lanes combine by wave shuffles, the four waves through LDS (fixed order).
-//   wthin_out   Cout_real <= 2: a block owns (pixel range z, filter tap, block of <= 256 input channels); a thread
-//               (pixel lane, 8 channels) reads 16 bytes of x at the tap-shifted position + the dY scalars per pixel.
+// Thin layer: the weight gradient of the discriminator's final conv (1024 -> 1 channel, 4 x 4 on an 8 x 8 map:
+// reference models/discriminators.py:160-172) as a streaming reduction on the vector unit.  The MFMA kernels above
+// spend a 16-wide tile side on that one channel: 63 us for 3 MB of operands; this one takes 21 us.  A block owns
+// (pixel range z, filter tap, block of <= 256 input channels); a thread (pixel lane, 8 channels) reads 16 bytes of x
+// at the tap-shifted position + the dY scalars per pixel; pixel lanes combine by wave shuffles, the four waves
+// through LDS (fixed order).  It leaves slabs [z][Cout][NK] and one bias-gradient partial row per z behind, i.e. it
+// plugs into the slab reduction (wgrad_scatter / csmri_wgrad_finish_multi) like wpatch.  (The same form on the
+// large-map thin layers -- U-Net head 76 vs 49 us, discriminator first layer 208 vs 60 us -- lost and is not kept.)
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wthin_decomp(const WParams& p, int m, int& b, int& oy, int& ox) {
   const int HoWo = p.Ho * p.Wo;
@@ -1037,85 +1034,6 @@ __device__ __forceinline__ void wthin_ld8(const char* q, int dt, float (&g)[8]) 
     const f32x4_t a = *(const f32x4_t*)q, b = *(const f32x4_t*)(q + 16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { g[i] = a[i]; g[4 + i] = b[i]; }
-  }
-}
-
-template <int KH, int KW>
-__global__ __launch_bounds__(256) void wthin_in1_kernel(const WParams p, int dt, int want_db) {
-  constexpr int NT = KH * KW;
-  __shared__ float red[4][8][NT * 8 + 8];                  // [wave][channel chunk within the wave's 8][sums]
-  const int es = dt == CSMRI_BF16 ? 2 : 4;
-  const int NC = p.Cout >> 3;                              // 8-channel chunks per pixel: power of two, 8..32
-  const int chunk = threadIdx.x & (NC - 1), pl = threadIdx.x / NC, lanes = 256 / NC;
-  const int z = blockIdx.x, Z = gridDim.x;
-  const int per = (p.M + Z - 1) / Z, m_begin = z * per, m_end = min(p.M, m_begin + per);
-  float acc[NT][8], accb[8];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) accb[j] = 0.f;
-  for (int m = m_begin + pl; m < m_end; m += lanes) {
-    int b, oy, ox;
-    wthin_decomp(p, m, b, oy, ox);
-    float g[8];
-    wthin_ld8(p.dy + ((size_t)m * p.dyps + chunk * 8) * es, dt, g);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) accb[j] += g[j];
-    const size_t ib = (size_t)b * p.Hin * p.Win;
-#pragma unroll
-    for (int ky = 0; ky < KH; ++ky) {
-      int u = oy * p.S - p.pt + ky;
-      bool oku = true;
-      if (p.border == CSMRI_BORDER_REFLECT) u = reflect_idx(u, p.Hin); else oku = (unsigned)u < (unsigned)p.Hin;
-#pragma unroll
-      for (int kx = 0; kx < KW; ++kx) {
-        int v = ox * p.S - p.pl + kx;
-        bool ok = oku;
-        if (p.border == CSMRI_BORDER_REFLECT) v = reflect_idx(v, p.Win); else ok = ok && (unsigned)v < (unsigned)p.Win;
-        float x = 0.f;
-        if (ok) {
-          const char* q = p.in0 + (ib + (size_t)u * p.Win + v) * p.ps0 * es;
-          x = dt == CSMRI_BF16 ? bf16_bits_to_f32(*(const unsigned short*)q) : *(const float*)q;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[ky * KW + kx][j] += x * g[j];
-      }
-    }
-  }
-  // pixel lanes of a wave (lane bits above the chunk bits), then the four waves in fixed order
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int o = NC; o < 64; o <<= 1) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[t][j] += __shfl_xor(acc[t][j], o);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) accb[j] += __shfl_xor(accb[j], o);
-  }
-  // NC == 8: a wave holds all 8 chunks once; NC == 16/32: the chunks of a pixel span lanes 0..NC-1 likewise
-  for (int c0 = 0; c0 < NC; c0 += 8) {
-    __syncthreads();
-    if (lane >= c0 && lane < c0 + 8 && lane < NC) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[wave][lane - c0][t * 8 + j] = acc[t][j];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) red[wave][lane - c0][NT * 8 + j] = accb[j];
-    }
-    __syncthreads();
-    float* slab = p.slab + (size_t)z * p.Cout * p.NK;
-    float* part = p.slab + (size_t)Z * p.Cout * p.NK + (size_t)z * p.Cout;
-    for (int e = threadIdx.x; e < 8 * (NT * 8 + 8); e += 256) {
-      const int cc = e / (NT * 8 + 8), r = e - cc * (NT * 8 + 8);
-      const float s = red[0][cc][r] + red[1][cc][r] + red[2][cc][r] + red[3][cc][r];
-      const int t = r >> 3, j = r & 7, co = (c0 + cc) * 8 + j;
-      if (c0 + cc >= NC) continue;
-      if (t < NT) slab[(size_t)co * p.NK + t * p.Cin] = s;              // k = (tap, ci = 0)
-      else if (want_db) part[co] = s;
-    }
   }
 }
 
@@ -1185,24 +1103,13 @@ __global__ __launch_bounds__(256) void wthin_out_kernel(const WParams p, int dt,
         red[128][threadIdx.x] + red[129][threadIdx.x] + red[130][threadIdx.x] + red[131][threadIdx.x];
 }
 
-static bool wpatch_eligible(const csmri_wgrad_desc* d);
-static bool wthin_in1_eligible(const csmri_wgrad_desc* d) {
-  if (d->Cin != 8 || d->Cin_real != 1 || d->KH != 4 || d->KW != 4 || d->in1 || d->upsample) return false;
-  const int nc = d->Cout / 8;
-  if (d->Cout % 8 || nc < 8 || nc > 32 || (nc & (nc - 1))) return false;
-  return !wpatch_eligible(d);
-}
 static bool wthin_out_eligible(const csmri_wgrad_desc* d) {
   if (d->Cout != 8 || d->Cout_real > 2 || d->in1 || d->upsample || d->Cin % 8) return false;
-  return d->KH * d->KW == 1 || !wpatch_eligible(d);
+  return (long long)d->B * d->Ho * d->Wo <= 4096 && d->Cin >= 256;        // deep K on few positions
 }
 static int wthin_out_kl(const csmri_wgrad_desc* d) { int kl = d->Cin / 8; while (kl > 32) kl = (kl + 1) / 2; int p2 = 1; while (p2 < kl) p2 <<= 1; return p2 > 32 ? 32 : p2; }
 static int wthin_splits(const csmri_wgrad_desc* d) {
   const long long M = (long long)d->B * d->Ho * d->Wo;
-  if (wthin_in1_eligible(d)) {
-    long long z = M / 512; if (z > 256) z = 256; if (z < 1) z = 1;          // >= 512 pixels per workgroup, <= 8 MB of slabs
-    return (int)z;
-  }
   const int kl = wthin_out_kl(d), cblocks = (d->Cin / 8 + kl - 1) / kl, kb = d->KH * d->KW * cblocks;
   long long z = 1024 / kb; if (z < 1) z = 1;
   const long long maxz = M / (4 * (256 / kl)); if (z > maxz) z = maxz; if (z < 1) z = 1;
@@ -1210,13 +1117,9 @@ static int wthin_splits(const csmri_wgrad_desc* d) {
   return (int)z;
 }
 static int wthin_launch(const WParams& p, const csmri_wgrad_desc* d, hipStream_t st) {
-  if (wthin_in1_eligible(d)) {
-    hipLaunchKernelGGL((wthin_in1_kernel<4, 4>), dim3(p.splitk), dim3(256), 0, st, p, d->dtype, d->db ? 1 : 0);
-  } else {
-    const int kl = wthin_out_kl(d), cblocks = (d->Cin / 8 + kl - 1) / kl;
-    hipLaunchKernelGGL(wthin_out_kernel, dim3(p.splitk, d->KH * d->KW * cblocks), dim3(256), 0, st, p, d->dtype,
-                       d->db ? 1 : 0, d->Cout_real, kl, cblocks);
-  }
+  const int kl = wthin_out_kl(d), cblocks = (d->Cin / 8 + kl - 1) / kl;
+  hipLaunchKernelGGL(wthin_out_kernel, dim3(p.splitk, d->KH * d->KW * cblocks), dim3(256), 0, st, p, d->dtype,
+                     d->db ? 1 : 0, d->Cout_real, kl, cblocks);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
@@ -1243,7 +1146,7 @@ static WConfig pick_wconfig(const csmri_wgrad_desc* d) {
 static int wgrad_ps(int dtype) { return dtype == CSMRI_BF16 ? 64 : 16; }
 
 extern "C" int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d) {
-  if (wthin_in1_eligible(d) || wthin_out_eligible(d)) return wthin_splits(d);
+  if (wthin_out_eligible(d)) return wthin_splits(d);
   if (wpatch_eligible(d)) return wpatch_groups(d);
   WConfig c = pick_wconfig(d);
   const long long NK = (long long)d->KH * d->KW * d->Cin;
@@ -1313,7 +1216,6 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
 // template instance csmri_wgrad dispatches to for this problem, spelled as rocprofv3 prints it
 extern "C" int csmri_wgrad_kernel_name(const csmri_wgrad_desc* d, char* buf, int n) {
   CSMRI_CHECK_ARG(d && buf && n > 0);
-  if (wthin_in1_eligible(d)) { snprintf(buf, n, "wthin_in1_kernel<4, 4>"); return CSMRI_OK; }
   if (wthin_out_eligible(d)) { snprintf(buf, n, "wthin_out_kernel"); return CSMRI_OK; }
   if (wpatch_eligible(d)) {
     snprintf(buf, n, "wpatch_kernel<%d, %d, %d>", d->Cin, d->Cin == 128 ? 32 : wpatch_cout(d),
@@ -1357,7 +1259,7 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // a split whose step range is empty still has to define its slab: zero everything first
   // when the split count does not divide evenly (cheap; slabs are small next to activations)
-  const bool thin = wthin_in1_eligible(d) || wthin_out_eligible(d);       // (write every slab entry they own themselves)
+  const bool thin = wthin_out_eligible(d);       // (write every slab entry they own themselves)
   if (!thin && (long long)p.steps_per_split * (p.splitk - 1) >= p.nsteps) {
     hipError_t e = hipMemsetAsync(d->slab, 0, (size_t)p.splitk * d->Cout * p.NK * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
@@ -1460,7 +1362,7 @@ extern "C" int csmri_wgrad_finish_multi(const csmri_wgrad_desc* descs, int n, vo
       t.Cout = d->Cout; t.NK = d->KH * d->KW * d->Cin; t.Cin = d->Cin; t.KH = d->KH; t.KW = d->KW;
       t.Cout_real = d->Cout_real; t.Cin_real = d->Cin_real; t.accumulate = d->accumulate;
       t.slab = d->slab; t.dw = d->dw;
-      const bool patch = wpatch_eligible(d) || wthin_in1_eligible(d) || wthin_out_eligible(d);
+      const bool patch = wpatch_eligible(d) || wthin_out_eligible(d);
       t.db = patch ? d->db : nullptr;                  // (other kernels: bias gradient already written by csmri_wgrad)
       t.part = d->slab + (size_t)t.splitk * d->Cout * t.NK; t.part_rows = t.splitk;
       long long nb = t.splitk <= 8 ? (long long)t.Cout_real * ((t.Cin_real + 63) / 64)
