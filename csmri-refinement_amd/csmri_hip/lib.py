@@ -67,6 +67,22 @@ class ConvBlockDesc(C.Structure):
   ]
 
 
+class ConvBlockBwdDesc(C.Structure):
+  _fields_ = [
+      ('dtype', i32),
+      ('num_convs', i32), ('num_filters', i32), ('kernel_size', i32), ('num_inputs', i32), ('num_outputs', i32),
+      ('border', i32),
+      ('x', vp), ('x_pix_stride', i32),
+      ('B', i32), ('H', i32), ('W', i32),
+      ('act', vp * 2), ('act_pix_stride', i32 * 2),
+      ('gy', vp), ('gy_dtype', i32), ('gy_pix_stride', i32),
+      ('wd', vp * 3), ('Kp', i32 * 3),
+      ('slope', f32),
+      ('dx', vp), ('dx_pix_stride', i32),
+      ('slab', vp * 3), ('splits', i32), ('want_db', i32),
+  ]
+
+
 class PackItem(C.Structure):
   _fields_ = [('w', vp), ('out', vp), ('mode', i32), ('dtype', i32), ('Cout', i32), ('Cin', i32),
               ('KH', i32), ('KW', i32)]
@@ -112,6 +128,8 @@ _SIGS = {
     'csmri_absmax': (i32, [i32, vp, i64, vp, vp]),
     'csmri_convblock_fused_supported': (i32, [vp]),
     'csmri_convblock_fused_fwd': (i32, [vp, vp]),
+    'csmri_convblock_fused_bwd': (i32, [vp, vp]),
+    'csmri_convblock_fused_bwd_splits': (i32, [i32, i32, i32]),
     'csmri_quantize_fp8': (i32, [i32, vp, vp, i64, vp, vp, vp]),
     'csmri_wgrad': (i32, [C.POINTER(WGradDesc), vp]),
     'csmri_wgrad_finish_multi': (i32, [C.POINTER(WGradDesc), i32, vp]),

@@ -851,6 +851,109 @@ def convblock_fused_forward(x, plan, out_dtype_last, need_acts, out_complex=Fals
   return [x, a1, a2, y]
 
 
+FUSED_CONVBLOCK_BWD = True        # tests turn it off for A/B against the per-layer backward
+
+
+def _grad_targets(layer):
+  """(dw, db, accumulate) of a layer's weight / bias gradient, honouring FlatAdam.lazy_zero like conv_wgrad."""
+  wgt = layer.weight
+  if wgt.grad is None:
+    wgt.grad = torch.zeros_like(wgt)
+  if layer.bias is not None and layer.bias.grad is None:
+    layer.bias.grad = torch.zeros_like(layer.bias)
+  fresh = getattr(wgt, '_grad_fresh', False)
+  wgt._kernel_grad = True
+  if layer.bias is not None:
+    layer.bias._kernel_grad = True
+  if fresh:
+    wgt._grad_fresh = False
+    if layer.bias is not None:
+      layer.bias._grad_fresh = False
+  assert wgt.grad.is_contiguous()
+  return wgt.grad, (layer.bias.grad if layer.bias is not None else None), int(not fresh)
+
+
+def convblock_fused_backward(plan, saved, g, need_dx, out_complex):
+  """The whole backward of a fused conv block in one launch (csrc/convblock_bwd.hip) + the slab reduction of its three
+  weight gradients; returns (ok, dx).  ``saved`` = [x, a1, a2, _]; ``g``: gradient of the block output."""
+  if not FUSED_CONVBLOCK_BWD or len(plan) != 3 or PROFILE is not None:
+    return False, None
+  layers = [l for l, _ in plan]
+  slopes = [s for _, s in plan]
+  x, a1, a2 = saved[0], saved[1], saved[2]
+  l0 = layers[0]
+  if a1 is None or a2 is None or x.dtype != torch.bfloat16 or a1.dtype != torch.bfloat16 or a2.dtype != torch.bfloat16:
+    return False, None
+  if slopes[0] != slopes[1] or slopes[2] != 1.0 or any(l.bias is None or l.fp8 or l.dtype != torch.bfloat16 for l in layers):
+    return False, None
+  if not all(l.weight.requires_grad and l.train_weights for l in layers):
+    return False, None
+  ok = all(l.kh == l.kw == 3 and l.stride == 1 and not l.upsample and l.border == BORDER_ZERO and
+           tuple(l.pads) == (1, 1, 1, 1) for l in layers) and \
+      (l0.cin, l0.cout, layers[1].cin, layers[1].cout, layers[2].cin, layers[2].cout) == (2, 32, 32, 32, 32, 2)
+  if not ok or not (is_nhwc(x) and is_nhwc(a1) and is_nhwc(a2)) or not (0.0 <= slopes[0] <= 1.0):
+    return False, None
+  g = as_nhwc(g)
+  b, h, w, _ = x.shape
+  if out_complex:
+    if g.dtype != torch.float32 or g.shape[3] != 2 or not g.is_contiguous():
+      return False, None
+  elif g.shape[3] < 8 or g.dtype not in (torch.float32, torch.bfloat16):
+    return False, None
+  d = lib.ConvBlockBwdDesc()
+  d.dtype = BF16
+  d.num_convs, d.num_filters, d.kernel_size, d.num_inputs, d.num_outputs, d.border = 3, 32, 3, 2, 2, BORDER_ZERO
+  d.x, d.x_pix_stride, d.B, d.H, d.W = x.data_ptr(), x.stride(2), b, h, w
+  d.act[0], d.act[1] = a1.data_ptr(), a2.data_ptr()
+  d.act_pix_stride[0], d.act_pix_stride[1] = a1.stride(2), a2.stride(2)
+  d.gy, d.gy_dtype, d.gy_pix_stride = g.data_ptr(), dt_of(g), g.stride(2)
+  keep = [g]
+  for i, l in enumerate(layers):
+    wp, kp, _, _ = l._pack(3)
+    d.wd[i], d.Kp[i] = wp.data_ptr(), kp
+    keep.append(wp)
+  d.slope = float(slopes[0])
+  dx = None
+  if need_dx:
+    dx = torch.empty(b, h, w, l0.cin_p, dtype=torch.bfloat16, device=x.device)
+    d.dx, d.dx_pix_stride = dx.data_ptr(), dx.stride(2)
+  z = lib.raw('csmri_convblock_fused_bwd_splits')(b, h, w)
+  d.splits, d.want_db = z, 1
+  descs = []
+  for i, l in enumerate(layers):
+    wd = lib.WGradDesc()
+    wd.dtype, wd.B, wd.Hin, wd.Win, wd.Cin = BF16, b, h, w, l.cin_p
+    wd.KH, wd.KW, wd.stride, wd.pad_t, wd.pad_l = 3, 3, 1, 1, 1
+    wd.Ho, wd.Wo, wd.Cout, wd.Cin_real, wd.Cout_real = h, w, l.cout_p, l.cin, l.cout
+    wd.splitk, wd.defer_finish = z, 2
+    dw, db, acc = _grad_targets(l)
+    wd.dw, wd.db, wd.accumulate = dw.data_ptr(), db.data_ptr(), acc
+    slab = torch.empty(lib.raw('csmri_wgrad_slab_bytes')(C.byref(wd)) // 4, dtype=torch.float32, device=x.device)
+    wd.slab = slab.data_ptr()
+    wd.in0, wd.dy = x.data_ptr(), g.data_ptr()          # (only their presence is checked by the reduction)
+    d.slab[i] = slab.data_ptr()
+    descs.append((wd, slab, dw, db))
+  if LAUNCH_LOG is not None:
+    LAUNCH_LOG.append(('convblock', 'convblock_bwd_kernel', z))
+  lib.call('csmri_convblock_fused_bwd', C.byref(d), stream())
+  fq = _WGRAD['finish']
+  want = WGRAD_FINISH_MULTI == '1' or (WGRAD_FINISH_MULTI == 'auto' and _WGRAD['stream'] is None)
+  if want and GRAD_READY_HOOK is None and _ensure_flush_callback():
+    if any(e[0].dw == wd.dw for e in fq for wd, _, _, _ in descs):
+      _finish_wgrads()
+    for wd, slab, dw, db in descs:
+      fq.append((wd, slab, dw, db, torch.cuda.current_stream()))
+  else:
+    arr = (lib.WGradDesc * 3)()
+    for i, (wd, _, _, _) in enumerate(descs):
+      C.memmove(C.byref(arr[i]), C.byref(wd), C.sizeof(lib.WGradDesc))
+    lib.call('csmri_wgrad_finish_multi', arr, 3, stream())
+    if GRAD_READY_HOOK is not None:
+      for l in layers:
+        GRAD_READY_HOOK(l)
+  return True, dx
+
+
 class ConvActStack(torch.autograd.Function):
   """A chain of (pad -> conv -> +bias -> LeakyReLU) layers as ONE autograd node (RecNet's ConvBlock,
   reference models/recnet.py:29-62).  Same kernels as ConvAct per layer; in the backward the activation
@@ -897,6 +1000,10 @@ class ConvActStack(torch.autograd.Function):
     n = len(plan)
     g = as_nhwc(gy)
     last_layer, last_slope = plan[-1]
+    if n == 3 and all(ctx.w_req) and saved[1] is not None:
+      ok, dx = convblock_fused_backward(plan, saved, g, ctx.needs_input_grad[0], ctx.out_complex)
+      if ok:
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
     if ctx.out_complex:              # [B,H,W,2] fp32 -> the data-gradient kernels' padded layout, one pass
       g = copy_channels(g, last_layer.cout_p, last_layer.dtype)
     elif g.dtype != last_layer.dtype:

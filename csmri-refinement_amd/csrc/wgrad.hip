@@ -1362,7 +1362,7 @@ extern "C" int csmri_wgrad_finish_multi(const csmri_wgrad_desc* descs, int n, vo
       t.Cout = d->Cout; t.NK = d->KH * d->KW * d->Cin; t.Cin = d->Cin; t.KH = d->KH; t.KW = d->KW;
       t.Cout_real = d->Cout_real; t.Cin_real = d->Cin_real; t.accumulate = d->accumulate;
       t.slab = d->slab; t.dw = d->dw;
-      const bool patch = wpatch_eligible(d) || wthin_out_eligible(d);
+      const bool patch = wpatch_eligible(d) || wthin_out_eligible(d) || d->defer_finish == 2;
       t.db = patch ? d->db : nullptr;                  // (other kernels: bias gradient already written by csmri_wgrad)
       t.part = d->slab + (size_t)t.splitk * d->Cout * t.NK; t.part_rows = t.splitk;
       long long nb = t.splitk <= 8 ? (long long)t.Cout_real * ((t.Cin_real + 63) / 64)

@@ -178,6 +178,39 @@ int csmri_convblock_fused_supported(const csmri_convblock_desc* d);
 int csmri_convblock_fused_fwd(const csmri_convblock_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------
+ * The BACKWARD pass of the same block as a single launch (SURVEY 8b `csmri_convblock_fused_bwd`): what
+ * `loss.backward()` (reference training/runner.py:163) runs through models/recnet.py:29-62 -- three data-gradient
+ * convolutions, two LeakyReLU derivatives, three weight gradients and three bias gradients -- with the
+ * intermediate gradients kept in LDS:
+ *   dA2 = conv3x3(dY, W3 flipped) * lrelu'(a2);  dA1 = conv3x3(dA2, W2 flipped) * lrelu'(a1);
+ *   dX = conv3x3(dA1, W1 flipped);  dW3 += a2^T dY, dW2 += a1^T dA2, dW1 += x^T dA1;  db_l += sum dY_l
+ * x, act[0] (a1), act[1] (a2): the block input and the saved activations of csmri_convblock_fused_fwd (bf16);
+ * gy: the gradient of the block output, fp32 dense complex [B,H,W,2] (gy_pix_stride 2) or [B,H,W,>=8] bf16 / fp32;
+ * wd[i] / Kp[i]: csmri_pack_weight(mode 3, CSMRI_BF16) of layer i; dx: [B,H,W,>=8] bf16 (channels 0..7 written,
+ * 2..7 zero) or NULL when the block input needs no gradient.
+ * Weight / bias gradients leave as `splits` slabs per layer in csmri_wgrad's slab format -- slab[i]:
+ * fp32 [splits][Cout_p][KH*KW*Cin_p] followed by [splits][Cout_p] bias partial rows (Cout_p, Cin_p = 32, 8 / 32,
+ * 32 / 8, 32 for i = 0, 1, 2; csmri_wgrad_slab_bytes of the layer's descriptor with splitk = splits) -- and are
+ * reduced into the fp32 reference-layout gradients by csmri_wgrad_finish_multi on the three layers' descriptors
+ * (splitk = splits, defer_finish = 2).  splits: workgroups launched (csmri_convblock_fused_bwd_splits).
+ * Same support matrix as the forward (bf16, 3 convs, 32 filters, kernel 3, 2 -> 2 channels, zero padding).
+ * ---------------------------------------------------------------------- */
+typedef struct csmri_convblock_bwd_desc {
+  int dtype;
+  int num_convs, num_filters, kernel_size, num_inputs, num_outputs, border;
+  const void* x; int x_pix_stride;
+  int B, H, W;
+  const void* act[2]; int act_pix_stride[2];
+  const void* gy; int gy_dtype; int gy_pix_stride;
+  const void* wd[3]; int Kp[3];
+  float slope;
+  void* dx; int dx_pix_stride;
+  float* slab[3]; int splits; int want_db;
+} csmri_convblock_bwd_desc;
+int csmri_convblock_fused_bwd(const csmri_convblock_bwd_desc* d, void* stream);
+int csmri_convblock_fused_bwd_splits(int B, int H, int W);
+
+/* ------------------------------------------------------------------------
  * fp8 operand preparation (BASELINE.json config 5: "fp8 MFMA convs").  The reference has no fp8 path;
  * the variant computes the same nn.Conv2d (models/unet.py:40-52, models/discriminators.py,
  * models/vgg.py) on operands rounded to OCP e4m3fn with one power-of-two scale per tensor:
@@ -212,7 +245,9 @@ typedef struct csmri_wgrad_desc {
   int splitk; float* slab;   /* [splitk][CoutPad][KH*KW*Cin] fp32 */
   int accumulate;            /* 0: overwrite dw/db, 1: add */
   int defer_finish;          /* 1: leave the slab reduction into dw (and the patch kernels' bias partials) to
-                                csmri_wgrad_finish_multi; the slab must stay alive until then */
+                                csmri_wgrad_finish_multi; the slab must stay alive until then.  2 (descriptors handed
+                                to csmri_wgrad_finish_multi only): the slabs AND one bias partial row per split were
+                                produced by csmri_convblock_fused_bwd */
 } csmri_wgrad_desc;
 
 int csmri_wgrad(const csmri_wgrad_desc* d, void* stream);

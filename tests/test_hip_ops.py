@@ -501,6 +501,8 @@ def test_convblock_fused_equals_per_layer_path(hip, shape):
   x = torch.randn(b, 2, h, w, generator=g)
   gy = torch.randn(b, 2, h, w, generator=g)
 
+  ops.FUSED_CONVBLOCK_BWD = False          # this test pins the forward; the fused backward has its own below
+
   def run(fused, train):
     ops.FUSED_CONVBLOCK = fused
     try:
@@ -561,6 +563,84 @@ def test_convblock_fused_equals_per_layer_path(hip, shape):
         assert torch.equal(a, c)
     finally:
       ops.FUSED_CONVBLOCK = True
+  ops.FUSED_CONVBLOCK_BWD = True
+
+
+@pytest.mark.parametrize('need_dx', [True, False], ids=['dx', 'nodx'])
+@pytest.mark.parametrize('complex_out', [False, True], ids=['padded', 'complex'])
+@pytest.mark.parametrize('shape', [(2, 64, 64), (1, 256, 256), (3, 40, 56), (2, 17, 33), (8, 128, 128)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_convblock_fused_backward(hip, shape, complex_out, need_dx):
+  """csmri_convblock_fused_bwd (the backward of RecNet's conv block, reference models/recnet.py:29-62 under
+  loss.backward() of training/runner.py:163, as ONE launch + the slab reduction) against (a) the six-kernel per-layer
+  backward it replaces and (b) torch autograd on the CPU with the same bf16-rounded operands and saved activations.
+  The two device paths round the intermediate gradients dA2 / dA1 to bf16 from fp32 sums taken in different orders,
+  so they agree to bf16 rounding (dX relative L2 <= 4e-3, weight / bias gradients <= 3e-3), and the fused path's
+  distance from the oracle must not exceed the per-layer path's by more than 30 % (+ 1e-4)."""
+  ops = hip.ops
+  b, h, w = shape
+  g = torch.Generator().manual_seed(h * 7 + w + b)
+  ws = [torch.randn(32, 2, 3, 3, generator=g) * 0.4, torch.randn(32, 32, 3, 3, generator=g) * 0.08,
+        torch.randn(2, 32, 3, 3, generator=g) * 0.08]
+  bs = [torch.randn(32, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(2, generator=g) * 0.1]
+  x = torch.randn(b, 2, h, w, generator=g)
+  gy = torch.randn(b, 2, h, w, generator=g)
+
+  def run(fused_bwd):
+    ops.FUSED_CONVBLOCK_BWD = fused_bwd
+    try:
+      params = [(torch.nn.Parameter(wt.clone().cuda()), torch.nn.Parameter(bi.clone().cuda())) for wt, bi in zip(ws, bs)]
+      plan = [(ops.ConvLayer(wp, bp, 1, (1, 1, 1, 1), 'zero', torch.bfloat16), 0.01 if i < 2 else 1.0)
+              for i, (wp, bp) in enumerate(params)]
+      xd = to_dev_nhwc(x, torch.bfloat16).requires_grad_(need_dx)
+      y = ops.ConvActStack.apply(xd, plan, ('complex', torch.float32) if complex_out else torch.float32,
+                                 *[t for pr in params for t in pr])
+      gd = to_dev_nhwc(gy, torch.float32)
+      log = ops.LAUNCH_LOG = []
+      y.backward(gd[..., :2].contiguous() if complex_out else gd)
+      ops.join_wgrad_stream()
+      torch.cuda.synchronize()
+      names = [e[1] for e in log]
+      ops.LAUNCH_LOG = None
+      return ([from_dev_nhwc(xd.grad, 2)] if need_dx else []) + [t.grad.cpu().clone() for pr in params for t in pr], names
+    finally:
+      ops.FUSED_CONVBLOCK_BWD = True
+      ops.LAUNCH_LOG = None
+  gf, nf = run(True)
+  gu, nu = run(False)
+  assert nf == ['convblock_bwd_kernel'], nf
+  assert 'convblock_bwd_kernel' not in nu and len(nu) >= 5, nu
+  # oracle: autograd through the reference block with the forward's bf16 roundings (operands, saved activations)
+  xr = x.bfloat16().float().requires_grad_(True)
+  wr = [wt.bfloat16().float().requires_grad_(True) for wt in ws]
+  br = [bi.clone().requires_grad_(True) for bi in bs]
+  r = xr
+  for i in range(3):
+    r = F.conv2d(F.pad(r, (1, 1, 1, 1)), wr[i], br[i])
+    if i < 2:
+      r = F.leaky_relu(r, 0.01)
+      r = r + (r.detach().bfloat16().float() - r.detach())      # value rounded to bf16, gradient straight through
+  r.backward(gy.bfloat16().float())
+  want = ([xr.grad] if need_dx else []) + [t.grad for pr in zip(wr, br) for t in pr]
+  labels = (['dx'] if need_dx else []) + ['dw1', 'db1', 'dw2', 'db2', 'dw3', 'db3']
+  for lab, a, c, o in zip(labels, gf, gu, want):
+    e_fu, e_fo, e_uo = rel_l2(a, c), rel_l2(a, o), rel_l2(c, o)
+    print('convblock bwd %s %-4s fused vs per-layer %.2e | vs oracle: fused %.2e per-layer %.2e' % (shape, lab, e_fu, e_fo, e_uo))
+    assert e_fu < (4e-3 if lab == 'dx' else 3e-3), (lab, e_fu)
+    assert e_fo <= 1.3 * e_uo + 1e-4, (lab, e_fo, e_uo)
+  if need_dx:
+    xg = None
+  # pad channels of dX stay exact zeros
+  if need_dx:
+    ops.FUSED_CONVBLOCK_BWD = True
+    params = [(torch.nn.Parameter(wt.clone().cuda()), torch.nn.Parameter(bi.clone().cuda())) for wt, bi in zip(ws, bs)]
+    plan = [(ops.ConvLayer(wp, bp, 1, (1, 1, 1, 1), 'zero', torch.bfloat16), 0.01 if i < 2 else 1.0)
+            for i, (wp, bp) in enumerate(params)]
+    xd = to_dev_nhwc(x, torch.bfloat16).requires_grad_(True)
+    y = ops.ConvActStack.apply(xd, plan, torch.float32, *[t for pr in params for t in pr])
+    y.backward(to_dev_nhwc(gy, torch.float32))
+    ops.join_wgrad_stream()
+    assert float(xd.grad[..., 2:].float().abs().max()) == 0.0
 
 
 def test_layout_roundtrip(hip):
