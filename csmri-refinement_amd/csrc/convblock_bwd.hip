@@ -44,8 +44,8 @@ struct BBParams {
 #define BB_PW 22
 #define BB_G3PX 496                          // 22 x 22 + the reach of stage 1's last fragment (zero filled)
 #define BB_A2PX 448                          // 20 x 22 = 440 positions (28 fragments)
-#define BB_A1PX 400                          // 18 x 22 = 396 positions (25 fragments)
-#define BB_XPX 400
+#define BB_A1PX 448                          // 18 x 22 = 396 positions (25 fragments); 7 LDS-DMA pieces of 64 pixels
+#define BB_XPX 448
 #define BB_A2F 28
 #define BB_A1F 25
 #define BB_PS2 (BB_A2PX * 16 + 64)           // plane strides: 64 mod 256 (transposed reads of a plane pair: no conflict)
@@ -73,6 +73,10 @@ __device__ __forceinline__ f32x4_t bb_unpack4(u32x2_t u) {
   return (f32x4_t){__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16),
                    __uint_as_float(u[1] & 0xffff0000u)};
 }
+
+__device__ __attribute__((aligned(16))) char bb_zero_page[16];
+typedef __attribute__((address_space(1))) const void* bb_gptr_t;
+typedef __attribute__((address_space(3))) void* bb_lptr_t;
 
 __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,19 +109,16 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
     for (int s = wv; s < 9; s += 2)
       *(u32x4_t*)(W3L + (s * 64 + lane) * 16) = *(const u32x4_t*)(p.wd1 + ((size_t)r16 * p.kp1 + s * 32 + g * 8) * 2);
   }
-  // zero the image tails that junk columns read (never written again): G3 pixels 484.., D2 440.., D1 396.., A* likewise
+  // zero the image tails that junk columns read (never written again): G3 pixels 484.., D2 440.., D1 396..
   for (int i = tid; i < (BB_G3PX - 484); i += BB_THREADS) *(u32x4_t*)(G3 + (484 + i) * 16) = (u32x4_t){0u, 0u, 0u, 0u};
   for (int i = tid; i < 4 * (BB_A2PX - 440); i += BB_THREADS) {
     const int k = i / (BB_A2PX - 440), q = 440 + i % (BB_A2PX - 440);
     *(u32x4_t*)(D2 + k * BB_PS2 + q * 16) = (u32x4_t){0u, 0u, 0u, 0u};
-    *(u32x4_t*)(A2 + k * BB_PS2 + q * 16) = (u32x4_t){0u, 0u, 0u, 0u};
   }
   for (int i = tid; i < 4 * (BB_A1PX - 396); i += BB_THREADS) {
     const int k = i / (BB_A1PX - 396), q = 396 + i % (BB_A1PX - 396);
     *(u32x4_t*)(D1 + k * BB_PS1 + q * 16) = (u32x4_t){0u, 0u, 0u, 0u};
-    *(u32x4_t*)(A1 + k * BB_PS1 + q * 16) = (u32x4_t){0u, 0u, 0u, 0u};
   }
-  for (int i = tid; i < (BB_XPX - 396); i += BB_THREADS) *(u32x4_t*)(XI + (396 + i) * 16) = (u32x4_t){0u, 0u, 0u, 0u};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -144,69 +145,65 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
   const int tplane = tp >> 1;                                    // which plane of the group's pair
 
   const int ntiles = p.B * p.tiles_x * p.tiles_y;
+  const int tpi = p.tiles_x * p.tiles_y;
+  // ---- input pipeline: the activations of tile t + 1 stream into their LDS images by LDS-DMA while tile t is
+  // multiplied -- a2 (and dY, through registers: it needs the fp32 -> bf16 conversion) as soon as phase 1 has
+  // consumed them, a1 after phase 2, x after phase 3.  A DMA piece = 64 consecutive pixels of one plane (1 KiB);
+  // out-of-image pixels and the images' tails come from a zero page.
+  auto dma_image = [&](int tl, const char* src, int sps, char* img, int pstride, int planes, int oy, int ox, int rows) {
+    const int b_ = tl / tpi, r_ = tl - b_ * tpi, ty_ = r_ / p.tiles_x, tx_ = r_ - ty_ * p.tiles_x;
+    const int yb = ty_ * BB_T - oy, xb = tx_ * BB_T - ox;
+    for (int i = wv; i < planes * 7; i += 8) {
+      const int k = i / 7, c = i - k * 7, pp = c * 64 + lane;
+      const int py = (pp * 2979) >> 16, px = pp - py * BB_PW;
+      const int y = yb + py, x = xb + px;
+      const bool ok = py < rows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const char* g_ = ok ? src + ((((size_t)b_ * p.H + y) * p.W + x) * (size_t)sps + k * 8) * 2 : bb_zero_page;
+      __builtin_amdgcn_global_load_lds((bb_gptr_t)g_, (bb_lptr_t)(img + k * pstride + c * 1024), 16, 0, 0);
+    }
+  };
+  unsigned vg3 = 0u;                            // this thread's dY pixel of the NEXT tile (bf16 pair)
+  auto load_g3 = [&](int tl) {
+    vg3 = 0u;
+    if (tid >= 484) return;
+    const int b_ = tl / tpi, r_ = tl - b_ * tpi, ty_ = r_ / p.tiles_x, tx_ = r_ - ty_ * p.tiles_x;
+    const int py = tid / BB_PW, px = tid - py * BB_PW;
+    const int y = ty_ * BB_T - 3 + py, x = tx_ * BB_T - 3 + px;
+    if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+      const size_t pix = ((size_t)b_ * p.H + y) * p.W + x;
+      if (p.gy_dt == CSMRI_F32) {
+        const f32x2_t v = *(const f32x2_t*)(p.gy + pix * (size_t)p.gyps * 4);
+        vg3 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+      } else {
+        vg3 = *(const unsigned*)(p.gy + pix * (size_t)p.gyps * 2);
+      }
+    }
+  };
+  const int gpy = tid / BB_PW, gpx = tid - gpy * BB_PW;
+  const bool g3_central = tid < 484 && gpy >= 3 && gpy < 3 + BB_T && gpx >= 3 && gpx < 3 + BB_T;
+  if ((int)blockIdx.x < ntiles) {
+    load_g3(blockIdx.x);
+    dma_image(blockIdx.x, p.a2, p.a2ps, A2, BB_PS2, 4, 2, 2, 20);
+    dma_image(blockIdx.x, p.a1, p.a1ps, A1, BB_PS1, 4, 1, 1, 18);
+    dma_image(blockIdx.x, p.x, p.xps, XI, 0, 1, 1, 1, 18);
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int t = tile;
-    const int b = t / (p.tiles_x * p.tiles_y);
-    t -= b * p.tiles_x * p.tiles_y;
+    const int b = t / tpi;
+    t -= b * tpi;
     const int tyi = t / p.tiles_x, txi = t - tyi * p.tiles_x;
     const int y0 = tyi * BB_T, x0 = txi * BB_T;
     const bool border = y0 < 2 || x0 < 2 || y0 + BB_T + 2 > p.H || x0 + BB_T + 2 > p.W;
+    const int next = tile + gridDim.x;
+    const bool has_next = next < ntiles;
 
-    // ---- stage the tile's inputs (all loads in flight together, then the LDS stores) ----------------------------
-    {
-      u32x4_t vg = (u32x4_t){0u, 0u, 0u, 0u}, vx = vg, va2[4], va1[4];
-      // G3: 22 x 22, origin (y0 - 3, x0 - 3)
-      if (tid < 484) {
-        const int py = tid / BB_PW, px = tid - py * BB_PW;
-        const int y = y0 - 3 + py, x = x0 - 3 + px;
-        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
-          const size_t pix = ((size_t)b * p.H + y) * p.W + x;
-          if (p.gy_dt == CSMRI_F32) {
-            const f32x2_t v = *(const f32x2_t*)(p.gy + pix * (size_t)p.gyps * 4);
-            vg[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-          } else {
-            vg[0] = *(const unsigned*)(p.gy + pix * (size_t)p.gyps * 2);
-          }
-          // bias gradient of layer 3: the tile's own 16 x 16 pixels, on the bf16 values the products see
-          if (py >= 3 && py < 3 + BB_T && px >= 3 && px < 3 + BB_T) {
-            bs3[0] += __uint_as_float(vg[0] << 16); bs3[1] += __uint_as_float(vg[0] & 0xffff0000u);
-          }
-        }
-      }
-      // X: 18 rows x 22, origin (y0 - 1, x0 - 1)
-      if (tid < 396) {
-        const int py = tid / BB_PW, px = tid - py * BB_PW;
-        const int y = y0 - 1 + py, x = x0 - 1 + px;
-        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-          vx = *(const u32x4_t*)(p.x + (((size_t)b * p.H + y) * p.W + x) * (size_t)p.xps * 2);
-      }
-      // A2: 20 rows x 22, origin (y0 - 2, x0 - 2); A1: 18 rows x 22, origin (y0 - 1, x0 - 1); 4 planes per pixel
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = tid + BB_THREADS * i, pp = idx >> 2, k = idx & 3;
-        va2[i] = (u32x4_t){0u, 0u, 0u, 0u}; va1[i] = va2[i];
-        if (pp < 440) {
-          const int py = pp / BB_PW, px = pp - py * BB_PW;
-          const int y = y0 - 2 + py, x = x0 - 2 + px;
-          if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-            va2[i] = *(const u32x4_t*)(p.a2 + ((((size_t)b * p.H + y) * p.W + x) * (size_t)p.a2ps + k * 8) * 2);
-        }
-        if (pp < 396) {
-          const int py = pp / BB_PW, px = pp - py * BB_PW;
-          const int y = y0 - 1 + py, x = x0 - 1 + px;
-          if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-            va1[i] = *(const u32x4_t*)(p.a1 + ((((size_t)b * p.H + y) * p.W + x) * (size_t)p.a1ps + k * 8) * 2);
-        }
-      }
-      if (tid < 484) *(u32x4_t*)(G3 + tid * 16) = vg;
-      if (tid < 396) *(u32x4_t*)(XI + tid * 16) = vx;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = tid + BB_THREADS * i, pp = idx >> 2, k = idx & 3;
-        if (pp < 440) *(u32x4_t*)(A2 + k * BB_PS2 + pp * 16) = va2[i];
-        if (pp < 396) *(u32x4_t*)(A1 + k * BB_PS1 + pp * 16) = va1[i];
-      }
+    // ---- this tile's dY pixel into its image (bias gradient of layer 3 on the bf16 values the products see); all of
+    // this tile's DMA pieces were issued during the previous tile: wait for mine, the barrier publishes everybody's
+    if (tid < 484) {
+      *(u32x4_t*)(G3 + tid * 16) = (u32x4_t){vg3, 0u, 0u, 0u};
+      if (g3_central) { bs3[0] += __uint_as_float(vg3 << 16); bs3[1] += __uint_as_float(vg3 & 0xffff0000u); }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // ---- phase 1: dA2 = conv(G3, W3 flipped) * lrelu'(a2) on 20 rows (origin y0 - 2, x0 - 2) ---------------------
@@ -241,21 +238,31 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
       if (central) { bs2[0] += bb_unpack4(o0); bs2[1] += bb_unpack4(o1); }
     }
     // ---- ... and the weight gradient of layer 3: x = a2 (patch origin = image origin + (1, 1)), dY = G3 centre ------
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int unit = wv + 8 * a;
-      if (unit >= 18) break;
-      const int tap = unit % 9, cf = unit / 9, ty = tap / 3, tx = tap - ty * 3;
-      const char* xb = A2 + (cf * 2 + tplane) * BB_PS2 + ((1 + ty) * BB_PW + 1 + tx + trow) * 16 + tquad;
+    {
       const char* yb = G3 + (3 * BB_PW + 3 + trow) * 16 + tquad;            // one plane: both halves of the pair read it
+      const char* xb[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int unit = min(wv + 8 * a, 17), tap = unit % 9, cf = unit / 9, ty = tap / 3, tx = tap - ty * 3;
+        xb[a] = A2 + (cf * 2 + tplane) * BB_PS2 + ((1 + ty) * BB_PW + 1 + tx + trow) * 16 + tquad;
+      }
 #pragma unroll 2
       for (int kc = 0; kc < 8; ++kc) {
         const int ko = kc * 2 * BB_PW * 16;
-        const bf16x8_t xf = bb_tr(xb + ko, xb + ko + 64), yf = bb_tr(yb + ko, yb + ko + 64);
-        aw3[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf, aw3[a], 0, 0, 0);
+        const bf16x8_t yf = bb_tr(yb + ko, yb + ko + 64);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (wv + 8 * a >= 18) break;                                      // wave-uniform
+          aw3[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb_tr(xb[a] + ko, xb[a] + ko + 64), yf, aw3[a], 0, 0, 0);
+        }
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // dA2 complete; dY and a2 images are free
+    if (has_next) {
+      load_g3(next);
+      dma_image(next, p.a2, p.a2ps, A2, BB_PS2, 4, 2, 2, 20);
+    }
 
     // ---- phase 2: dA1 = conv(dA2, W2 flipped) * lrelu'(a1) on 18 rows (origin y0 - 1, x0 - 1) --------------------
     for (int j = wv; j < BB_A1F; j += 8) {
@@ -287,24 +294,33 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
       *(u32x2_t*)(D1 + so1) = o1;
       if (central) { bs1[0] += bb_unpack4(o0); bs1[1] += bb_unpack4(o1); }
     }
-    // ---- ... and the weight gradient of layer 2: x = a1 (patch origin = image origin), dY = dA2 centre (2, 2) -------
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int unit = wv + 8 * a;
-      if (unit >= 18) break;
-      const int tap = unit % 9, cf = unit / 9, ty = tap / 3, tx = tap - ty * 3;
-      const char* xb = A1 + (cf * 2 + tplane) * BB_PS1 + (ty * BB_PW + tx + trow) * 16 + tquad;
+    // ---- ... and the weight gradient of layer 2: x = a1 (patch origin = image origin), dY = dA2 centre (2, 2).  The dY
+    // fragments of a K chunk are read once and shared by this wave's units (3 transposed reads per MFMA otherwise:
+    // past what the LDS delivers next to the matrix pipe)
+    {
       const char* yb = D2 + tplane * BB_PS2 + (2 * BB_PW + 2 + trow) * 16 + tquad;
+      const char* xb[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int unit = min(wv + 8 * a, 17), tap = unit % 9, cf = unit / 9, ty = tap / 3, tx = tap - ty * 3;
+        xb[a] = A1 + (cf * 2 + tplane) * BB_PS1 + (ty * BB_PW + tx + trow) * 16 + tquad;
+      }
 #pragma unroll 2
       for (int kc = 0; kc < 8; ++kc) {
         const int ko = kc * 2 * BB_PW * 16;
-        const bf16x8_t xf = bb_tr(xb + ko, xb + ko + 64);
         const bf16x8_t yf0 = bb_tr(yb + ko, yb + ko + 64), yf1 = bb_tr(yb + 2 * BB_PS2 + ko, yb + 2 * BB_PS2 + ko + 64);
-        aw2[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf0, aw2[a][0], 0, 0, 0);
-        aw2[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf1, aw2[a][1], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (wv + 8 * a >= 18) break;                                      // wave-uniform
+          const bf16x8_t xf = bb_tr(xb[a] + ko, xb[a] + ko + 64);
+          aw2[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf0, aw2[a][0], 0, 0, 0);
+          aw2[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf1, aw2[a][1], 0, 0, 0);
+        }
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // dA1 complete; the a1 image is free
+    if (has_next) dma_image(next, p.a1, p.a1ps, A1, BB_PS1, 4, 1, 1, 18);
 
     // ---- phase 3: dX = conv(dA1, W1 flipped) on the 16 x 16 tile: fragment j = output row j --------------------------
     if (p.dx) {
@@ -338,7 +354,9 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
         aw1[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf1, aw1[1], 0, 0, 0);
       }
     }
-    __syncthreads();          // (the next tile's staging overwrites the images)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // the x image is free (and dA2 / dA1 may be overwritten)
+    if (has_next) dma_image(next, p.x, p.xps, XI, 0, 1, 1, 1, 18);
   }
 
   // ---- one slab per layer and workgroup: [Cout_p][NK], NK index = tap * Cin_p + ci; D row = 4g + reg, column = r16 ---
