@@ -127,13 +127,15 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
   __syncthreads();
 
   // ---- weight-gradient accumulators (persist over the tiles of this workgroup) ----------------------------------
-  // units: layer 3 and 2: (tap, 16-channel half of ci) = 18 units, wave wv owns units wv, wv + 8, wv + 16;
+  // units: layer 3 and 2: (tap, 16-channel half of ci) = 18 units, wave wv owns units 7 - wv, 15 - wv, 23 - wv (< 18):
+  // the waves that get a fourth data-gradient fragment in a phase (the low ones) get two units, the high ones three;
   //        layer 1: tap PAIRS (8 channels each) = 5 units, waves 0..4 own one each
   f32x4_t aw3[3], aw2[3][2], aw1[2];
 #pragma unroll
   for (int a = 0; a < 3; ++a) { aw3[a] = zero4; aw2[a][0] = zero4; aw2[a][1] = zero4; }
   aw1[0] = zero4; aw1[1] = zero4;
-  f32x4_t bs2[2] = {zero4, zero4}, bs1[2] = {zero4, zero4};      // bias-gradient partial sums of this lane
+  f32x4_t bs2[2] = {zero4, zero4};                               // bias gradient of layer 2: ones x dY products (wave 3)
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
   float bs3[2] = {0.f, 0.f};
 
   // transposed-read lane constants: K chunk kc = tile rows 2kc, 2kc + 1; this lane addresses pixel klo = 8 * (lane>>4) +
@@ -208,42 +210,45 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
 
     // ---- phase 1: dA2 = conv(G3, W3 flipped) * lrelu'(a2) on 20 rows (origin y0 - 2, x0 - 2) ---------------------
     // K step s = filter row, lane group g = tap column (column 3 meets zero weights)
-    for (int j = wv; j < BB_A2F; j += 8) {
-      bf16x8_t xf[3];
-      const char* src = G3 + (j * 16 + r16 + g) * 16;
+    auto stage1 = [&](auto border_tag) {
+      constexpr bool BORDER = decltype(border_tag)::value;
+      for (int j = wv; j < BB_A2F; j += 8) {
+        bf16x8_t xf[3];
+        const char* src = G3 + (j * 16 + r16 + g) * 16;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) xf[s] = *(const bf16x8_t*)(src + s * BB_PW * 16);
-      f32x4_t acc0 = zero4, acc1 = zero4;
+        for (int s = 0; s < 3; ++s) xf[s] = *(const bf16x8_t*)(src + s * BB_PW * 16);
+        f32x4_t acc0 = zero4, acc1 = zero4;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(W1L + (s * 64 + lane) * 16), xf[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(W1L + ((3 + s) * 64 + lane) * 16), xf[s], acc1, 0, 0, 0);
+        for (int s = 0; s < 3; ++s) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(W1L + (s * 64 + lane) * 16), xf[s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(W1L + ((3 + s) * 64 + lane) * 16), xf[s], acc1, 0, 0, 0);
+        }
+        const int q = j * 16 + r16;
+        float one = 1.f, sl = p.slope;                               // derivative factors of an in-image pixel
+        if (BORDER) {
+          const int qy = (q * 2979) >> 16, qx = q - qy * BB_PW;      // q / 22 for q < 448
+          if (!((unsigned)(y0 - 2 + qy) < (unsigned)p.H && (unsigned)(x0 - 2 + qx) < (unsigned)p.W)) { one = 0.f; sl = 0.f; }
+        }
+        const int so0 = (g >> 1) * BB_PS2 + q * 16 + (g & 1) * 8, so1 = so0 + 2 * BB_PS2;
+        const f32x4_t m0 = bb_unpack4(*(const u32x2_t*)(A2 + so0)), m1 = bb_unpack4(*(const u32x2_t*)(A2 + so1));
+        f32x4_t v0, v1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v0[r] = acc0[r] * (m0[r] > 0.f ? one : sl);
+          v1[r] = acc1[r] * (m1[r] > 0.f ? one : sl);
+        }
+        *(u32x2_t*)(D2 + so0) = pack4_bf16(v0);
+        *(u32x2_t*)(D2 + so1) = pack4_bf16(v1);
       }
-      const int q = j * 16 + r16;
-      const int qy = (q * 2979) >> 16, qx = q - qy * BB_PW;          // q / 22 for q < 448
-      float keep = 1.f;
-      if (border) keep = ((unsigned)(y0 - 2 + qy) < (unsigned)p.H && (unsigned)(x0 - 2 + qx) < (unsigned)p.W) ? 1.f : 0.f;
-      const bool central = qy >= 2 && qy < 2 + BB_T && qx >= 2 && qx < 2 + BB_T;
-      const int so0 = (g >> 1) * BB_PS2 + q * 16 + (g & 1) * 8, so1 = so0 + 2 * BB_PS2;
-      const f32x4_t m0 = bb_unpack4(*(const u32x2_t*)(A2 + so0)), m1 = bb_unpack4(*(const u32x2_t*)(A2 + so1));
-      f32x4_t v0, v1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v0[r] = acc0[r] * (m0[r] > 0.f ? 1.f : p.slope) * keep;
-        v1[r] = acc1[r] * (m1[r] > 0.f ? 1.f : p.slope) * keep;
-      }
-      const u32x2_t o0 = pack4_bf16(v0), o1 = pack4_bf16(v1);
-      *(u32x2_t*)(D2 + so0) = o0;
-      *(u32x2_t*)(D2 + so1) = o1;
-      if (central) { bs2[0] += bb_unpack4(o0); bs2[1] += bb_unpack4(o1); }
-    }
+    };
+    if (border) stage1(std::true_type{}); else stage1(std::false_type{});
     // ---- ... and the weight gradient of layer 3: x = a2 (patch origin = image origin + (1, 1)), dY = G3 centre ------
     {
       const char* yb = G3 + (3 * BB_PW + 3 + trow) * 16 + tquad;            // one plane: both halves of the pair read it
       const char* xb[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const int unit = min(wv + 8 * a, 17), tap = unit % 9, cf = unit / 9, ty = tap / 3, tx = tap - ty * 3;
+        const int unit = min(7 - wv + 8 * a, 17), tap = unit % 9, cf = unit / 9, ty = tap / 3, tx = tap - ty * 3;
         xb[a] = A2 + (cf * 2 + tplane) * BB_PS2 + ((1 + ty) * BB_PW + 1 + tx + trow) * 16 + tquad;
       }
 #pragma unroll 2
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
         const bf16x8_t yf = bb_tr(yb + ko, yb + ko + 64);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          if (wv + 8 * a >= 18) break;                                      // wave-uniform
+          if (7 - wv + 8 * a >= 18) break;                                      // wave-uniform
           aw3[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb_tr(xb[a] + ko, xb[a] + ko + 64), yf, aw3[a], 0, 0, 0);
         }
       }
@@ -265,35 +270,38 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
     }
 
     // ---- phase 2: dA1 = conv(dA2, W2 flipped) * lrelu'(a1) on 18 rows (origin y0 - 1, x0 - 1) --------------------
-    for (int j = wv; j < BB_A1F; j += 8) {
-      bf16x8_t xf[9];
-      const char* src = D2 + g * BB_PS2 + (j * 16 + r16) * 16;
+    auto stage2 = [&](auto border_tag) {
+      constexpr bool BORDER = decltype(border_tag)::value;
+      for (int j = wv; j < BB_A1F; j += 8) {
+        bf16x8_t xf[9];
+        const char* src = D2 + g * BB_PS2 + (j * 16 + r16) * 16;
 #pragma unroll
-      for (int s = 0; s < 9; ++s) xf[s] = *(const bf16x8_t*)(src + ((s / 3) * BB_PW + (s % 3)) * 16);
-      f32x4_t acc0 = zero4, acc1 = zero4;
+        for (int s = 0; s < 9; ++s) xf[s] = *(const bf16x8_t*)(src + ((s / 3) * BB_PW + (s % 3)) * 16);
+        f32x4_t acc0 = zero4, acc1 = zero4;
 #pragma unroll
-      for (int s = 0; s < 9; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w2f[0][s]), xf[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w2f[1][s]), xf[s], acc1, 0, 0, 0);
+        for (int s = 0; s < 9; ++s) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w2f[0][s]), xf[s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w2f[1][s]), xf[s], acc1, 0, 0, 0);
+        }
+        const int q = j * 16 + r16;
+        float one = 1.f, sl = p.slope;
+        if (BORDER) {
+          const int qy = (q * 2979) >> 16, qx = q - qy * BB_PW;
+          if (!((unsigned)(y0 - 1 + qy) < (unsigned)p.H && (unsigned)(x0 - 1 + qx) < (unsigned)p.W)) { one = 0.f; sl = 0.f; }
+        }
+        const int so0 = (g >> 1) * BB_PS1 + q * 16 + (g & 1) * 8, so1 = so0 + 2 * BB_PS1;
+        const f32x4_t m0 = bb_unpack4(*(const u32x2_t*)(A1 + so0)), m1 = bb_unpack4(*(const u32x2_t*)(A1 + so1));
+        f32x4_t v0, v1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v0[r] = acc0[r] * (m0[r] > 0.f ? one : sl);
+          v1[r] = acc1[r] * (m1[r] > 0.f ? one : sl);
+        }
+        *(u32x2_t*)(D1 + so0) = pack4_bf16(v0);
+        *(u32x2_t*)(D1 + so1) = pack4_bf16(v1);
       }
-      const int q = j * 16 + r16;
-      const int qy = (q * 2979) >> 16, qx = q - qy * BB_PW;
-      float keep = 1.f;
-      if (border) keep = ((unsigned)(y0 - 1 + qy) < (unsigned)p.H && (unsigned)(x0 - 1 + qx) < (unsigned)p.W) ? 1.f : 0.f;
-      const bool central = qy >= 1 && qy < 1 + BB_T && qx >= 1 && qx < 1 + BB_T;
-      const int so0 = (g >> 1) * BB_PS1 + q * 16 + (g & 1) * 8, so1 = so0 + 2 * BB_PS1;
-      const f32x4_t m0 = bb_unpack4(*(const u32x2_t*)(A1 + so0)), m1 = bb_unpack4(*(const u32x2_t*)(A1 + so1));
-      f32x4_t v0, v1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v0[r] = acc0[r] * (m0[r] > 0.f ? 1.f : p.slope) * keep;
-        v1[r] = acc1[r] * (m1[r] > 0.f ? 1.f : p.slope) * keep;
-      }
-      const u32x2_t o0 = pack4_bf16(v0), o1 = pack4_bf16(v1);
-      *(u32x2_t*)(D1 + so0) = o0;
-      *(u32x2_t*)(D1 + so1) = o1;
-      if (central) { bs1[0] += bb_unpack4(o0); bs1[1] += bb_unpack4(o1); }
-    }
+    };
+    if (border) stage2(std::true_type{}); else stage2(std::false_type{});
     // ---- ... and the weight gradient of layer 2: x = a1 (patch origin = image origin), dY = dA2 centre (2, 2).  The dY
     // fragments of a K chunk are read once and shared by this wave's units (3 transposed reads per MFMA otherwise:
     // past what the LDS delivers next to the matrix pipe)
@@ -302,16 +310,20 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
       const char* xb[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const int unit = min(wv + 8 * a, 17), tap = unit % 9, cf = unit / 9, ty = tap / 3, tx = tap - ty * 3;
+        const int unit = min(7 - wv + 8 * a, 17), tap = unit % 9, cf = unit / 9, ty = tap / 3, tx = tap - ty * 3;
         xb[a] = A1 + (cf * 2 + tplane) * BB_PS1 + (ty * BB_PW + tx + trow) * 16 + tquad;
       }
 #pragma unroll 2
       for (int kc = 0; kc < 8; ++kc) {
         const int ko = kc * 2 * BB_PW * 16;
         const bf16x8_t yf0 = bb_tr(yb + ko, yb + ko + 64), yf1 = bb_tr(yb + 2 * BB_PS2 + ko, yb + 2 * BB_PS2 + ko + 64);
+        if (wv == 3) {                                                        // bias gradient of layer 2 (row 0 of ones x dY)
+          bs2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf0, bs2[0], 0, 0, 0);
+          bs2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf1, bs2[1], 0, 0, 0);
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          if (wv + 8 * a >= 18) break;                                      // wave-uniform
+          if (7 - wv + 8 * a >= 18) break;                                      // wave-uniform
           const bf16x8_t xf = bb_tr(xb[a] + ko, xb[a] + ko + 64);
           aw2[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf0, aw2[a][0], 0, 0, 0);
           aw2[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf1, aw2[a][1], 0, 0, 0);
@@ -341,14 +353,14 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
     // ---- ... and the weight gradient of layer 1: x = block input, 8 channels: a fragment is a PAIR of taps x 8
     // channels (lanes tp = 0, 1 address the first tap, tp = 2, 3 the second; the last pair repeats tap 8, its second
     // half is never written); dY = dA1 centre (1, 1)
-    if (wv < 5) {
+    if (wv < 6) {                                 // (wave 5: the bias gradient of layer 1 instead of a tap pair)
       const int tap = min(2 * wv + tplane, 8), ty = tap / 3, tx = tap - ty * 3;
       const char* xb = XI + (ty * BB_PW + tx + trow) * 16 + tquad;
       const char* yb = D1 + tplane * BB_PS1 + (1 * BB_PW + 1 + trow) * 16 + tquad;
 #pragma unroll 2
       for (int kc = 0; kc < 8; ++kc) {
         const int ko = kc * 2 * BB_PW * 16;
-        const bf16x8_t xf = bb_tr(xb + ko, xb + ko + 64);
+        const bf16x8_t xf = wv == 5 ? ones : bb_tr(xb + ko, xb + ko + 64);
         const bf16x8_t yf0 = bb_tr(yb + ko, yb + ko + 64), yf1 = bb_tr(yb + 2 * BB_PS1 + ko, yb + 2 * BB_PS1 + ko + 64);
         aw1[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf0, aw1[0], 0, 0, 0);
         aw1[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf1, aw1[1], 0, 0, 0);
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
   const int z = blockIdx.x, Z = gridDim.x;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const int unit = wv + 8 * a;
+    const int unit = 7 - wv + 8 * a;
     if (unit >= 18) break;
     const int tap = unit % 9, cf = unit / 9;
     if (r16 < 8) *(f32x4_t*)(p.slab3 + ((size_t)z * 8 + r16) * 288 + tap * 32 + cf * 16 + g * 4) = aw3[a];
@@ -380,30 +392,28 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
     }
   }
   if (p.want_db) {
-    // bias partial rows behind the slabs: lanes of a wave over their positions (r16), then the 8 waves through LDS
+    // bias partial rows behind the slabs.  Layers 2 and 1: row 0 of the ones products (lanes g == 0, register 0, column
+    // r16 = channel within the 16-channel fragment); layer 3: per-thread sums of the staging pass, waves through LDS
+    if (wv == 3 && g == 0) {
+      p.slab2[(size_t)Z * 32 * 288 + (size_t)z * 32 + r16] = bs2[0][0];
+      p.slab2[(size_t)Z * 32 * 288 + (size_t)z * 32 + 16 + r16] = bs2[1][0];
+    }
+    if (wv == 5 && g == 0) {
+      p.slab1[(size_t)Z * 32 * 72 + (size_t)z * 32 + r16] = aw1[0][0];
+      p.slab1[(size_t)Z * 32 * 72 + (size_t)z * 32 + 16 + r16] = aw1[1][0];
+    }
     __syncthreads();
-    float* red = (float*)smem;                       // [8 waves][16 + 16 + 2 ... ]: 40 floats per wave
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v2 = bs2[n][r], v1 = bs1[n][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { v2 += __shfl_xor(v2, o); v1 += __shfl_xor(v1, o); }
-        if (r16 == 0) { red[wv * 80 + n * 16 + 4 * g + r] = v2; red[wv * 80 + 32 + n * 16 + 4 * g + r] = v1; }
-      }
+    float* red = (float*)smem;
     float v30 = bs3[0], v31 = bs3[1];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { v30 += __shfl_xor(v30, o); v31 += __shfl_xor(v31, o); }
-    if (lane == 0) { red[wv * 80 + 64] = v30; red[wv * 80 + 65] = v31; }
+    if (lane == 0) { red[wv * 2] = v30; red[wv * 2 + 1] = v31; }
     __syncthreads();
-    if (tid < 66) {
-      float s = 0.f;
+    if (tid < 2) {
+      float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) s += red[w * 80 + tid];
-      if (tid < 32) p.slab2[(size_t)Z * 32 * 288 + (size_t)z * 32 + tid] = s;
-      else if (tid < 64) p.slab1[(size_t)Z * 32 * 72 + (size_t)z * 32 + tid - 32] = s;
-      else p.slab3[(size_t)Z * 8 * 288 + (size_t)z * 8 + tid - 64] = s;
+      for (int w = 0; w < 8; ++w) sum += red[w * 2 + tid];
+      p.slab3[(size_t)Z * 8 * 288 + (size_t)z * 8 + tid] = sum;
     }
   }
 }
