@@ -148,19 +148,31 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
 
   const int ntiles = p.B * p.tiles_x * p.tiles_y;
   const int tpi = p.tiles_x * p.tiles_y;
-  // ---- input pipeline: the activations of tile t + 1 stream into their LDS images by LDS-DMA while tile t is
-  // multiplied -- a2 (and dY, through registers: it needs the fp32 -> bf16 conversion) as soon as phase 1 has
-  // consumed them, a1 after phase 2, x after phase 3.  A DMA piece = 64 consecutive pixels of one plane (1 KiB);
-  // out-of-image pixels and the images' tails come from a zero page.
+  // ---- input pipeline (LDS-DMA): a2 of tile t + 1 (and its dY, through registers: it needs the fp32 -> bf16
+  // conversion) stream in as soon as phase 1 of tile t has consumed them; a1 and x of tile t under its own phase 1.
+  // A DMA piece = 64 consecutive pixels of one plane (1 KiB); out-of-image pixels and the images' tails come from a
+  // zero page.
+  // piece i of an image = plane i / 7, pixels (i % 7) * 64 + lane; wave wv issues pieces wv, wv + 8, wv + 16, wv + 24.
+  // The piece's pixel (py, px) inside the region is a per-lane constant: decoded once, not per tile.
+  int dpy[4], dpx[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = wv + 8 * a, c = i % 7, pp = c * 64 + lane;
+    dpy[a] = (pp * 2979) >> 16; dpx[a] = pp - dpy[a] * BB_PW;
+  }
   auto dma_image = [&](int tl, const char* src, int sps, char* img, int pstride, int planes, int oy, int ox, int rows) {
     const int b_ = tl / tpi, r_ = tl - b_ * tpi, ty_ = r_ / p.tiles_x, tx_ = r_ - ty_ * p.tiles_x;
     const int yb = ty_ * BB_T - oy, xb = tx_ * BB_T - ox;
-    for (int i = wv; i < planes * 7; i += 8) {
-      const int k = i / 7, c = i - k * 7, pp = c * 64 + lane;
-      const int py = (pp * 2979) >> 16, px = pp - py * BB_PW;
-      const int y = yb + py, x = xb + px;
-      const bool ok = py < rows && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      const char* g_ = ok ? src + ((((size_t)b_ * p.H + y) * p.W + x) * (size_t)sps + k * 8) * 2 : bb_zero_page;
+    const bool inner = yb >= 0 && xb >= 0 && yb + rows <= p.H && xb + BB_PW <= p.W;     // workgroup-uniform
+    const char* base = src + (((size_t)b_ * p.H + yb) * p.W + xb) * (size_t)sps * 2;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int i = wv + 8 * a;
+      if (i >= planes * 7) break;
+      const int k = i / 7, c = i - k * 7;
+      bool ok = dpy[a] < rows;
+      if (!inner) ok = ok && (unsigned)(yb + dpy[a]) < (unsigned)p.H && (unsigned)(xb + dpx[a]) < (unsigned)p.W;
+      const char* g_ = ok ? base + ((size_t)(dpy[a] * p.W + dpx[a]) * sps + k * 8) * 2 : bb_zero_page;
       __builtin_amdgcn_global_load_lds((bb_gptr_t)g_, (bb_lptr_t)(img + k * pstride + c * 1024), 16, 0, 0);
     }
   };
@@ -186,8 +198,6 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
   if ((int)blockIdx.x < ntiles) {
     load_g3(blockIdx.x);
     dma_image(blockIdx.x, p.a2, p.a2ps, A2, BB_PS2, 4, 2, 2, 20);
-    dma_image(blockIdx.x, p.a1, p.a1ps, A1, BB_PS1, 4, 1, 1, 18);
-    dma_image(blockIdx.x, p.x, p.xps, XI, 0, 1, 1, 1, 18);
   }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int t = tile;
@@ -207,6 +217,10 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // a1 and x of this tile stream in under phase 1 (their images are free since the previous tile's phases 2 / 3; every
+    // wait of the loop then finds only transfers that had a whole phase to land)
+    dma_image(tile, p.a1, p.a1ps, A1, BB_PS1, 4, 1, 1, 18);
+    dma_image(tile, p.x, p.xps, XI, 0, 1, 1, 1, 18);
 
     // ---- phase 1: dA2 = conv(G3, W3 flipped) * lrelu'(a2) on 20 rows (origin y0 - 2, x0 - 2) ---------------------
     // K step s = filter row, lane group g = tap column (column 3 meets zero weights)
@@ -262,8 +276,8 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();               // dA2 complete; dY and a2 images are free
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // dA2 complete, a1 / x landed; dY and a2 images are free
     if (has_next) {
       load_g3(next);
       dma_image(next, p.a2, p.a2ps, A2, BB_PS2, 4, 2, 2, 20);
@@ -332,7 +346,6 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();               // dA1 complete; the a1 image is free
-    if (has_next) dma_image(next, p.a1, p.a1ps, A1, BB_PS1, 4, 1, 1, 18);
 
     // ---- phase 3: dX = conv(dA1, W1 flipped) on the 16 x 16 tile: fragment j = output row j --------------------------
     if (p.dx) {
@@ -368,7 +381,6 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();               // the x image is free (and dA2 / dA1 may be overwritten)
-    if (has_next) dma_image(next, p.x, p.xps, XI, 0, 1, 1, 1, 18);
   }
 
   // ---- one slab per layer and workgroup: [Cout_p][NK], NK index = tap * Cin_p + ci; D row = 4g + reg, column = r16 ---
