@@ -654,6 +654,17 @@ def test_layout_roundtrip(hip):
     assert float(t[..., 3:].float().abs().max()) == 0
     back = ops.nhwc_to_nchw(t, 3).cpu()
     assert torch.equal(back, ref)
+  # the 1- and 2-channel fast paths (four pixels per thread) incl. the dense interleaved complex form, and a shape
+  # whose H*W is not a multiple of 4 (generic kernel): bit-exact
+  for c, h, w in ((2, 16, 24), (1, 16, 24), (2, 5, 7), (2, 256, 256)):
+    x = torch.randn(3, c, h, w)
+    for dt in (torch.float32, torch.bfloat16):
+      t = ops.nchw_to_nhwc(x.cuda(), dt)
+      assert t.shape == (3, h, w, 8) and torch.equal(from_dev_nhwc(t, c), x.to(dt).float())
+      assert float(t[..., c:].float().abs().max()) == 0
+    if c == 2:
+      t2 = ops.nchw_to_nhwc(x.cuda(), torch.float32, 2)
+      assert t2.shape == (3, h, w, 2) and torch.equal(t2.cpu(), x.permute(0, 2, 3, 1).contiguous())
 
 
 def test_small_ops(hip):
