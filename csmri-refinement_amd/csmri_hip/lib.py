@@ -83,6 +83,10 @@ class ConvBlockBwdDesc(C.Structure):
   ]
 
 
+class ScalarList(C.Structure):
+  _fields_ = [('v', vp * 16), ('w', f32 * 16), ('n', i32)]
+
+
 class PackItem(C.Structure):
   _fields_ = [('w', vp), ('out', vp), ('mode', i32), ('dtype', i32), ('Cout', i32), ('Cin', i32),
               ('KH', i32), ('KW', i32)]
@@ -184,6 +188,12 @@ _SIGS = {
     'csmri_adam': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
     'csmri_adam_dev': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp]),
     'csmri_image_pool_exchange': (i32, [vp, vp, vp, vp, i32, i64, vp]),
+    'csmri_weighted_sum': (i32, [C.POINTER(ScalarList), vp, vp]),
+    'csmri_weighted_sum_bwd': (i32, [C.POINTER(ScalarList), vp, vp, vp]),
+    'csmri_bce_logits_pair': (i32, [vp, i64, f32, f32, vp, vp]),
+    'csmri_bce_logits_pair_bwd': (i32, [vp, i64, f32, f32, vp, vp, vp]),
+    'csmri_psnr_mean': (i32, [vp, i32, vp, vp]),
+    'csmri_disc_accuracy': (i32, [vp, vp, i32, i32, vp, vp]),
     'csmri_dropout2d_mask': (i32, [vp, i64, f32, vp, vp]),
     'csmri_bucket_pack_bf16': (i32, [vp, i64, vp, i64, vp]),
     'csmri_bucket_reduce': (i32, [vp, i32, i64, vp, vp]),

@@ -1530,7 +1530,7 @@ class RefineCombine(torch.autograd.Function):
     u, scale, mm = ctx.saved_tensors
     b, h, w, cp = u.shape
     gpred = gpred.contiguous()
-    du = torch.zeros(b, h, w, cp, dtype=u.dtype, device=u.device)
+    du = torch.zeros(b, h, w, cp, dtype=u.dtype, device=u.device)        # (pad channels must be exact zeros)
     part = torch.empty(1026, dtype=torch.float32, device=u.device)
     lib.call('csmri_refine_combine_bwd', gpred.data_ptr(), u.data_ptr(), dt_of(u), u.stride(2),
              scale.data_ptr(), mm.data_ptr(), b, h * w, du.data_ptr(), dt_of(du), du.stride(2),
@@ -1641,6 +1641,89 @@ class BCELogits(torch.autograd.Function):
     lib.call('csmri_bce_logits_bwd', lg.data_ptr(), lg.numel(), ctx.target, coeff.data_ptr(), 1.0,
              out.data_ptr(), 0, stream())
     return out, None
+
+
+class WeightedSum(torch.autograd.Function):
+  """total = sum_i w_i * loss_i of n <= 16 scalar loss tensors (fp32, list order): the runners'
+  `torch.sum(torch.cat(losses) * weights)` (reference adversarial_runner.py:314-320) as one launch, one more backward.
+  Call: WeightedSum.apply(weights_tuple, *losses)."""
+
+  @staticmethod
+  def forward(ctx, weights, *losses):
+    n = len(losses)
+    L = lib.ScalarList()
+    vals = [v.detach().reshape(1).float().contiguous() for v in losses]
+    for i in range(n):
+      L.v[i], L.w[i] = vals[i].data_ptr(), float(weights[i])
+    L.n = n
+    out = torch.empty(1, dtype=torch.float32, device=vals[0].device)
+    lib.call('csmri_weighted_sum', C.byref(L), out.data_ptr(), stream())
+    ctx.weights, ctx.n = [float(w) for w in weights], n
+    ctx.shapes = [(v.shape, v.dtype) for v in losses]
+    return out.reshape(())
+
+  @staticmethod
+  def backward(ctx, g):
+    L = lib.ScalarList()
+    for i in range(ctx.n):
+      L.w[i] = ctx.weights[i]
+    L.n = ctx.n
+    gg = g.reshape(1).float().contiguous()
+    out = torch.empty(ctx.n, dtype=torch.float32, device=g.device)
+    lib.call('csmri_weighted_sum_bwd', C.byref(L), gg.data_ptr(), out.data_ptr(), stream())
+    return (None,) + tuple(out[i].reshape(shape).to(dt) if dt != torch.float32 else out[i].reshape(shape)
+                           for i, (shape, dt) in enumerate(ctx.shapes))
+
+
+def weighted_sum(losses, weights):
+  """weights: host floats (list / 1-D CPU or device tensor read ONCE at construction by the caller)."""
+  _need_gpu(losses[0])
+  return WeightedSum.apply(tuple(float(w) for w in weights), *losses)
+
+
+class BCELogitsPair(torch.autograd.Function):
+  """mean BCE(sigmoid(l[:b]), t_first) + mean BCE(sigmoid(l[b:]), t_second) on the logits of a batched [first; second]
+  discriminator pass (adversarial_loss.py:71-85 GANLoss 'disc'): one launch forward, one backward, no slicing of the
+  logits in the autograd graph."""
+
+  @staticmethod
+  def forward(ctx, logits, t_first, t_second):
+    lg = logits.contiguous().float()
+    assert lg.shape[0] % 2 == 0
+    res = torch.empty(3, dtype=torch.float32, device=lg.device)
+    lib.call('csmri_bce_logits_pair', lg.data_ptr(), lg.numel() // 2, float(t_first), float(t_second), res.data_ptr(),
+             stream())
+    ctx.save_for_backward(lg)
+    ctx.t = (float(t_first), float(t_second))
+    return res[0]
+
+  @staticmethod
+  def backward(ctx, g):
+    lg, = ctx.saved_tensors
+    coeff = g.reshape(1).float().contiguous()
+    out = torch.empty_like(lg)
+    lib.call('csmri_bce_logits_pair_bwd', lg.data_ptr(), lg.numel() // 2, ctx.t[0], ctx.t[1], coeff.data_ptr(),
+             out.data_ptr(), stream())
+    return out, None, None
+
+
+def psnr_mean(mse):
+  """mean_b 10 log10(1 / mse_b) as a device scalar (csmri_psnr_mean)."""
+  out = torch.empty(1, dtype=torch.float32, device=mse.device)
+  m = mse.contiguous().float()
+  lib.call('csmri_psnr_mean', m.data_ptr(), m.numel(), out.data_ptr(), stream())
+  return out.reshape(())
+
+
+def disc_accuracy(prob_fake, prob_real):
+  """csmri_disc_accuracy: either argument may be None; [B, ...] fp32 probabilities, B <= 64."""
+  ref = prob_fake if prob_fake is not None else prob_real
+  pf = prob_fake.detach().contiguous().float() if prob_fake is not None else None
+  pr = prob_real.detach().contiguous().float() if prob_real is not None else None
+  b = ref.shape[0]
+  out = torch.empty(1, dtype=torch.float32, device=ref.device)
+  lib.call('csmri_disc_accuracy', ptr(pf), ptr(pr), b, ref[0].numel(), out.data_ptr(), stream())
+  return out.reshape(())
 
 
 def sigmoid_prob(logits):

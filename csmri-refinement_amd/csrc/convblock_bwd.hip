@@ -60,6 +60,12 @@ struct BBParams {
 #define BB_OFF_W1 (BB_OFF_W3 + 9 * 1024)  // stage-1 weights likewise: 6 x 1 KiB
 #define BB_LDS (BB_OFF_W1 + 6 * 1024)
 #define BB_THREADS 512
+#ifndef BB_KC_UNROLL
+#define BB_KC_UNROLL 8
+#endif
+#define BB_STR2(x) #x
+#define BB_STR(x) BB_STR2(x)
+#define BB_UNROLL_KC _Pragma(BB_STR(unroll BB_KC_UNROLL))
 
 typedef __attribute__((ext_vector_type(4))) short bb_s16x4_t;
 struct bb_s16x8_pair { bb_s16x4_t lo, hi; };
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
         const int unit = min(7 - wv + 8 * a, 17), tap = unit % 9, cf = unit / 9, ty = tap / 3, tx = tap - ty * 3;
         xb[a] = A2 + (cf * 2 + tplane) * BB_PS2 + ((1 + ty) * BB_PW + 1 + tx + trow) * 16 + tquad;
       }
-#pragma unroll 2
+BB_UNROLL_KC
       for (int kc = 0; kc < 8; ++kc) {
         const int ko = kc * 2 * BB_PW * 16;
         const bf16x8_t yf = bb_tr(yb + ko, yb + ko + 64);
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
         const int unit = min(7 - wv + 8 * a, 17), tap = unit % 9, cf = unit / 9, ty = tap / 3, tx = tap - ty * 3;
         xb[a] = A1 + (cf * 2 + tplane) * BB_PS1 + (ty * BB_PW + tx + trow) * 16 + tquad;
       }
-#pragma unroll 2
+BB_UNROLL_KC
       for (int kc = 0; kc < 8; ++kc) {
         const int ko = kc * 2 * BB_PW * 16;
         const bf16x8_t yf0 = bb_tr(yb + ko, yb + ko + 64), yf1 = bb_tr(yb + 2 * BB_PS2 + ko, yb + 2 * BB_PS2 + ko + 64);
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
       const int tap = min(2 * wv + tplane, 8), ty = tap / 3, tx = tap - ty * 3;
       const char* xb = XI + (ty * BB_PW + tx + trow) * 16 + tquad;
       const char* yb = D1 + tplane * BB_PS1 + (1 * BB_PW + 1 + trow) * 16 + tquad;
-#pragma unroll 2
+BB_UNROLL_KC
       for (int kc = 0; kc < 8; ++kc) {
         const int ko = kc * 2 * BB_PW * 16;
         const bf16x8_t xf = wv == 5 ? ones : bb_tr(xb + ko, xb + ko + 64);

@@ -712,3 +712,111 @@ extern "C" int csmri_dropout2d_mask(float* mask, long long n, float p, unsigned 
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
+
+// ------------------------------------------------------------------ scalar glue of the step ----
+// The runner's scalar arithmetic as single launches (each was 3-9 framework launches inside the captured step):
+//   csmri_weighted_sum      total = sum_i w_i * loss_i            (reference base_runner / adversarial_runner.py:314-320:
+//                           `torch.sum(torch.cat(losses) * weights)`), fp32, in list order; backward g_i = g * w_i
+//   csmri_bce_logits_pair   mean BCE(sigmoid(l[0:n]), t0) + mean BCE(sigmoid(l[n:2n]), t1): the discriminator's GAN loss
+//                           on the [fake; real] logits of one batched pass (models/adversarial_loss.py:71-85)
+//   csmri_psnr_mean         mean_b 10 log10(1 / mse_b)            (metrics/image_metrics.py:7-19, metrics/__init__.py:38-72)
+//   csmri_disc_accuracy     binary accuracy of per-image mean probabilities against label 0 (fake) / 1 (real)
+//                           (metrics/scalar_metrics.py:26-53)
+__global__ void weighted_sum_kernel(const csmri_scalar_list L, float* out) {
+  if (threadIdx.x || blockIdx.x) return;
+  float s = 0.f;
+  for (int i = 0; i < L.n; ++i) s += L.w[i] * L.v[i][0];
+  out[0] = s;
+}
+__global__ void weighted_sum_bwd_kernel(const csmri_scalar_list L, const float* g, float* out) {
+  const int i = threadIdx.x;
+  if (i < L.n) out[i] = g[0] * L.w[i];
+}
+extern "C" int csmri_weighted_sum(const csmri_scalar_list* items, float* out, void* stream) {
+  CSMRI_CHECK_ARG(items && out && items->n > 0 && items->n <= CSMRI_SCALAR_LIST_MAX);
+  for (int i = 0; i < items->n; ++i) CSMRI_CHECK_ARG(items->v[i]);
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *items, out);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+extern "C" int csmri_weighted_sum_bwd(const csmri_scalar_list* items, const float* g, float* out, void* stream) {
+  CSMRI_CHECK_ARG(items && g && out && items->n > 0 && items->n <= CSMRI_SCALAR_LIST_MAX);
+  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *items, g, out);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+__global__ __launch_bounds__(256) void bce_logits_pair_kernel(const float* l, long long n, float t0, float t1, float* result) {
+  double a0 = 0, a1 = 0;
+  for (long long i = threadIdx.x; i < 2 * n; i += 256) {
+    const float t = i < n ? t0 : t1;
+    const float p = 1.f / (1.f + expf(-l[i]));
+    const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+    const double v = (double)(-(t * lp + (1.f - t) * l1p));
+    if (i < n) a0 += v; else a1 += v;
+  }
+  const double s0 = block_sum(a0);
+  __syncthreads();
+  const double s1 = block_sum(a1);
+  if (threadIdx.x == 0) {
+    const float m0 = (float)(s0 / (double)n), m1 = (float)(s1 / (double)n);
+    result[0] = m0 + m1; result[1] = m0; result[2] = m1;
+  }
+}
+extern "C" int csmri_bce_logits_pair(const float* logits, long long n_half, float t_first, float t_second, float* result,
+                                     void* stream) {
+  CSMRI_CHECK_ARG(logits && result && n_half > 0);
+  hipLaunchKernelGGL(bce_logits_pair_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, n_half, t_first,
+                     t_second, result);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+__global__ void bce_logits_pair_bwd_kernel(const float* l, long long n, float t0, float t1, const float* coeff, float* g) {
+  const float k = (coeff ? coeff[0] : 1.f) / (float)n;
+  GRID_STRIDE(i, 2 * n) {
+    const float p = 1.f / (1.f + expf(-l[i]));
+    g[i] = (p - (i < n ? t0 : t1)) * k;
+  }
+}
+extern "C" int csmri_bce_logits_pair_bwd(const float* logits, long long n_half, float t_first, float t_second,
+                                         const float* coeff, float* glogits, void* stream) {
+  CSMRI_CHECK_ARG(logits && glogits && n_half > 0);
+  hipLaunchKernelGGL(bce_logits_pair_bwd_kernel, dim3(grid_for(2 * n_half)), dim3(256), 0, (hipStream_t)stream, logits,
+                     n_half, t_first, t_second, coeff, glogits);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+__global__ void psnr_mean_kernel(const float* mse, int B, float* out) {
+  if (threadIdx.x || blockIdx.x) return;
+  double s = 0;
+  for (int b = 0; b < B; ++b) s += (10.0 / log(10.0)) * log(1.0 / (double)mse[b]);
+  out[0] = (float)(s / (double)B);
+}
+extern "C" int csmri_psnr_mean(const float* mse, int B, float* out, void* stream) {
+  CSMRI_CHECK_ARG(mse && out && B > 0);
+  hipLaunchKernelGGL(psnr_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mse, B, out);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
+__global__ __launch_bounds__(64) void disc_accuracy_kernel(const float* pf, const float* pr, int B, int n, float* out) {
+  // lane b: image b of the fake and/or the real batch (B <= 64 images each); per-image mean in fp32, in element order
+  const int b = threadIdx.x;
+  float hits = 0.f;
+  if (b < B) {
+    if (pf) { float s = 0.f; for (int i = 0; i < n; ++i) s += pf[(size_t)b * n + i]; hits += (s / (float)n > 0.5f) ? 0.f : 1.f; }
+    if (pr) { float s = 0.f; for (int i = 0; i < n; ++i) s += pr[(size_t)b * n + i]; hits += (s / (float)n > 0.5f) ? 1.f : 0.f; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
+  if (b == 0) out[0] = hits / (float)(B * ((pf ? 1 : 0) + (pr ? 1 : 0)));
+}
+extern "C" int csmri_disc_accuracy(const float* prob_fake, const float* prob_real, int B, int n_per_image, float* out,
+                                   void* stream) {
+  CSMRI_CHECK_ARG((prob_fake || prob_real) && out && B > 0 && B <= 64 && n_per_image > 0);
+  hipLaunchKernelGGL(disc_accuracy_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, prob_fake, prob_real, B,
+                     n_per_image, out);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}

@@ -1301,7 +1301,7 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
     // gradient of the other kernels is a column sum over dY, which may not outlive this call: done now
     if (d->db && !patch) {
       float* part = d->slab + (size_t)p.splitk * d->Cout * p.NK;
-      int rows = cdiv(p.M, 512); if (rows > DB_ROWS) rows = DB_ROWS; if (rows < 1) rows = 1;
+      int rows = cdiv(p.M, 512); if (rows > 256) rows = 256; if (rows < 1) rows = 1;   // (final pass: rows / 8 serial steps)
       hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows), dim3(256), 0, st, d->dtype, p.dy, p.dyps,
                          (long long)p.M, d->Cout, part);
       CSMRI_LAUNCH_CHECK();
@@ -1330,7 +1330,7 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
     CSMRI_LAUNCH_CHECK();
   } else if (d->db) {
     float* part = d->slab + (size_t)p.splitk * d->Cout * p.NK;
-    int rows = cdiv(p.M, 512); if (rows > DB_ROWS) rows = DB_ROWS; if (rows < 1) rows = 1;
+    int rows = cdiv(p.M, 512); if (rows > 256) rows = 256; if (rows < 1) rows = 1;   // (final pass: rows / 8 serial steps)
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows), dim3(256), 0, st, d->dtype, p.dy, p.dyps,
                        (long long)p.M, d->Cout, part);
     CSMRI_LAUNCH_CHECK();

@@ -35,6 +35,11 @@ class GANLoss(nn.Module):
   def forward(self, out_disc_fake, out_disc_real):
     if self.loss_type == 'gen':
       return ops.BCELogits.apply(out_disc_fake['logits'], self.gen_label)
+    pair = out_disc_fake.get('_pair_logits')
+    if pair is not None and pair is out_disc_real.get('_pair_logits') and pair.is_cuda:
+      # the two halves of ONE batched [fake; real] pass: one launch on the un-split logits (no slice nodes in the
+      # autograd graph: their backward was two fills, two copies and an add)
+      return ops.BCELogitsPair.apply(pair, self.disc_fake_label, self.disc_real_label)
     return (ops.BCELogits.apply(out_disc_fake['logits'], self.disc_fake_label) +
             ops.BCELogits.apply(out_disc_real['logits'], self.disc_real_label))
 

@@ -112,7 +112,9 @@ class RecNet(nn.Module):
     """inp, kspace, mask: [B,2,H,W] fp32 (re, im planes).  Returns [B,2,H,W]."""
     ensure_pack_group(self)          # trainable: one multi-layer re-pack per mode after an optimizer step (15 x 2 launches otherwise)
     x_pad = ops.ToNHWC.apply(inp, self.dtype, 8)             # conv input layout
-    x_c = ops.ToNHWC.apply(inp, torch.float32, 2)            # interleaved complex
+    # interleaved complex copy of the input: only the residual form (use_refinement) and a cascade without any
+    # block read it
+    x_c = ops.ToNHWC.apply(inp, torch.float32, 2) if (self.use_refinement or not len(self.conv_blocks)) else None
     k0 = ops.nchw_to_nhwc(kspace, torch.float32, 2)
     m8 = ops.mask_to_u8(mask)
     recs = []
@@ -135,6 +137,7 @@ class RecNet(nn.Module):
         if idx < nb - 1:
           x_pad = _CastPad.apply(x_c, self.dtype)
     out = ops.ToNCHW.apply(x_c, 2)
+    out._nhwc = x_c.detach()           # the same image in device layout (metrics read it instead of converting back)
     if self.return_intermediate_recs:
       return {'pred': out, 'reconstructions': recs}
     return out

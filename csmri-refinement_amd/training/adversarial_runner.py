@@ -99,6 +99,8 @@ def build_runner(conf, cuda, mode):
 def _split_disc_output(out, b):
   """Halves of a discriminator output computed on a stacked [first; second] batch."""
   first, second = {}, {}
+  if torch.is_tensor(out.get('logits')) and out['logits'].shape[0] == 2 * b:
+    first['_pair_logits'] = second['_pair_logits'] = out['logits']
   for k, v in out.items():
     if torch.is_tensor(v):
       first[k], second[k] = v[:b], v[b:]
@@ -166,6 +168,7 @@ class AdversarialRunner(BaseRunner):
                                                     self.disc_adv_criteria)
     self.discriminator_enabled = True
     self.generator_enabled = True
+    self._host_weights = {}
 
     def _get_pretraining_schedule(epochs):          # reference adversarial_runner.py:195-209
       if epochs is None:
@@ -234,8 +237,13 @@ class AdversarialRunner(BaseRunner):
   def predict(self, batch):
     return self.gen(*self.train_model_input_fn(batch, use_batch_transform=False))
 
-  @staticmethod
-  def _weighted_total(losses, weights):
+  def _weighted_total(self, losses, weights):
+    if losses[0].is_cuda and len(losses) <= 16:
+      key = id(weights)
+      host = self._host_weights.get(key)
+      if host is None:                     # (loss weights are configuration constants: read back once)
+        host = self._host_weights[key] = [float(w) for w in weights.detach().cpu()]
+      return ops.weighted_sum(losses, host)
     return torch.sum(torch.stack(losses) * weights)
 
   def _update_step(self, optimizer, losses, weights):

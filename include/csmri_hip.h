@@ -503,6 +503,31 @@ int csmri_adam_dev(float* p, const float* g, float* m, float* v, long long n, fl
 int csmri_image_pool_exchange(const void* x, void* pool, void* out, const long long* plan, int n,
                               long long bytes_per_image, void* stream);
 
+/* Scalar glue of a training step, one launch each (they were 3-9 framework launches inside the captured step).
+ * csmri_weighted_sum: out[0] = sum_i w[i] * v[i][0] in list order, fp32 -- the runner's
+ *   `torch.sum(torch.cat(losses) * weights)` (reference training/adversarial_runner.py:314-320, runner.py:159-161);
+ *   csmri_weighted_sum_bwd: out[i] = g[0] * w[i].
+ * csmri_bce_logits_pair: result[0] = mean BCE(sigmoid(l[0:n]), t_first) + mean BCE(sigmoid(l[n:2n]), t_second) (torch's
+ *   log clamp at -100), result[1], result[2] the two terms: the discriminator GAN loss on the [fake; real] logits of
+ *   one batched pass (models/adversarial_loss.py:71-85); _bwd: glogits[i] = coeff[0] * (sigmoid(l[i]) - t) / n.
+ * csmri_psnr_mean: out[0] = mean_b 10 log10(1 / mse[b]) in double (metrics/image_metrics.py:7-19).
+ * csmri_disc_accuracy: fraction of images whose mean probability is classified correctly, fake images against
+ *   label 0 and / or real images against label 1 (metrics/scalar_metrics.py:26-53); either pointer may be NULL;
+ *   B <= 64 images of n_per_image probabilities each. */
+#define CSMRI_SCALAR_LIST_MAX 16
+typedef struct csmri_scalar_list {
+  const float* v[CSMRI_SCALAR_LIST_MAX]; float w[CSMRI_SCALAR_LIST_MAX]; int n;
+} csmri_scalar_list;
+int csmri_weighted_sum(const csmri_scalar_list* items, float* out, void* stream);
+int csmri_weighted_sum_bwd(const csmri_scalar_list* items, const float* g, float* out, void* stream);
+int csmri_bce_logits_pair(const float* logits, long long n_half, float t_first, float t_second, float* result,
+                          void* stream);
+int csmri_bce_logits_pair_bwd(const float* logits, long long n_half, float t_first, float t_second,
+                              const float* coeff, float* glogits, void* stream);
+int csmri_psnr_mean(const float* mse, int B, float* out, void* stream);
+int csmri_disc_accuracy(const float* prob_fake, const float* prob_real, int B, int n_per_image, float* out,
+                        void* stream);
+
 /* nn.Dropout2d masks of one discriminator forward pass (reference models/discriminators.py:150-152: one
  * Bernoulli(1 - p) draw per (image, channel), survivors scaled by 1 / (1 - p)), all dropout layers in ONE launch:
  *   mask[i] = keep_i / (1 - p),  keep_i = [u_i < 1 - p],
