@@ -2,7 +2,7 @@
 # usage (GPU box): tools/pmc_insts.sh -> per-kernel instruction mix (VALU / MFMA / LDS / SALU per launch)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/pmci -o r01 -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-overlap --steps 4 --warmup 2 > $R/gpurun_out/pmci.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/pmci -o r01 -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-other-configs --settle-s 0 --no-overlap --steps 4 --warmup 2 > $R/gpurun_out/pmci.log 2>&1
 python3 - $R <<'PY'
 import csv, glob, sys, collections
 R = sys.argv[1]

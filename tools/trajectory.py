@@ -10,6 +10,8 @@ same image-pool decisions (python `random`, re-seeded), eager launches:
   c2   RecNet(5 blocks, 3 convs, 32 filters) MSE training (incl. the DC adjoints)
   c3   2-refinement GAN step; the frozen RecNet(3,3,32) is first trained for --pretrain-steps fp32 MSE steps and
        handed to both runs through the reference's pretrained_weights mechanism
+`--dtypes fp32,bf16,fp32p`: fp32p is the CONTROL, the fp32 run again from initial weights perturbed by 1e-6 relative --
+how far two fp32 trajectories drift apart by themselves.
 
 Recorded per dtype: every step's losses and training PSNR (curves down-sampled to <= 250 points), and at the end
 the PSNR of the trained model on held-out batches (train-mode BatchNorm for the GAN generator as during training,
@@ -97,7 +99,23 @@ def psnr_of(runner, batches, train_mode):
 
 def run(config, dtype, args, train, held, pretrained, dev):
   import torch
+  perturbed = dtype == 'fp32p'
+  if perturbed:
+    dtype = 'fp32'
   runner, conf = build(config, dtype, args.batch, args.width, args.seed, pretrained)
+  if perturbed:
+    # CONTROL: the fp32 run again from initial weights moved by 1e-6 relative (a few fp32 ulps): how far two fp32
+    # trajectories drift apart by themselves -- the yardstick for the bf16 run's distance
+    gen = torch.Generator(device='cpu').manual_seed(args.seed + 77)
+    with torch.no_grad():
+      for net in (getattr(runner, 'gen', None), getattr(runner, 'disc', None), getattr(runner, 'model', None)):
+        if net is None:
+          continue
+        for prm in net.parameters():
+          if prm.requires_grad:
+            prm.mul_(1.0 + 1e-6 * torch.randn(prm.shape, generator=gen).to(prm.device))
+    from csmri_hip import ops
+    ops.bump_weight_epoch()
   if dtype == 'fp8':
     from models.utils import set_fp8_forward
     for net in (getattr(runner, 'gen', None), getattr(runner, 'disc', None), getattr(runner, 'model', None)):
