@@ -297,7 +297,7 @@ def roofline(runner, loader_factory, dtype, steps=2, config='c3'):
   # HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very
   # command (tools/pmc_bench.sh; FETCH_SIZE doubled per the gfx950 correction), committed under profiles/
   traffic, traffic_src = None, None
-  for tname in ('r02_pmc_bench_traffic.json', 'r01_pmc_bench_traffic.json'):
+  for tname in ('r03_pmc_bench_traffic.json', 'r02_pmc_bench_traffic.json', 'r01_pmc_bench_traffic.json'):
     tpath = os.path.join(ROOT, 'profiles', tname)
     if config == 'c3' and dtype == 'bf16' and traffic is None and os.path.exists(tpath):   # the PMC passes ran this workload
       for name, rec in json.load(open(tpath)).items():
