@@ -274,7 +274,7 @@ extern "C" size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d) {
 
 extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   { csmri_gconv_desc t = *d; t.splitk = 1;
-    if (thin_out1_eligible(&t) || tconv_eligible(&t) || pconv_eligible(&t)) return 1; }
+    if (thin_out1_eligible(&t) || tconv_eligible(&t) || pconv2_eligible(&t) || pconv_eligible(&t)) return 1; }
   if (gconv_glds256_eligible(d)) return gconv_glds256_splitk(d);
   GConfig c = pick_config(d);
   if (gconv_glds_eligible(d)) { c.BM = 128; c.BN = gconv_glds_bn(d); }
@@ -382,6 +382,7 @@ extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int
   CSMRI_CHECK_ARG(d && buf && n > 0);
   if (d->dtype == CSMRI_FP8) { gconv_fp8_kernel_name(d, buf, n); return CSMRI_OK; }
   if (thin_out1_eligible(d)) { thin_kernel_name(d, buf, n); return CSMRI_OK; }
+  if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3>"); return CSMRI_OK; }
   if (pconv_eligible(d)) { snprintf(buf, n, "pconv_kernel<8>"); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (gconv_glds256_eligible(d)) { snprintf(buf, n, "%s", gconv_glds256_name(d)); return CSMRI_OK; }
@@ -414,6 +415,7 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
     return CSMRI_OK;
   }
   if (thin_out1_eligible(d)) return thin_out1_launch(p, d, st);
+  if (pconv2_eligible(d)) return pconv2_launch(p, d, st);
   if (pconv_eligible(d)) return pconv_launch(p, d, st);
   if (tconv_eligible(d)) return tconv_launch(p, d, st);
   if (gconv_glds_eligible(d)) {

@@ -57,6 +57,10 @@ int pconv_eligible(const csmri_gconv_desc* d);
 int pconv_stats_rows(const csmri_gconv_desc* d);
 int pconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 
+// pconv2.hip
+int pconv2_eligible(const csmri_gconv_desc* d);
+int pconv2_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
+
 // gconv_glds.hip
 int gconv_glds_eligible(const csmri_gconv_desc* d);
 int gconv_glds_bn(const csmri_gconv_desc* d);

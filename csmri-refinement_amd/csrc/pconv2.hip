@@ -1,0 +1,296 @@
+// pconv2: the patch-structured convolution of pconv.hip as a persistent, role-split, fully pipelined kernel -- stride-1
+// 3 x 3 / 4 x 4 layers with Cin % 64 == 0 and Cout % 128 == 0 (VGG19 conv2_2 .. conv4_4 and their data gradients, the
+// U-Net's 128-channel layers).
+//
+// Why: the 128 x 128 implicit-GEMM tile of gconv_glds.hip moves 32 KiB from L2 into LDS per 2.1 MFLOP (64 FLOP/B); at
+// the 66-73 GB/s per CU an LDS gather from L2 sustains (MI355X_MICROARCH.md, "Indexed rows") that caps it near
+// 1.1 PFLOP/s, and the best layers sit at 0.96.  A 16 x 16 output tile x 128 output channels that stages its 18 x 18
+// input patch once per 64-channel chunk and streams only the weights per tap moves 185 KiB per 37.7 MFLOP
+// (203 FLOP/B): the L2 -> LDS stream stops being the limit.
+//
+// One workgroup of 12 waves per CU owns one 128-channel block of the output and walks the spatial tiles worker,
+// worker + workers, ...; the loop over (tile, 64-channel chunk, tap) is ONE flat sequence of steps (the operand stream
+// never drains at a tile boundary).  Roles (an LDS-DMA piece costs its issuing wave 60-185 cycles, MI355X_MICROARCH.md
+// cycle constants: waves that multiply must not issue them):
+//   waves 8..11  loaders: every step 4 pieces (1 KiB each) of the weight stage three steps ahead into a ring of 4
+//                stages (16 KiB: 128 channels x 64 K), plus the next chunk's patch (8 planes of 16 B x patch pixels, two
+//                buffers) spread over the chunk's first taps; counted vmcnt retires exactly the stage read next.
+//   waves 0..7   4 position groups x 2 channel halves; the waves of channel half 1 run half a step behind those of half
+//                0 (ping-pong): on every SIMD one wave is in its 32-MFMA block while the other reads its 16 fragments.
+// Two workgroup barriers per step; a buffer is read one phase after the barrier behind the wait that retired it and
+// refilled one phase after the barrier behind its last read.
+// LDS images: patch = tconv's plane-major image (16-B plane p of pixel q at p * PLANE + 16 q, PLANE % 256 == 0);
+// weights = gconv_glds's 128-B rows with the XOR swizzle applied on the source side.  Epilogue = pconv's (bias, leaky slope,
+// activation-derivative gate of the data gradient); no BatchNorm partial sums, one input tensor.
+#include <utility>
+#include "mma_core.h"
+#include "gconv_params.h"
+
+__device__ __attribute__((aligned(16))) char p2_zero_page[16];
+typedef __attribute__((address_space(1))) const void* p2g_t;
+typedef __attribute__((address_space(3))) void* p2l_t;
+
+__device__ __forceinline__ int p2_woff(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int N> __device__ __forceinline__ void p2_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define P2_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <int... I, class F>
+__device__ __forceinline__ void p2_unroll(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+template <int TH, int TW>
+__global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
+  constexpr int NT = TH * TW, TPW = 16 + TW - 1, TPH = 16 + TH - 1, NPIX = TPH * TPW;
+  constexpr int PLANE = (NPIX * 16 + 255) & ~255, PBUF = 8 * PLANE, WST = 128 * 128, NG = 6;
+  constexpr int PPT = NT >= 12 ? 1 : 2, PTAPS = 12 / PPT;      // patch pieces per loader and tap; taps that carry them
+  static_assert(NT >= 4 && PTAPS + 3 <= NT && NPIX >= 64 && NPIX <= NG * 64 && 2 * PBUF + 4 * WST <= 160 * 1024, "patch / ring do not fit");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (p.Wo + 15) >> 4, tiles_y = (p.Ho + 15) >> 4, tiles_img = tiles_x * tiles_y;
+  const int ntile = p.mtiles, NB = p.ntiles;
+  const int ncc = p.Cin >> 6;
+
+  // which output-channel block, which spatial worker: an XCD (workgroup id % 8) keeps ONE channel block's weights in its L2
+  int nblk, worker, workers;
+  {
+    const int id = blockIdx.x, G = gridDim.x;
+    if ((8 % NB) == 0 && (G & 7) == 0) {
+      const int per = 8 / NB, xcd = id & 7;
+      nblk = xcd / per; worker = (id >> 3) * per + (xcd % per); workers = (G >> 3) * per;
+    } else { nblk = id % NB; worker = id / NB; workers = G / NB; }
+  }
+  const int n0 = nblk * 128;
+  const int my_tiles = worker < ntile ? (ntile - worker + workers - 1) / workers : 0;
+  const int n_chunks = my_tiles * ncc, S = n_chunks * NT;
+  if (S == 0) return;
+
+  if (wv >= 8) {
+    // =================================================== loader waves ===================================================
+    const int L = wv - 8;
+    // weights: piece k of a stage = rows 8 (L + 4 k) .. + 7 (8 rows x 128 B), 16-B slots XOR-swizzled at the source
+    const int lrow = lane >> 3;
+    const int wchunk = (lane & 7) ^ ((4 * (L & 1) + (lane >> 4)) & 7);
+    const char* wbase = p.w + (size_t)n0 * p.Kp * 2;
+    const size_t wstep = (size_t)32 * p.Kp * 2;
+    const char* w0p = wbase; const char* w1p = wbase + wstep; const char* w2p = wbase + 2 * wstep; const char* w3p = wbase + 3 * wstep;
+    const unsigned wvoff = (unsigned)(((L * 8 + lrow) * p.Kp + wchunk * 8) * 2);
+    unsigned cin2 = (unsigned)p.Cin * 2u;
+    asm volatile("" : "+s"(w0p), "+s"(w1p), "+s"(w2p), "+s"(w3p), "+s"(cin2));
+    int w_s = 0, w_tap = 0, w_cc = 0;
+    unsigned w_koff = 0, w_ring = 0;
+    auto issue_w = [&]() {
+      char* dst = smem + 2 * PBUF + w_ring + L * 1024;
+      const size_t off = (size_t)(wvoff + w_koff);
+      __builtin_amdgcn_global_load_lds((p2g_t)(w0p + off), (p2l_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((p2g_t)(w1p + off), (p2l_t)(dst + 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((p2g_t)(w2p + off), (p2l_t)(dst + 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((p2g_t)(w3p + off), (p2l_t)(dst + 12288), 16, 0, 0);
+      ++w_s;
+      w_ring = (w_ring + WST) & (4 * WST - 1);
+      w_koff += cin2;
+      if (++w_tap == NT) { w_tap = 0; if (++w_cc == ncc) w_cc = 0; w_koff = (unsigned)w_cc * 128u; }
+    };
+    // patch: piece k (0..11) of a chunk = plane L + 4 (k / 6), pixel group k % 6
+    int p_q = 0, p_cc = 0, p_tile = worker;
+    int spix[NG];
+    auto patch_pixels = [&](int T) {
+      const int b = T / tiles_img, t = T - b * tiles_img;
+      const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+      const int y0 = tyi * 16 + p.dy0, x0 = txi * 16 + p.dx0;
+#pragma unroll
+      for (int grp = 0; grp < NG; ++grp) {
+        const int P = (grp * 64 < NPIX - 64 ? grp * 64 : NPIX - 64) + lane;
+        const int py = P / TPW, px = P - py * TPW;
+        int u = y0 + py, w = x0 + px;
+        if (p.border == CSMRI_BORDER_REFLECT) {
+          u = u < 0 ? -u : u; u = min(u, 2 * (p.Hin - 1) - u);
+          w = w < 0 ? -w : w; w = min(w, 2 * (p.Win - 1) - w);
+        }
+        const bool ok = ((unsigned)u < (unsigned)p.Hin) & ((unsigned)w < (unsigned)p.Win);
+        spix[grp] = ok ? (b * p.Hin + u) * p.Win + w : -1;
+      }
+    };
+    patch_pixels(p_tile);
+    // (kept in registers: the compiler would re-load kernel arguments it finds no SGPR for inside the step loop)
+    const char* in0 = p.in0 + L * 16;
+    unsigned ps0b = (unsigned)p.ps0 * 2u;
+    const char* zero_page = p2_zero_page;
+    asm volatile("" : "+s"(in0), "+s"(ps0b), "+s"(zero_page));
+    auto patch_piece = [&](auto kc_) {                 // piece k of chunk p_cc of tile p_tile
+      constexpr int k = decltype(kc_)::value, hi = k / 6, grp = k % 6;
+      constexpr int px0 = grp * 64 < NPIX - 64 ? grp * 64 : NPIX - 64;
+      const char* base = in0 + p_cc * 128 + hi * 64;
+      const unsigned ps = ps0b;
+      char* dst = smem + (p_q & 1) * PBUF + (L + 4 * hi) * PLANE + px0 * 16;
+      const char* s = spix[grp] >= 0 ? base + (size_t)((unsigned)spix[grp] * ps) : zero_page;
+      __builtin_amdgcn_global_load_lds((p2g_t)s, (p2l_t)dst, 16, 0, 0);
+    };
+    auto patch_done = [&]() {
+      ++p_q;
+      if (++p_cc == ncc) { p_cc = 0; p_tile += workers; if (p_tile < ntile) patch_pixels(p_tile); }
+    };
+    // prologue: patch 0, stages 0..2
+    p2_unroll(std::make_integer_sequence<int, 12>{}, patch_piece);
+    patch_done();
+    issue_w(); issue_w(); issue_w();
+    p2_vmwait<8>();                                    // patch 0 and stage 0 (older than stages 1, 2)
+    __builtin_amdgcn_s_barrier();
+    int s = 0;
+    for (int q = 0; q < n_chunks; ++q) {
+      const bool patch_here = q + 1 < n_chunks;
+      p2_unroll(std::make_integer_sequence<int, NT>{}, [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        // ---- first half of step s: stage s+3 into the buffer stage s-1 left; a slice of the next chunk's patch
+        if (w_s < S) issue_w();
+        if constexpr (t < PTAPS) {
+          if (patch_here) {
+            p2_unroll(std::make_integer_sequence<int, PPT>{}, [&](auto jc) { patch_piece(std::integral_constant<int, t * PPT + decltype(jc)::value>{}); });
+            if constexpr (t == PTAPS - 1) patch_done();
+          }
+        }
+        __builtin_amdgcn_s_barrier();
+        // ---- second half: retire stage s+1 (read from the next first half on).  Younger in issue order: the patch
+        // pieces of step s-2, all of steps s-1 and s (4 weight pieces each + that tap's patch pieces)
+        constexpr int pp = (t - 2 >= 0 && t - 2 < PTAPS ? PPT : 0) + (t - 1 >= 0 && t - 1 < PTAPS ? PPT : 0) + (t < PTAPS ? PPT : 0);
+        if (s + 3 >= S) p2_vmwait<0>();
+        else if (patch_here) p2_vmwait<8 + pp>();
+        else p2_vmwait<8>();
+        __builtin_amdgcn_s_barrier();
+        ++s;
+      });
+    }
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // ===================================================== compute waves =====================================================
+  const int wm = wv & 3, wn = wv >> 2;                // wn is also the ping-pong group (one wave of each per SIMD)
+  const int r16 = lane & 15, g = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(p2l_t)smem;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // fragment addresses: one VGPR per operand and K half; fragment index and tap are immediate offsets
+  const unsigned abase = lds0 + g * PLANE + ((4 * wm * TPW + r16) << 4);
+  const unsigned wb0 = lds0 + 2 * PBUF + p2_woff(wn * 64 + r16, g), wb1 = lds0 + 2 * PBUF + p2_woff(wn * 64 + r16, 4 + g);
+  auto epilogue = [&](int T) {
+    const int b = T / tiles_img, t = T - b * tiles_img;
+    const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+    const int y0 = tyi * 16, x0 = txi * 16;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int oy = y0 + 4 * wm + f, ox = x0 + r16;
+      const bool mv = oy < p.Ho && ox < p.Wo;
+      const OutPos op = gconv_out_pos(p, b, oy * p.osy + p.ooy, ox * p.osx + p.oox);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + g * 4;
+        f32x4_t v = acc[i][f];
+        acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (!mv) continue;
+        if (p.bias) v += *(const f32x4_t*)(p.bias + n);
+        if (p.slope != 1.f) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * p.slope : v[r];
+        }
+        if (p.gsrc && op.g_ok) {
+          f32x4_t gs = load4(p.gsrc, op.gpix + n, p.gdt);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gs[r] > 0.f ? v[r] : v[r] * p.gslope;
+        }
+        store4(op.base, op.opix + n, p.out_dt, v);
+      }
+    }
+  };
+
+  __builtin_amdgcn_s_barrier();                       // patch 0 and stage 0 have landed
+  if (wn) __builtin_amdgcn_s_barrier();               // channel half 1: half a step behind
+  int c_cc = 0, c_tile = worker;
+  unsigned r_ring = 0;
+  for (int q = 0; q < n_chunks; ++q) {
+    const unsigned pa = abase + (q & 1) * PBUF;
+    p2_unroll(std::make_integer_sequence<int, NT>{}, [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      // ======== read half: this step's 16 fragments ========
+      const unsigned w0 = wb0 + r_ring, w1 = wb1 + r_ring;
+      r_ring = (r_ring + WST) & (4 * WST - 1);
+      u32x4_t a[2][4], b[2][4];
+      constexpr int TAP = ((t / TW) * TPW + (t % TW)) * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) P2_READ(b[0][i], w0, i * 2048);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) P2_READ(a[0][f], pa, TAP + f * TPW * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) P2_READ(b[1][i], w1, i * 2048);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) P2_READ(a[1][f], pa, TAP + 4 * PLANE + f * TPW * 16);
+      // (the reads are complete before the barrier behind which a loader may refill what they read)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]),
+                     "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]));
+      __builtin_amdgcn_s_barrier();
+      // ======== multiply half ========
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[kc][i]),
+                                                                __builtin_bit_cast(bf16x8_t, a[kc][f]), acc[i][f], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (t == NT - 1) {
+        if (++c_cc == ncc) { c_cc = 0; epilogue(c_tile); c_tile += workers; }
+      }
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  if (!wn) __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+static int p2_plane(const csmri_gconv_desc* d) {
+  const int npix = (16 + d->TH - 1) * (16 + d->TW - 1);
+  return (npix * 16 + 255) & ~255;
+}
+
+static void p2_grid(const csmri_gconv_desc* d, int* ntile, int* nb, int* workers) {
+  *ntile = d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16);
+  *nb = d->Cout / 128;
+  int maxw = 256 / *nb; if (maxw < 1) maxw = 1;
+  const int rounds = (*ntile + maxw - 1) / maxw;
+  *workers = (*ntile + rounds - 1) / rounds;
+}
+
+int pconv2_eligible(const csmri_gconv_desc* d) {
+  if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
+  if (d->nclass > 1 || d->splitk > 1 || d->upsample || d->in1 || d->stats_partial) return 0;
+  if (d->TH != 3 || d->TW != 3 || d->out_sy != 1 || d->out_sx != 1) return 0;
+  // Measured (profiles/r03_pconv2_layers.log): against gconv_glds / gconv_glds256 / pconv, alone with warm caches +15 % at
+  // 512 input channels (1.20 vs 1.05 PFLOP/s on VGG conv4_x, batch 16), +-3 % at 128 / 256; inside the training step
+  // (operands cold, other streams' kernels beside it) only the 512-channel layers keep their gain (-9 us per launch),
+  // the 128 / 256-channel ones lose 2..15 us: a 16-byte-per-pixel patch gather of a tensor that is not L2-resident
+  // costs more than the 128-row kernels' full-line fetches.  So: 512+ input channels, a full chip of tile blocks.
+  if (d->Cin % 64 || d->Cin < 512 || d->Cout % 128) return 0;
+  if ((long long)d->B * d->Hin * d->Win * d->in0_pix_stride * 2 >= (1ll << 32)) return 0;
+  if ((long long)d->Cout * d->TH * d->TW * d->Cin * 2 >= (1ll << 31)) return 0;
+  int ntile, nb, workers;
+  p2_grid(d, &ntile, &nb, &workers);
+  return (long long)ntile * nb >= 256;
+}
+
+int pconv2_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
+  GParams p = p0;
+  int ntile, nb, workers;
+  p2_grid(d, &ntile, &nb, &workers);
+  p.mtiles = ntile; p.ntiles = nb;
+  const int lds = 2 * 8 * p2_plane(d) + 4 * 128 * 128;
+  CSMRI_SET_MAX_LDS((pconv2_kernel<3, 3>), 160 * 1024);
+  hipLaunchKernelGGL((pconv2_kernel<3, 3>), dim3(workers * nb), dim3(768), lds, st, p);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}

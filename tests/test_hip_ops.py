@@ -69,6 +69,7 @@ CONV_CASES = [
     ('odd_m', 8, 24, 3, 1, 'zero', False, 13, 7, 3),
     ('vgg3_tile256', 256, 256, 3, 1, 'zero', False, 128, 121, 4),
     ('vgg2_patch', 128, 128, 3, 1, 'zero', False, 128, 120, 8),      # 512 tiles of 16x16: pconv, fwd and dgrad (tile edge at x=120)
+    ('vgg4_patch2', 512, 512, 3, 1, 'zero', False, 40, 36, 12),       # 108 tiles x 4 channel blocks: pconv2 (loader waves), fwd and dgrad; partial edge tiles
     ('unet_patch_k4', 128, 128, 4, 1, 'reflection', False, 96, 96, 16),  # pconv with a 4x4 reflection-padded filter   # 242 tiles of 256 rows (last one partial): gconv_glds256, fwd and dgrad
 ]
 
@@ -103,7 +104,7 @@ def ref_conv(x, wt, bias, stride, pads, mode, up, slope):
 def test_conv_fwd_bwd(hip, case, dtype):
   ops = hip.ops
   name, cin, cout, k, stride, border, up, h, w, b = case
-  if name in ('vgg3_tile256', 'vgg2_patch', 'unet_patch_k4') and dtype == torch.float32:
+  if name in ('vgg3_tile256', 'vgg2_patch', 'vgg4_patch2', 'unet_patch_k4') and dtype == torch.float32:
     pytest.skip('the 256-row / patch kernels are bf16-only; at 16M outputs the fp32 comparison trips on '
                 'LeakyReLU-derivative sign flips of pre-activations at the rounding floor')
   layer, wt, bias, x, pads, mode = make_layer(hip, case, dtype)
