@@ -336,8 +336,7 @@ extern "C" int csmri_convblock_fused_fwd(const csmri_convblock_desc* d, void* st
   const long long blocks = (long long)d->B * p.tiles_x * p.tiles_y;
   if (blocks >= (1ll << 31)) return CSMRI_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  static const char* wg_env = getenv("CSMRI_CONVBLOCK_WGS");      // tuning knob: persistent workgroups (2 per CU)
-  const int wgs = wg_env ? atoi(wg_env) : 512;
+  const int wgs = 512;                                  // persistent workgroups: 2 per CU
   const int grid = (int)(blocks < wgs ? blocks : wgs);
   if (d->act[0] && d->act[1]) {
     CSMRI_SET_MAX_LDS(convblock_fwd_kernel<true>, CB_LDS);

@@ -248,8 +248,6 @@ struct GConfig { int BM, BN, WM, KC; };
 static GConfig pick_config(const csmri_gconv_desc* d) {
   GConfig c;
   c.KC = d->dtype == CSMRI_BF16 ? 2 : 1;
-  static const char* kc_env = getenv("CSMRI_GCONV_KC");      // tuning knob (bf16, 128x128 tile only)
-  if (kc_env && d->dtype == CSMRI_BF16 && d->Cout > 64) c.KC = atoi(kc_env) == 1 ? 1 : 2;
   if (d->Cout > 64) { c.BM = 128; c.BN = 128; c.WM = 2; }
   else if (d->Cout > 32) { c.BM = 128; c.BN = 64; c.WM = 2; }
   else if (d->Cout > 16) { c.BM = 256; c.BN = 32; c.WM = 4; }
@@ -286,15 +284,12 @@ extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   // measured (tools/bench_conv.py, main + reduce; bench.py): from ~224 tiles on the two-buffer kernel without
   // split-K beats 2-3 slices + reduce (36 vs 44 us on a 256-tile layer, +2 % on the step); ~192-tile problems want
   // 3 slices (768 workgroups), smaller ones ~512 workgroups (less slab traffic for the same latency hiding)
-  static const char* tgt_env = getenv("CSMRI_GCONV_BLOCKS");       // tuning knob: target workgroups
-  static const char* nos_env = getenv("CSMRI_GCONV_NOSPLIT_TILES");   // A/B knob
   // ... except deep-K problems at exactly one workgroup per CU (VGG conv4_x data gradients on 8 images: 256 tiles,
   // 72 steps): 2 slices = 2 workgroups per CU overlap each other's loads, 53.7 vs 64.1 us incl. the reduce
   // (tools/sk_sweep.sh); at 32 steps (U-Net 128 -> 128 4x4) the same split loses 2x
-  static const char* deep_env = getenv("CSMRI_GCONV_DEEP_SPLIT");   // A/B knob: 0 disables
-  const bool deep = !(deep_env && atoi(deep_env) == 0) && tiles <= 256 && nsteps >= 64 && !d->out_halo && nclass == 1;
-  if (tiles >= (nos_env ? atoi(nos_env) : 224) && !deep) return 1;
-  const int target = tgt_env ? atoi(tgt_env) : (deep ? 512 : tiles >= 192 ? 768 : 512);
+  const bool deep = tiles <= 256 && nsteps >= 64 && !d->out_halo && nclass == 1;
+  if (tiles >= 224 && !deep) return 1;
+  const int target = deep ? 512 : tiles >= 192 ? 768 : 512;
   int sk = (int)((target + tiles - 1) / tiles);
   int maxsk = nsteps / 8; if (maxsk < 1) maxsk = 1;
   if (sk > maxsk) sk = maxsk;

@@ -25,7 +25,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int glds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// NW = 8 (experiment, CSMRI_GLDS_WAVES=8): the same tile on 2 x 4 waves, every wave issuing half the LDS-DMA
+// NW = 8: the same tile on 2 x 4 waves, every wave issuing half the LDS-DMA (two-buffer 128-channel variant)
 template <int BN, int NST, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gconv_glds_kernel(const GParams p) {
   constexpr int BM = 128, WM = 2, WN = NW / 2;
@@ -317,8 +317,6 @@ __global__ __launch_bounds__(64 * NW, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gc
 int gconv_glds_bn(const csmri_gconv_desc* d) { return d->Cout % 128 == 0 ? 128 : 64; }
 
 int gconv_glds_eligible(const csmri_gconv_desc* d) {
-  static const char* off = getenv("CSMRI_NO_GLDS");
-  if (off) return 0;
   if (d->dtype != CSMRI_BF16) return 0;
   if (d->Cin % 64 || d->Cout % 64) return 0;
   if (d->in1 && d->c0 % 64) return 0;
@@ -342,13 +340,7 @@ static int launch_glds(const GParams& p, hipStream_t st) {
 // the two-buffer loop was tuned: it now beats the ring on 129..256-workgroup grids, e.g. 36 vs 41 us on
 // the U-Net 128 -> 128 4x4 layer)
 static int glds_stages(long long blocks) {
-  static const char* env = getenv("CSMRI_GLDS_STAGES");     // A/B knob
-  if (env) return atoi(env);
-  static const char* ring = getenv("CSMRI_GLDS_RING_MAX");   // A/B knob: grids up to this size use the 4-deep ring
-  const long long ring_max = ring ? atoll(ring) : 128;
-  static const char* two = getenv("CSMRI_GLDS_TWO_MAX");     // A/B knob: grids up to this size use two buffers
-  const long long two_max = two ? atoll(two) : 512;
-  return blocks <= ring_max ? 4 : (blocks <= two_max ? 2 : 1);
+  return blocks <= 128 ? 4 : (blocks <= 512 ? 2 : 1);
 }
 
 int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
@@ -359,22 +351,15 @@ int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t 
   p.mtiles = cdiv(p.M, 128); p.ntiles = d->Cout / bn;
   const long long w_elems = (long long)d->Cout * d->TH * d->TW * d->Cin * p.nclass;
   const long long x_elems = (long long)d->B * d->Hin * d->Win * d->Cin;
-  static const char* ord = getenv("CSMRI_GLDS_ORDER");          // A/B knob: 0 = mt-major, 1 = nt-major
-  p.nt_major = ord ? atoi(ord) : (w_elems > x_elems);
+  p.nt_major = w_elems > x_elems;
   const int nst = glds_stages((long long)p.mtiles * p.ntiles * p.nclass * p.splitk);   // (kernel_name mirrors this)
   // 8 waves (2 x 4) instead of 4 (2 x 2) on the same tile: every wave issues half the LDS-DMA instructions.  A wave's
   // DMA stream is what limits the operand intake of these grid-limited layers (1-2 workgroups per CU): 481 -> 618
   // TFLOP/s on the U-Net 128 -> 128 4x4 layer, +4..12 % on the discriminator / VGG conv3-4 shapes, -2 % on 16 x 16
   // maps; 16 waves (2 x 8) lose 5-12 % again: one fragment column per wave doubles the LDS reads per MFMA
-  // (profiles/r02_gconv_glds_8wave_sweep.log).  CSMRI_GLDS_WAVES: A/B knob (4 = round-1 layout everywhere; bit mask 1 = two-buffer
-  // BN 128, 2 = one-buffer BN 128, 4 = BN 64).
-  static const char* nw_env = getenv("CSMRI_GLDS_WAVES");
-  const int nw_mask = nw_env ? (atoi(nw_env) == 4 ? 0 : atoi(nw_env) == 8 ? 7 : atoi(nw_env)) : 1;
-  if (bn == 128 && nst == 2 && (nw_mask & 1)) return launch_glds<128, 2, 8>(p, st);
-  if (bn == 128 && nst == 1 && (nw_mask & 2)) return launch_glds<128, 1, 8>(p, st);
-  if (bn == 64 && nst == 2 && (nw_mask & 4)) return launch_glds<64, 2, 8>(p, st);
-  if (bn == 64 && nst == 1 && (nw_mask & 4)) return launch_glds<64, 1, 8>(p, st);
-  if (bn == 128) return nst == 4 ? launch_glds<128, 4>(p, st) : nst == 2 ? launch_glds<128, 2>(p, st) : launch_glds<128, 1>(p, st);
+  // (profiles/r02_gconv_glds_8wave_sweep.log): the 8-wave layout is used for the two-buffer 128-channel variant only.
+  if (bn == 128 && nst == 2) return launch_glds<128, 2, 8>(p, st);
+  if (bn == 128) return nst == 4 ? launch_glds<128, 4>(p, st) : launch_glds<128, 1>(p, st);
   return nst == 4 ? launch_glds<64, 4>(p, st) : nst == 2 ? launch_glds<64, 2>(p, st) : launch_glds<64, 1>(p, st);
 }
 
@@ -382,9 +367,6 @@ void gconv_glds_kernel_name(const csmri_gconv_desc* d, char* buf, int n) {
   const int bn = gconv_glds_bn(d), nclass = d->nclass > 0 ? d->nclass : 1, sk = d->splitk > 0 ? d->splitk : 1;
   const long long blocks = (long long)cdiv((long long)d->B * d->Ho * d->Wo, 128) * (d->Cout / bn) * nclass * sk;
   const int nst = glds_stages(blocks);
-  static const char* nw_env = getenv("CSMRI_GLDS_WAVES");
-  const int nw_mask = nw_env ? (atoi(nw_env) == 4 ? 0 : atoi(nw_env) == 8 ? 7 : atoi(nw_env)) : 1;
-  const bool w8 = (bn == 128 && nst == 2 && (nw_mask & 1)) || (bn == 128 && nst == 1 && (nw_mask & 2)) ||
-                  (bn == 64 && nst <= 2 && (nw_mask & 4));
+  const bool w8 = bn == 128 && nst == 2;
   snprintf(buf, n, "gconv_glds_kernel<%d, %d, %d>", bn, nst, w8 ? 8 : 4);
 }

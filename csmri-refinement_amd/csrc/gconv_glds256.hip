@@ -223,14 +223,8 @@ __global__ __launch_bounds__(512, 2) void gconv_glds256_kernel(const GParams p) 
 }
 
 // ---------------------------------------------------------------------------------------------
-static int g256_bn(const csmri_gconv_desc* d) {
-  static const char* env = getenv("CSMRI_GLDS256_BN");          // A/B knob
-  if (env) return atoi(env);
-  const int nclass = d->nclass > 0 ? d->nclass : 1;
-  const long long mt = (long long)cdiv((long long)d->B * d->Ho * d->Wo, 256) * nclass;
-  (void)mt;
-  return 256;      // measured: 256 x 128 tiles (8 waves of 64 x 64) lose to the 128-row kernels everywhere
-}
+// (measured: 256 x 128 tiles -- 8 waves of 64 x 64 -- lose to the 128-row kernels everywhere: only <256> is built)
+static int g256_bn(const csmri_gconv_desc* d) { (void)d; return 256; }
 
 static long long g256_tiles(const csmri_gconv_desc* d) {
   const int nclass = d->nclass > 0 ? d->nclass : 1;
@@ -240,18 +234,16 @@ static long long g256_tiles(const csmri_gconv_desc* d) {
 // Measured (tools/bench_conv.py): the 256-row tiles win where they fill the chip WITHOUT split-K
 // (one workgroup per CU: at least ~224 tiles); below that the 128-row kernels with their slabs do better.
 int gconv_glds256_eligible(const csmri_gconv_desc* d) {
-  static const char* off = getenv("CSMRI_NO_GLDS256");          // A/B knob
-  if (off) return 0;
   if (!gconv_glds_eligible(d)) return 0;
   if (d->Cout % g256_bn(d) || d->stats_partial) return 0;
-  static const char* mint = getenv("CSMRI_GLDS256_MIN_TILES");   // A/B knob
-  return g256_tiles(d) >= (mint ? atoi(mint) : 224);
+  return g256_tiles(d) >= 224;
 }
 
 int gconv_glds256_splitk(const csmri_gconv_desc* d) { (void)d; return 1; }
 
 const char* gconv_glds256_name(const csmri_gconv_desc* d) {
-  return g256_bn(d) == 256 ? "gconv_glds256_kernel<256>" : "gconv_glds256_kernel<128>";
+  (void)d;
+  return "gconv_glds256_kernel<256>";
 }
 
 int gconv_glds256_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
@@ -264,10 +256,8 @@ int gconv_glds256_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream
   const long long x_elems = (long long)d->B * d->Hin * d->Win * d->Cin;
   p.nt_major = w_elems > x_elems;
   CSMRI_SET_MAX_LDS(gconv_glds256_kernel<256>, 2 * (256 + 256) * 128);
-  CSMRI_SET_MAX_LDS(gconv_glds256_kernel<128>, 2 * (256 + 128) * 128);
   dim3 grid(p.mtiles * p.ntiles, 1, p.nclass * p.splitk);
-  if (bn == 256) hipLaunchKernelGGL(gconv_glds256_kernel<256>, grid, dim3(512), 2 * (256 + 256) * 128, st, p);
-  else hipLaunchKernelGGL(gconv_glds256_kernel<128>, grid, dim3(512), 2 * (256 + 128) * 128, st, p);
+  hipLaunchKernelGGL(gconv_glds256_kernel<256>, grid, dim3(512), 2 * (256 + 256) * 128, st, p);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -197,24 +197,19 @@ static long long pconv_blocks(const csmri_gconv_desc* d) {
 }
 
 int pconv_eligible(const csmri_gconv_desc* d) {
-  static const char* on = getenv("CSMRI_PCONV");               // A/B knob (default: on)
-  if (on && atoi(on) == 0) return 0;
   if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
   if (d->nclass > 1 || d->splitk > 1 || d->upsample) return 0;
   // (64 input channels: +12 % over tconv on VGG conv2_1 in isolation, nothing at step level: left with tconv)
-  static const char* minc = getenv("CSMRI_PCONV_MINCIN");      // A/B knob
-  if (d->Cin % 64 || d->Cin < (minc ? atoi(minc) : 128) || d->Cout % 128) return 0;
+  if (d->Cin % 64 || d->Cin < 128 || d->Cout % 128) return 0;
   // measured (tools/bench_conv.py): +17..25 % over the 128-row kernel at 128 input channels (VGG conv2_2 and
   // its data gradient); at 256+ channels the one-barrier-per-64-MFMA loop with an exposed patch re-stage per
   // chunk loses to gconv_glds / gconv_glds256 (-4..-20 %), so those stay there until this loop is pipelined
-  static const char* maxc = getenv("CSMRI_PCONV_MAXCIN");      // A/B knob
-  if (d->Cin > (maxc ? atoi(maxc) : 128)) return 0;
+  if (d->Cin > 128) return 0;
   if (d->in1 && d->c0 % 64) return 0;
   if (d->out_sy != 1 || d->out_sx != 1) return 0;
   if (d->TH * d->TW < 4 || (16 + d->TH - 1) * (16 + d->TW - 1) > 6 * 64) return 0;
   if ((long long)d->B * d->Hin * d->Win * (d->in0_pix_stride > d->in1_pix_stride ? d->in0_pix_stride : d->in1_pix_stride) * 2 >= (1ll << 32)) return 0;
-  static const char* minb = getenv("CSMRI_PCONV_MIN_BLOCKS");  // A/B knob
-  return pconv_blocks(d) >= (minb ? atoi(minb) : 512);          // two workgroups per CU
+  return pconv_blocks(d) >= 512;                                // two workgroups per CU
 }
 
 int pconv_stats_rows(const csmri_gconv_desc* d) {

@@ -254,8 +254,6 @@ int tconv_eligible(const csmri_gconv_desc* d) {
   if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
   if ((d->nclass > 1) || d->splitk > 1) return 0;
   if (!(d->Cin == 8 || d->Cin == 16 || d->Cin == 32 || d->Cin == 64)) return 0;
-  static const char* maxcin_env = getenv("CSMRI_TCONV_MAXCIN");     // A/B knob
-  if (d->Cin > (maxcin_env ? atoi(maxcin_env) : 64)) return 0;
   const int tpc = d->Cin >= 32 ? 1 : 32 / d->Cin;
   if (d->TW % tpc) return 0;
   if (d->out_sy != 1 || d->out_sx != 1) return 0;

@@ -362,150 +362,10 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* img, int off_lo, int off
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
-template <int BP, int BQ, int WP, int WQ>
-__global__ __launch_bounds__(256) void wgrad_tr_kernel(const WParams p) {
-  constexpr int PS = 64;                              // pixels per K step (2 MFMA chunks)
-  constexpr int CP = BP / 8, CQ = BQ / 8;             // 16-byte chunks per pixel row
-  constexpr int NXV = 64 * CP / 256, PXS = 256 / CP;  // X vectors per thread, pixel spacing
-  constexpr int NYV = (64 * CQ + 255) / 256, PYS = 256 / CQ;
-  constexpr int WTP = BP / WP, WTQ = BQ / WQ, FP = WTP / 16, FQ = WTQ / 16;
-  constexpr int IMG_X = 64 * BP * 2, IMG_Y = 64 * BQ * 2, BUF = IMG_X + IMG_Y;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wp = wid / WQ, wq = wid % WQ;
-  const int ptile = blockIdx.x / p.qtiles, qtile = blockIdx.x - ptile * p.qtiles;
-  const int p0 = ptile * BP, q0 = qtile * BQ;
-  const int ks = blockIdx.z;
-  const int s_begin = ks * p.steps_per_split;
-  const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
-  const int HoWo = p.Ho * p.Wo;
-  const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
-
-  // X operand: this thread's 16-byte chunk = 8 consecutive (tap, ci) columns, fixed for the launch
-  const int xchunk = tid % CP, xpix0 = tid / CP;
-  const int col = p0 + xchunk * 8;
-  const bool xact = col < p.NK;
-  int ci = 0, dyo = 0, dxo = 0;
-  if (xact) {
-    const int tap = col / p.Cin;
-    ci = col - tap * p.Cin;
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
-    dyo = ky - p.pt; dxo = kx - p.pl;
-  }
-  const char* xsrc = (ci < p.c0) ? p.in0 + (size_t)ci * 2 : p.in1 + (size_t)(ci - p.c0) * 2;
-  const int xps = (ci < p.c0) ? p.ps0 : p.ps1;
-  int sb[NXV], soy[NXV], sox[NXV];
-#pragma unroll
-  for (int j = 0; j < NXV; ++j) {
-    const int m = s_begin * PS + xpix0 + j * PXS;
-    sb[j] = m / HoWo;
-    const int r = m - sb[j] * HoWo;
-    soy[j] = r / p.Wo; sox[j] = r - soy[j] * p.Wo;
-  }
-  // Y operand (dY): chunk = 8 consecutive output channels
-  const int ychunk = tid % CQ, ypix0 = tid / CQ;
-  const bool yact = q0 + ychunk * 8 < p.Cout;
-
-  u32x4_t xr[NXV], yr[NYV];
-  auto load_step = [&](int s) {
-#pragma unroll
-    for (int j = 0; j < NXV; ++j) {
-      const int m = s * PS + xpix0 + j * PXS;
-      u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
-      if (xact && m < p.M) {
-        int u = soy[j] * p.S + dyo, w = sox[j] * p.S + dxo;
-        bool ok = true;
-        if (p.border == CSMRI_BORDER_REFLECT) { u = reflect_idx(u, Hv); w = reflect_idx(w, Wv); }
-        else ok = (unsigned)u < (unsigned)Hv && (unsigned)w < (unsigned)Wv;
-        if (p.ups) { u >>= 1; w >>= 1; }
-        if (ok) v = *(const u32x4_t*)(xsrc + (((size_t)sb[j] * p.Hin + u) * p.Win + w) * (size_t)xps * 2);
-      }
-      xr[j] = v;
-      sox[j] += PS;
-      while (sox[j] >= p.Wo) { sox[j] -= p.Wo; if (++soy[j] == p.Ho) { soy[j] = 0; ++sb[j]; } }
-    }
-#pragma unroll
-    for (int j = 0; j < NYV; ++j) {
-      const int pix = ypix0 + j * PYS, m = s * PS + pix;
-      u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
-      if (pix < PS && yact && m < p.M)
-        v = *(const u32x4_t*)(p.dy + ((size_t)m * p.dyps + q0 + ychunk * 8) * 2);
-      yr[j] = v;
-    }
-  };
-  auto store_step = [&](int buf) {
-    char* base = smem + buf * BUF;
-#pragma unroll
-    for (int j = 0; j < NXV; ++j) *(u32x4_t*)(base + img_off<CP>(xpix0 + j * PXS, xchunk)) = xr[j];
-#pragma unroll
-    for (int j = 0; j < NYV; ++j) {
-      const int pix = ypix0 + j * PYS;
-      if (pix < PS) *(u32x4_t*)(base + IMG_X + img_off<CQ>(pix, ychunk)) = yr[j];
-    }
-  };
-
-  f32x4_t acc[FP][FQ];
-#pragma unroll
-  for (int i = 0; i < FP; ++i)
-#pragma unroll
-    for (int j = 0; j < FQ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  // transposed-read lane geometry: lane = 16*g + 4*q + pp
-  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-  auto mma_step = [&](const char* base) {
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-      const int rlo = kc * 32 + 8 * g + tq, rhi = rlo + 4;
-      bf16x8_t pf[FP], qf[FQ];
-#pragma unroll
-      for (int i = 0; i < FP; ++i) {
-        const int ch = (wp * WTP + i * 16) / 8 + (tp >> 1);
-        pf[i] = tr_frag(base, img_off<CP>(rlo, ch) + (tp & 1) * 8, img_off<CP>(rhi, ch) + (tp & 1) * 8);
-      }
-#pragma unroll
-      for (int j = 0; j < FQ; ++j) {
-        const int ch = (wq * WTQ + j * 16) / 8 + (tp >> 1);
-        qf[j] = tr_frag(base + IMG_X, img_off<CQ>(rlo, ch) + (tp & 1) * 8, img_off<CQ>(rhi, ch) + (tp & 1) * 8);
-      }
-#pragma unroll
-      for (int i = 0; i < FP; ++i)
-#pragma unroll
-        for (int j = 0; j < FQ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  if (s_begin < s_end) {
-    load_step(s_begin);
-    store_step(0);
-    __syncthreads();
-    for (int s = s_begin; s < s_end; ++s) {
-      const int cur = (s - s_begin) & 1;
-      const bool more = s + 1 < s_end;
-      if (more) load_step(s + 1);
-      mma_step(smem + cur * BUF);
-      if (more) store_step(cur ^ 1);
-      __syncthreads();
-    }
-  }
-  const int r16 = lane & 15;
-#pragma unroll
-  for (int j = 0; j < FQ; ++j) {
-    const int co = q0 + wq * WTQ + j * 16 + r16;
-    if (co >= p.Cout) continue;
-#pragma unroll
-    for (int i = 0; i < FP; ++i) {
-      const int cc = p0 + wp * WTP + i * 16 + g * 4;
-      if (cc < p.NK) *(f32x4_t*)(p.slab + ((size_t)ks * p.Cout + co) * p.NK + cc) = acc[i][j];
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// wgrad_glds_kernel: same tiles, images and transposed fragment reads as wgrad_tr_kernel, but the
-// [pixel][channel] images are filled by LDS-DMA (global_load_lds_dwordx4): no staging registers,
-// no ds_write pass (a ds_write_b128 costs 13 LDS cycles per wave-instruction, which made the
-// register-staged kernel store-bound).  An LDS-DMA wave-instruction writes 64 consecutive
+// wgrad_glds_kernel: the [pixel][channel] images are filled by LDS-DMA (global_load_lds_dwordx4): no staging
+// registers, no ds_write pass (a ds_write_b128 costs 13 LDS cycles per wave-instruction, which made the
+// register-staged round-1 kernel store-bound).  An LDS-DMA wave-instruction writes 64 consecutive
 // 16-byte slots, so the chunk swizzle of img_off is applied on the source side: the lane that
 // owns slot s of pixel row r fetches chunk s ^ f(r).  One LDS buffer, two barriers per 64-pixel
 // step; 3-4 workgroups per CU overlap each other's loads and MFMAs.
@@ -956,8 +816,7 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
 
 static int wpatch_cout(const csmri_wgrad_desc* d) { return d->Cout <= 16 ? 16 : d->Cout; }
 static bool wpatch_eligible(const csmri_wgrad_desc* d) {
-  static const char* off = getenv("CSMRI_NO_WPATCH");          // A/B knob
-  if (off || d->dtype != CSMRI_BF16 || d->stride != 1) return false;
+  if (d->dtype != CSMRI_BF16 || d->stride != 1) return false;
   if (!(d->Cin == 8 || d->Cin == 32 || d->Cin == 64 || (d->Cin == 128 && d->Cout == 64))) return false;
   if (!(d->Cout == 8 || d->Cout == 16 || d->Cout == 32 || d->Cout == 64)) return false;
   if (d->KH * d->KW > 16 || d->KH < 1 || d->KW < 1) return false;
@@ -967,13 +826,12 @@ static bool wpatch_eligible(const csmri_wgrad_desc* d) {
 }
 static int wpatch_groups(const csmri_wgrad_desc* d) {
   const long long tiles = (long long)d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16);
-  static const char* env = getenv("CSMRI_WPATCH_BLOCKS");        // tuning knob: persistent workgroups
-  long long g = env ? atoi(env) : 512;
+  long long g = 512;                                             // persistent workgroups
   if (g > tiles / 4) g = tiles / 4;                              // at least 4 tiles per workgroup
   // every workgroup leaves a slab of Cout x NK floats: keep the slab traffic below the operands' own bytes
   const long long slab = (long long)d->Cout * d->KH * d->KW * d->Cin * 4;
   const long long operands = ((long long)d->B * d->Hin * d->Win * d->Cin + (long long)d->B * d->Ho * d->Wo * d->Cout) * 2;
-  if (!env && g * slab > operands) g = operands / slab;
+  if (g * slab > operands) g = operands / slab;
   if (g < 128) g = 128;
   if (g > tiles) g = tiles;
   return (int)(g < 1 ? 1 : g);
@@ -985,8 +843,7 @@ static int launch_wpatch(const WParams& p0, hipStream_t st, int qtiles = 1) {
   const int xrows = 1024 / (CIN / 8 * 16);
   const int one = ((TPH * TPW + xrows - 1) / xrows) * 1024 + 256 * COUT * 2;
   // two stages where two workgroups per CU still fit (<= 80 KiB each); the big-patch variants stay single-staged
-  static const char* env = getenv("CSMRI_WPATCH_STAGES");      // A/B knob
-  p.stages = env ? atoi(env) : (2 * one <= 80 * 1024 ? 2 : 1);
+  p.stages = 2 * one <= 80 * 1024 ? 2 : 1;
   const int lds = p.stages >= 2 ? 2 * one : one;
   CSMRI_SET_MAX_LDS((wpatch_kernel<CIN, COUT, WAVES>), lds);
   hipLaunchKernelGGL((wpatch_kernel<CIN, COUT, WAVES>), dim3(p.splitk, qtiles), dim3(WAVES * 64), lds, st, p);
@@ -1134,9 +991,7 @@ static WConfig pick_wconfig(const csmri_wgrad_desc* d) {
   if (d->Cout > 64) { c.BP = 128; c.BQ = 128; }
   else if (d->Cout > 32) {
     // 256 x 64 with one 64 x 64 tile per wave: 1.0 transposed LDS reads per MFMA instead of 1.5
-    static const char* env = getenv("CSMRI_WGRAD_BP64");       // A/B knob
-    const bool wide = (env ? atoi(env) == 256 : true) && d->dtype == CSMRI_BF16 && !getenv("CSMRI_WGRAD_TR") &&
-                      (long long)d->KH * d->KW * d->Cin >= 256 && wgrad_row_aligned(d);
+    const bool wide = d->dtype == CSMRI_BF16 && (long long)d->KH * d->KW * d->Cin >= 256 && wgrad_row_aligned(d);
     c.BP = wide ? 256 : 128; c.BQ = 64;
   }
   else if (d->Cout > 16) { c.BP = 256; c.BQ = 32; }      // (512 x 32, one 128 x 32 tile per wave: measured slower)
@@ -1152,8 +1007,7 @@ extern "C" int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d) {
   const long long NK = (long long)d->KH * d->KW * d->Cin;
   const long long tiles = (long long)cdiv(NK, c.BP) * cdiv(d->Cout, c.BQ);
   const int nsteps = cdiv((long long)d->B * d->Ho * d->Wo, wgrad_ps(d->dtype));
-  static const char* target_env = getenv("CSMRI_WGRAD_BLOCKS");   // tuning knob
-  const int target = target_env ? atoi(target_env) : 512;
+  const int target = 512;
   int sk = (int)((target + tiles - 1) / tiles);
   int maxsk = nsteps / 4; if (maxsk < 1) maxsk = 1;
   if (sk > maxsk) sk = maxsk;
@@ -1170,16 +1024,6 @@ static int launch_wgrad(const WParams& p, hipStream_t st) {
   constexpr int KC = DT == CSMRI_BF16 ? 2 : 1;
   constexpr int lds = 2 * KC * (BP + BQ) * 64;
   auto kern = wgrad_kernel<DT, BP, BQ, WP, WQ>;
-  CSMRI_SET_MAX_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, dim3(p.ptiles * p.qtiles, 1, p.splitk), dim3(256), lds, st, p);
-  CSMRI_LAUNCH_CHECK();
-  return CSMRI_OK;
-}
-
-template <int BP, int BQ, int WP, int WQ>
-static int launch_wgrad_tr(const WParams& p, hipStream_t st) {
-  constexpr int lds = 2 * 64 * (BP + BQ) * 2;
-  auto kern = wgrad_tr_kernel<BP, BQ, WP, WQ>;
   CSMRI_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(p.ptiles * p.qtiles, 1, p.splitk), dim3(256), lds, st, p);
   CSMRI_LAUNCH_CHECK();
@@ -1224,9 +1068,7 @@ extern "C" int csmri_wgrad_kernel_name(const csmri_wgrad_desc* d, char* buf, int
   }
   WConfig c = pick_wconfig(d);
   const int wp = c.BQ >= 128 || (c.BQ == 64 && c.BP == 128) ? 2 : 4, wq = wp == 2 ? 2 : 1;
-  static const char* use_tr = getenv("CSMRI_WGRAD_TR");
   if (d->dtype != CSMRI_BF16) { snprintf(buf, n, "wgrad_kernel<%d, %d, %d, %d, %d>", d->dtype, c.BP, c.BQ, wp, wq); return CSMRI_OK; }
-  if (use_tr) { snprintf(buf, n, "wgrad_tr_kernel<%d, %d, %d, %d>", c.BP, c.BQ, wp, wq); return CSMRI_OK; }
   const bool row = wgrad_row_aligned(d) && (long long)d->B * d->Hin * d->Win < (1 << 24) &&
                    d->in0_pix_stride < (1 << 22) && d->in1_pix_stride < (1 << 22) &&
                    (long long)d->B * d->Hin * d->Win * (d->in0_pix_stride > d->in1_pix_stride ? d->in0_pix_stride : d->in1_pix_stride) * 2 < (1ll << 32);
@@ -1266,7 +1108,6 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   }
   int rc;
 #define WG(DT_, BP_, BQ_, WP_, WQ_) rc = launch_wgrad<DT_, BP_, BQ_, WP_, WQ_>(p, st)
-  static const char* use_tr = getenv("CSMRI_WGRAD_TR");       // A/B knob: register-staged variant
   const bool patch = thin || wpatch_eligible(d);          // (both leave their bias-gradient partial rows behind the slabs)
   if (thin) {
     rc = wthin_launch(p, d, st);
@@ -1274,20 +1115,12 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
     WParams q = p;
     q.nsteps = d->db ? 1 : 0;                      // wpatch reuses the field: also produce the bias-gradient partials
     rc = wpatch_launch(q, d, st);
-  } else if (d->dtype == CSMRI_BF16 && !use_tr) {
-    static const char* w8_env = getenv("CSMRI_WGRAD_WAVES");     // A/B knob: 8 = 2 x 4 waves on the 128 x 128 tile
-    const bool w8 = w8_env && atoi(w8_env) == 8 && wgrad_row_aligned(d);
-    if (c.BQ == 128 && w8) rc = launch_wgrad_glds<128, 128, 2, 4>(p, st);
-    else if (c.BQ == 128) rc = launch_wgrad_glds<128, 128, 2, 2>(p, st);
+  } else if (d->dtype == CSMRI_BF16) {
+    if (c.BQ == 128) rc = launch_wgrad_glds<128, 128, 2, 2>(p, st);
     else if (c.BQ == 64 && c.BP == 256) rc = launch_wgrad_glds<256, 64, 4, 1>(p, st);
     else if (c.BQ == 64) rc = launch_wgrad_glds<128, 64, 2, 2>(p, st);
     else if (c.BQ == 32) rc = launch_wgrad_glds<256, 32, 4, 1>(p, st);
     else rc = launch_wgrad_glds<256, 16, 4, 1>(p, st);
-  } else if (d->dtype == CSMRI_BF16) {
-    if (c.BQ == 128) rc = launch_wgrad_tr<128, 128, 2, 2>(p, st);
-    else if (c.BQ == 64) rc = launch_wgrad_tr<128, 64, 2, 2>(p, st);
-    else if (c.BQ == 32) rc = launch_wgrad_tr<256, 32, 4, 1>(p, st);
-    else rc = launch_wgrad_tr<256, 16, 4, 1>(p, st);
   } else {
     if (c.BQ == 128) WG(CSMRI_F32, 128, 128, 2, 2);
     else if (c.BQ == 64) WG(CSMRI_F32, 128, 64, 2, 2);

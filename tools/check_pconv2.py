@@ -1,4 +1,4 @@
-"""pconv2 (CSMRI_PCONV2=1) against torch fp32 on bf16-rounded operands + timing; usage: check_pconv2.py [case ...] [fwd|dgrad]"""
+"""The patch convolutions (pconv / pconv2, as csmri_gconv dispatches them) against torch fp32 on bf16-rounded operands + timing; usage: check_pconv2.py [case ...] [fwd|dgrad]"""
 import os, sys, math
 import torch
 import torch.nn.functional as F
