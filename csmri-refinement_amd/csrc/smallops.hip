@@ -289,7 +289,7 @@ extern "C" int csmri_loss_bwd(int kind, int dtype, const void* a, int a_pix_stri
 }
 
 // ---- several mean losses in one launch (feature matching: one L1 per discriminator layer) ----
-#define LOSS_MULTI_BLOCKS 64
+#define LOSS_MULTI_BLOCKS 256
 struct LossItems { csmri_loss_item it[CSMRI_LOSS_MAX_ITEMS]; };
 extern "C" size_t csmri_loss_multi_work_bytes(int n) { return (size_t)n * LOSS_MULTI_BLOCKS * sizeof(double); }
 
@@ -298,23 +298,35 @@ __global__ __launch_bounds__(256) void loss_multi_partial_kernel(int kind, int d
   if (t.dtype_plus1) dt = t.dtype_plus1 - 1;
   const int nv = (t.C_real + 3) >> 2;
   const unsigned total = (unsigned)(t.npix * nv);            // host: < 2^31
-  double acc = 0.0;
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += LOSS_MULTI_BLOCKS * 256) {
+  // four vectors in flight per thread, four independent double accumulators (the round-2 loop -- one 8-byte load,
+  // four dependent double adds per iteration, 64 workgroups per tensor -- ran at 0.9 TB/s: 74 us per launch)
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  auto one = [&](unsigned i) -> float {
     const unsigned p = i / nv;
     const int c = (int)(i - p * nv) * 4;
+    float s = 0.f;
     if (c + 4 <= t.C_real) {
       f32x4_t x = load4(t.a, (long long)p * t.a_pix_stride + c, dt);
       f32x4_t y = t.b ? load4(t.b, (long long)p * t.b_pix_stride + c, dt) : (f32x4_t){0, 0, 0, 0};
-      for (int q = 0; q < 4; ++q) { float d = x[q] - y[q]; acc += kind == 0 ? fabsf(d) : d * d; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { float d = x[q] - y[q]; s += kind == 0 ? fabsf(d) : d * d; }
     } else {
       for (int q = 0; c + q < t.C_real; ++q) {
         float d = load_elem(t.a, (long long)p * t.a_pix_stride + c + q, dt) -
                   (t.b ? load_elem(t.b, (long long)p * t.b_pix_stride + c + q, dt) : 0.f);
-        acc += kind == 0 ? fabsf(d) : d * d;
+        s += kind == 0 ? fabsf(d) : d * d;
       }
     }
+    return s;
+  };
+  const unsigned stride = LOSS_MULTI_BLOCKS * 256;
+  unsigned i = blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < total; i += 4 * stride) {
+    const float s0 = one(i), s1 = one(i + stride), s2 = one(i + 2 * stride), s3 = one(i + 3 * stride);
+    acc[0] += (double)s0; acc[1] += (double)s1; acc[2] += (double)s2; acc[3] += (double)s3;
   }
-  double tot = block_sum(acc);
+  for (; i < total; i += stride) acc[0] += (double)one(i);
+  double tot = block_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
   if (threadIdx.x == 0) work[blockIdx.y * LOSS_MULTI_BLOCKS + blockIdx.x] = tot;
 }
 __global__ __launch_bounds__(64) void loss_multi_final_kernel(const LossItems L, int n, const double* work, float* result) {
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(64) void loss_multi_final_kernel(const LossItems L,
   const int i = threadIdx.x;
   if (i < n) {
     double t = 0;
-    for (int k = 0; k < LOSS_MULTI_BLOCKS; ++k) t += work[i * LOSS_MULTI_BLOCKS + k];
+    for (int k = 0; k < LOSS_MULTI_BLOCKS; ++k) t += work[i * LOSS_MULTI_BLOCKS + k];     // fixed order
     means[i] = t / ((double)L.it[i].npix * (double)L.it[i].C_real);
     result[1 + i] = (float)means[i];
   }
