@@ -377,7 +377,7 @@ extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int
   CSMRI_CHECK_ARG(d && buf && n > 0);
   if (d->dtype == CSMRI_FP8) { gconv_fp8_kernel_name(d, buf, n); return CSMRI_OK; }
   if (thin_out1_eligible(d)) { thin_kernel_name(d, buf, n); return CSMRI_OK; }
-  if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3>"); return CSMRI_OK; }
+  if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3, 128>"); return CSMRI_OK; }
   if (pconv_eligible(d)) { snprintf(buf, n, "pconv_kernel<8>"); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (gconv_glds256_eligible(d)) { snprintf(buf, n, "%s", gconv_glds256_name(d)); return CSMRI_OK; }

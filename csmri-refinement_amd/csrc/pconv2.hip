@@ -38,10 +38,13 @@ template <int N> __device__ __forceinline__ void p2_vmwait() { asm volatile("s_w
 template <int... I, class F>
 __device__ __forceinline__ void p2_unroll(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
-template <int TH, int TW>
+template <int TH, int TW, int BN>
 __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
   constexpr int NT = TH * TW, TPW = 16 + TW - 1, TPH = 16 + TH - 1, NPIX = TPH * TPW;
-  constexpr int PLANE = (NPIX * 16 + 255) & ~255, PBUF = 8 * PLANE, WST = 128 * 128, NG = 6;
+  constexpr int PLANE = (NPIX * 16 + 255) & ~255, PBUF = 8 * PLANE, WST = BN * 128, NG = 6;
+  constexpr int FN = BN / 32;                                   // 16-channel fragments per compute wave
+  constexpr int WP = BN / 32;                                   // weight pieces (8 rows x 128 B) per loader and stage
+  static_assert(BN == 128 || BN == 64, "output-channel block");
   constexpr int PPT = NT >= 12 ? 1 : 2, PTAPS = 12 / PPT;      // patch pieces per loader and tap; taps that carry them
   static_assert(NT >= 4 && PTAPS + 3 <= NT && NPIX >= 64 && NPIX <= NG * 64 && 2 * PBUF + 4 * WST <= 160 * 1024, "patch / ring do not fit");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
       nblk = xcd / per; worker = (id >> 3) * per + (xcd % per); workers = (G >> 3) * per;
     } else { nblk = id % NB; worker = id / NB; workers = G / NB; }
   }
-  const int n0 = nblk * 128;
+  const int n0 = nblk * BN;
   const int my_tiles = worker < ntile ? (ntile - worker + workers - 1) / workers : 0;
   const int n_chunks = my_tiles * ncc, S = n_chunks * NT;
   if (S == 0) return;
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
     const char* wbase = p.w + (size_t)n0 * p.Kp * 2;
     const size_t wstep = (size_t)32 * p.Kp * 2;
     const char* w0p = wbase; const char* w1p = wbase + wstep; const char* w2p = wbase + 2 * wstep; const char* w3p = wbase + 3 * wstep;
+    (void)w2p; (void)w3p;
     const unsigned wvoff = (unsigned)(((L * 8 + lrow) * p.Kp + wchunk * 8) * 2);
     unsigned cin2 = (unsigned)p.Cin * 2u;
     asm volatile("" : "+s"(w0p), "+s"(w1p), "+s"(w2p), "+s"(w3p), "+s"(cin2));
@@ -84,8 +88,10 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
       const size_t off = (size_t)(wvoff + w_koff);
       __builtin_amdgcn_global_load_lds((p2g_t)(w0p + off), (p2l_t)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((p2g_t)(w1p + off), (p2l_t)(dst + 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((p2g_t)(w2p + off), (p2l_t)(dst + 8192), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((p2g_t)(w3p + off), (p2l_t)(dst + 12288), 16, 0, 0);
+      if constexpr (WP == 4) {
+        __builtin_amdgcn_global_load_lds((p2g_t)(w2p + off), (p2l_t)(dst + 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((p2g_t)(w3p + off), (p2l_t)(dst + 12288), 16, 0, 0);
+      }
       ++w_s;
       w_ring = (w_ring + WST) & (4 * WST - 1);
       w_koff += cin2;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
     p2_unroll(std::make_integer_sequence<int, 12>{}, patch_piece);
     patch_done();
     issue_w(); issue_w(); issue_w();
-    p2_vmwait<8>();                                    // patch 0 and stage 0 (older than stages 1, 2)
+    p2_vmwait<2 * WP>();                               // patch 0 and stage 0 (older than stages 1, 2)
     __builtin_amdgcn_s_barrier();
     int s = 0;
     for (int q = 0; q < n_chunks; ++q) {
@@ -151,11 +157,11 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
         }
         __builtin_amdgcn_s_barrier();
         // ---- second half: retire stage s+1 (read from the next first half on).  Younger in issue order: the patch
-        // pieces of step s-2, all of steps s-1 and s (4 weight pieces each + that tap's patch pieces)
+        // pieces of step s-2, all of steps s-1 and s (WP weight pieces each + that tap's patch pieces)
         constexpr int pp = (t - 2 >= 0 && t - 2 < PTAPS ? PPT : 0) + (t - 1 >= 0 && t - 1 < PTAPS ? PPT : 0) + (t < PTAPS ? PPT : 0);
         if (s + 3 >= S) p2_vmwait<0>();
-        else if (patch_here) p2_vmwait<8 + pp>();
-        else p2_vmwait<8>();
+        else if (patch_here) p2_vmwait<2 * WP + pp>();
+        else p2_vmwait<2 * WP>();
         __builtin_amdgcn_s_barrier();
         ++s;
       });
@@ -168,14 +174,14 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
   const int wm = wv & 3, wn = wv >> 2;                // wn is also the ping-pong group (one wave of each per SIMD)
   const int r16 = lane & 15, g = lane >> 4;
   const unsigned lds0 = (unsigned)(size_t)(p2l_t)smem;
-  f32x4_t acc[4][4];
+  f32x4_t acc[FN][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FN; ++i)
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // fragment addresses: one VGPR per operand and K half; fragment index and tap are immediate offsets
   const unsigned abase = lds0 + g * PLANE + ((4 * wm * TPW + r16) << 4);
-  const unsigned wb0 = lds0 + 2 * PBUF + p2_woff(wn * 64 + r16, g), wb1 = lds0 + 2 * PBUF + p2_woff(wn * 64 + r16, 4 + g);
+  const unsigned wb0 = lds0 + 2 * PBUF + p2_woff(wn * (BN / 2) + r16, g), wb1 = lds0 + 2 * PBUF + p2_woff(wn * (BN / 2) + r16, 4 + g);
   auto epilogue = [&](int T) {
     const int b = T / tiles_img, t = T - b * tiles_img;
     const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
@@ -186,8 +192,8 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
       const bool mv = oy < p.Ho && ox < p.Wo;
       const OutPos op = gconv_out_pos(p, b, oy * p.osy + p.ooy, ox * p.osx + p.oox);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + g * 4;
+      for (int i = 0; i < FN; ++i) {
+        const int n = n0 + wn * (BN / 2) + i * 16 + g * 4;
         f32x4_t v = acc[i][f];
         acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         if (!mv) continue;
@@ -217,27 +223,32 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
       // ======== read half: this step's 16 fragments ========
       const unsigned w0 = wb0 + r_ring, w1 = wb1 + r_ring;
       r_ring = (r_ring + WST) & (4 * WST - 1);
-      u32x4_t a[2][4], b[2][4];
+      u32x4_t a[2][4], b[2][FN];
       constexpr int TAP = ((t / TW) * TPW + (t % TW)) * 16;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) P2_READ(b[0][i], w0, i * 2048);
+      for (int i = 0; i < FN; ++i) P2_READ(b[0][i], w0, i * 2048);
 #pragma unroll
       for (int f = 0; f < 4; ++f) P2_READ(a[0][f], pa, TAP + f * TPW * 16);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) P2_READ(b[1][i], w1, i * 2048);
+      for (int i = 0; i < FN; ++i) P2_READ(b[1][i], w1, i * 2048);
 #pragma unroll
       for (int f = 0; f < 4; ++f) P2_READ(a[1][f], pa, TAP + 4 * PLANE + f * TPW * 16);
       // (the reads are complete before the barrier behind which a loader may refill what they read)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]),
-                     "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]));
+      if constexpr (FN == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]),
+                       "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]),
+                       "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]));
       __builtin_amdgcn_s_barrier();
       // ======== multiply half ========
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FN; ++i)
 #pragma unroll
           for (int f = 0; f < 4; ++f)
             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[kc][i]),
@@ -258,9 +269,10 @@ static int p2_plane(const csmri_gconv_desc* d) {
   return (npix * 16 + 255) & ~255;
 }
 
+static int p2_bn(const csmri_gconv_desc* d) { (void)d; return 128; }
 static void p2_grid(const csmri_gconv_desc* d, int* ntile, int* nb, int* workers) {
   *ntile = d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16);
-  *nb = d->Cout / 128;
+  *nb = d->Cout / p2_bn(d);
   int maxw = 256 / *nb; if (maxw < 1) maxw = 1;
   const int rounds = (*ntile + maxw - 1) / maxw;
   *workers = (*ntile + rounds - 1) / rounds;
@@ -270,12 +282,13 @@ int pconv2_eligible(const csmri_gconv_desc* d) {
   if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
   if (d->nclass > 1 || d->splitk > 1 || d->upsample || d->in1 || d->stats_partial) return 0;
   if (d->TH != 3 || d->TW != 3 || d->out_sy != 1 || d->out_sx != 1) return 0;
-  // Measured (profiles/r03_pconv2_layers.log): against gconv_glds / gconv_glds256 / pconv, alone with warm caches +15 % at
-  // 512 input channels (1.20 vs 1.05 PFLOP/s on VGG conv4_x, batch 16), +-3 % at 128 / 256; inside the training step
-  // (operands cold, other streams' kernels beside it) only the 512-channel layers keep their gain (-9 us per launch),
-  // the 128 / 256-channel ones lose 2..15 us: a 16-byte-per-pixel patch gather of a tensor that is not L2-resident
-  // costs more than the 128-row kernels' full-line fetches.  So: 512+ input channels, a full chip of tile blocks.
-  if (d->Cin % 64 || d->Cin < 512 || d->Cout % 128) return 0;
+  // Measured (profiles/r03_pconv2_layers.log): against gconv_glds / gconv_glds256 / pconv / tconv, alone with warm caches
+  // +15 % at 512 input channels (1.20 vs 1.05 PFLOP/s on VGG conv4_x, batch 16), +27 % at 64 -> 128 (VGG conv2_1),
+  // +-3 % at 128 / 256; inside the training step every class with a full chip of tile blocks is worth 0.01-0.04 ms
+  // (5.61 vs 5.65 ms with all of them), layers with fewer blocks lose (half-empty chip, one workgroup per CU).
+  // (64-channel output blocks -- VGG conv1_2 -- were built and measured too: 117 vs tconv's 122 us alone, the step 0.1 ms
+  // SLOWER: a wave's 64 x 32 tile reads 12 fragments per 16 MFMAs)
+  if (d->Cin % 64 || d->Cout % 128) return 0;
   if ((long long)d->B * d->Hin * d->Win * d->in0_pix_stride * 2 >= (1ll << 32)) return 0;
   if ((long long)d->Cout * d->TH * d->TW * d->Cin * 2 >= (1ll << 31)) return 0;
   int ntile, nb, workers;
@@ -288,9 +301,10 @@ int pconv2_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) 
   int ntile, nb, workers;
   p2_grid(d, &ntile, &nb, &workers);
   p.mtiles = ntile; p.ntiles = nb;
-  const int lds = 2 * 8 * p2_plane(d) + 4 * 128 * 128;
-  CSMRI_SET_MAX_LDS((pconv2_kernel<3, 3>), 160 * 1024);
-  hipLaunchKernelGGL((pconv2_kernel<3, 3>), dim3(workers * nb), dim3(768), lds, st, p);
+  const int bn = p2_bn(d);
+  const int lds = 2 * 8 * p2_plane(d) + 4 * bn * 128;
+  CSMRI_SET_MAX_LDS((pconv2_kernel<3, 3, 128>), 160 * 1024);
+  hipLaunchKernelGGL((pconv2_kernel<3, 3, 128>), dim3(workers * nb), dim3(768), lds, st, p);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

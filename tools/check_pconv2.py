@@ -14,6 +14,9 @@ CASES.update({
     'vgg2_2b8': (128, 128, 3, 1, 'zero', False, 128, 128, 8),
     'vgg3_1b8d': (256, 128, 3, 1, 'zero', False, 64, 64, 8),
     'u128b8': (128, 128, 4, 1, 'reflection', False, 64, 64, 8),
+    'vgg1_2b16': (64, 64, 3, 1, 'zero', False, 256, 256, 16),
+    'vgg1_2b8': (64, 64, 3, 1, 'zero', False, 256, 256, 8),
+    'odd64': (64, 64, 3, 1, 'zero', False, 150, 137, 3),
     'odd': (128, 128, 3, 1, 'zero', False, 50, 37, 3),
     'oddr': (192, 256, 4, 1, 'reflection', False, 35, 50, 2),
 })
