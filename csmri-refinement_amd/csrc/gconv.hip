@@ -258,7 +258,6 @@ static GConfig pick_config(const csmri_gconv_desc* d) {
 static int desc_M(const csmri_gconv_desc* d) { return d->B * d->Ho * d->Wo; }
 
 extern "C" int csmri_gconv_stats_rows(const csmri_gconv_desc* d) {
-  { csmri_gconv_desc t = *d; t.splitk = 1; if (pconv_eligible(&t)) return pconv_stats_rows(d); }
   if (tconv_eligible(d)) return tconv_stats_rows(d);
   GConfig c = pick_config(d);
   return cdiv(desc_M(d), c.BM) * c.WM;
@@ -272,8 +271,7 @@ extern "C" size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d) {
 
 extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   { csmri_gconv_desc t = *d; t.splitk = 1;
-    if (thin_out1_eligible(&t) || tconv_eligible(&t) || pconv2_eligible(&t) || pconv_eligible(&t)) return 1; }
-  if (gconv_glds256_eligible(d)) return gconv_glds256_splitk(d);
+    if (thin_out1_eligible(&t) || tconv_eligible(&t) || pconv2_eligible(&t)) return 1; }
   GConfig c = pick_config(d);
   if (gconv_glds_eligible(d)) { c.BM = 128; c.BN = gconv_glds_bn(d); }
   if (d->dtype == CSMRI_FP8) { c.BM = 128; c.BN = gconv_fp8_bn(d); c.KC = 1; }
@@ -378,9 +376,7 @@ extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int
   if (d->dtype == CSMRI_FP8) { gconv_fp8_kernel_name(d, buf, n); return CSMRI_OK; }
   if (thin_out1_eligible(d)) { thin_kernel_name(d, buf, n); return CSMRI_OK; }
   if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3, 128>"); return CSMRI_OK; }
-  if (pconv_eligible(d)) { snprintf(buf, n, "pconv_kernel<8>"); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
-  if (gconv_glds256_eligible(d)) { snprintf(buf, n, "%s", gconv_glds256_name(d)); return CSMRI_OK; }
   if (gconv_glds_eligible(d)) { gconv_glds_kernel_name(d, buf, n); return CSMRI_OK; }
   GConfig c = pick_config(d);
   const int wn = c.BN >= 64 ? 2 : 1;
@@ -411,10 +407,9 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
   }
   if (thin_out1_eligible(d)) return thin_out1_launch(p, d, st);
   if (pconv2_eligible(d)) return pconv2_launch(p, d, st);
-  if (pconv_eligible(d)) return pconv_launch(p, d, st);
   if (tconv_eligible(d)) return tconv_launch(p, d, st);
   if (gconv_glds_eligible(d)) {
-    rc = gconv_glds256_eligible(d) ? gconv_glds256_launch(p, d, st) : gconv_glds_launch(p, d, st);
+    rc = gconv_glds_launch(p, d, st);
     if (rc != CSMRI_OK) return rc;
     if (p.splitk > 1 && !(d->flags & CSMRI_GCONV_DEFER_REDUCE)) return launch_reduce(p, st);
     return CSMRI_OK;

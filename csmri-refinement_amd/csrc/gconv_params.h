@@ -52,11 +52,6 @@ int tconv_stats_rows(const csmri_gconv_desc* d);
 int tconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 void tconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
 
-// pconv.hip
-int pconv_eligible(const csmri_gconv_desc* d);
-int pconv_stats_rows(const csmri_gconv_desc* d);
-int pconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
-
 // pconv2.hip
 int pconv2_eligible(const csmri_gconv_desc* d);
 int pconv2_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
@@ -66,12 +61,6 @@ int gconv_glds_eligible(const csmri_gconv_desc* d);
 int gconv_glds_bn(const csmri_gconv_desc* d);
 int gconv_glds_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 void gconv_glds_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
-
-// gconv_glds256.hip
-int gconv_glds256_eligible(const csmri_gconv_desc* d);
-int gconv_glds256_splitk(const csmri_gconv_desc* d);
-const char* gconv_glds256_name(const csmri_gconv_desc* d);
-int gconv_glds256_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 
 
 // gconv_fp8.hip

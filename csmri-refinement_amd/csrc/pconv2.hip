@@ -1,6 +1,7 @@
-// pconv2: the patch-structured convolution of pconv.hip as a persistent, role-split, fully pipelined kernel -- stride-1
-// 3 x 3 / 4 x 4 layers with Cin % 64 == 0 and Cout % 128 == 0 (VGG19 conv2_2 .. conv4_4 and their data gradients, the
-// U-Net's 128-channel layers).
+// pconv2: patch-structured convolution (tconv.hip's idea carried to many channels) as a persistent, role-split, fully
+// pipelined kernel -- stride-1 3 x 3 layers with Cin % 64 == 0 and Cout % 128 == 0 on a full chip of tile blocks (VGG19
+// conv2_1 .. conv4_4 at batch 16 and most of their data gradients at batch 8).  It replaced round 2's pconv (128 input
+// channels) and gconv_glds256 (256 x 256 tiles), which no benchmarked layer reached any more.
 //
 // Why: the 128 x 128 implicit-GEMM tile of gconv_glds.hip moves 32 KiB from L2 into LDS per 2.1 MFLOP (64 FLOP/B); at
 // the 66-73 GB/s per CU an LDS gather from L2 sustains (MI355X_MICROARCH.md, "Indexed rows") that caps it near
@@ -20,7 +21,7 @@
 // Two workgroup barriers per step; a buffer is read one phase after the barrier behind the wait that retired it and
 // refilled one phase after the barrier behind its last read.
 // LDS images: patch = tconv's plane-major image (16-B plane p of pixel q at p * PLANE + 16 q, PLANE % 256 == 0);
-// weights = gconv_glds's 128-B rows with the XOR swizzle applied on the source side.  Epilogue = pconv's (bias, leaky slope,
+// weights = gconv_glds's 128-B rows with the XOR swizzle applied on the source side.  Epilogue = tconv's (bias, leaky slope,
 // activation-derivative gate of the data gradient); no BatchNorm partial sums, one input tensor.
 #include <utility>
 #include "mma_core.h"

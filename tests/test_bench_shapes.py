@@ -180,7 +180,7 @@ def test_dispatch_variants_are_all_exercised():
   fam = set(n.split('<')[0].replace('void ', '') for n in names)
   splitk = any(e[2] > 1 and e[0] == 'gconv' for v in SEEN.values() for e in v)
   assert splitk, 'no split-K convolution among the bench shapes'
-  need = {'tconv_kernel', 'gconv_kernel', 'gconv_glds_kernel', 'gconv_glds256_kernel', 'pconv_kernel', 'pconv2_kernel',
+  need = {'tconv_kernel', 'gconv_kernel', 'gconv_glds_kernel', 'pconv2_kernel',
           'thin_out1_kernel', 'wpatch_kernel', 'wgrad_glds_row_kernel', 'wthin_out_kernel'}
   assert need <= fam, (need - fam, fam)
   path = os.path.join(ROOT, 'profiles', 'r03_bench_n1.json')

@@ -68,9 +68,9 @@ CONV_CASES = [
     ('vgg', 64, 128, 3, 1, 'zero', False, 24, 40, 1),
     ('odd_m', 8, 24, 3, 1, 'zero', False, 13, 7, 3),
     ('vgg3_tile256', 256, 256, 3, 1, 'zero', False, 128, 121, 4),
-    ('vgg2_patch', 128, 128, 3, 1, 'zero', False, 128, 120, 8),      # 512 tiles of 16x16: pconv, fwd and dgrad (tile edge at x=120)
+    ('vgg2_patch', 128, 128, 3, 1, 'zero', False, 128, 120, 8),      # 512 tiles of 16x16: pconv2, fwd and dgrad (tile edge at x=120)
     ('vgg4_patch2', 512, 512, 3, 1, 'zero', False, 40, 36, 12),       # 108 tiles x 4 channel blocks: pconv2 (loader waves), fwd and dgrad; partial edge tiles
-    ('unet_patch_k4', 128, 128, 4, 1, 'reflection', False, 96, 96, 16),  # pconv with a 4x4 reflection-padded filter   # 242 tiles of 256 rows (last one partial): gconv_glds256, fwd and dgrad
+    ('unet_patch_k4', 128, 128, 4, 1, 'reflection', False, 96, 96, 16),  # a 4x4 reflection-padded 128-channel layer at 1152 row tiles (gconv_glds, one-buffer variant)
 ]
 
 

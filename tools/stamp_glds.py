@@ -1,5 +1,5 @@
 """Diagnostic: per-phase cycle sums of gconv_glds' K loop (needs the -DCSMRI_DBG_STAMPS library).
-usage: python tools/stamp_glds.py cin cout H B   (3x3 zero-pad conv, split-K off; shapes with fewer than 224 256-row tiles -- larger ones go to gconv_glds256: tools/stamp_glds256.py)"""
+usage: python tools/stamp_glds.py cin cout H B   (3x3 zero-pad conv, split-K off)"""
 import os, sys, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'csmri-refinement_amd'))
