@@ -8,4 +8,5 @@ f=$(find $R/gpurun_out/tl -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/trace_timeline.py "$f" > $R/gpurun_out/timeline.txt
 NAMELEN=150 python3 $R/tools/trace_timeline.py "$f" | head -40 > $R/gpurun_out/timeline_head.txt
 python3 $R/tools/trace_concurrency.py "$f" > $R/gpurun_out/concurrency.txt
+python3 $R/tools/trace_critical_path.py "$f" > $R/gpurun_out/critical_path.txt
 rm -rf $R/gpurun_out/tl
