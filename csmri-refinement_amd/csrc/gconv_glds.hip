@@ -53,37 +53,45 @@ __global__ __launch_bounds__(64 * NW, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gc
   const int lrow = lane >> 3;
   const int chunk = (lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7);
 
-  int by[GA], bx[GA], ib[GA];
-#pragma unroll
-  for (int j = 0; j < GA; ++j) {
-    const int m = m0 + (j * NW + wid) * 8 + lrow;
-    if (m < p.M) {
-      int b, oy, ox;
+  // Source pixel of every (filter tap, tile row), computed ONCE into an LDS table (-1 = out of the image: zero page).  The
+  // K loop used to rebuild them per wave at every tap change -- position decomposition, border rule, two multiplies per
+  // row: with 128 input channels (a tap change every 2 steps) the hardware counters showed 3.8-7.9 vector instructions per
+  // MFMA in these kernels against ~1 in the steady-state loop.
+  int* const tab = (int*)(smem + NST * BUF);
+  const int ntaps = p.TH * p.TW;
+  {
+    const int row = tid & 127, m = m0 + row;
+    int b = 0, oy = 0, ox = 0;
+    const bool mv = m < p.M;
+    if (mv) {
       if (p.howo_shift >= 0) { b = m >> p.howo_shift; const int r = m & (HoWo - 1); oy = r >> p.wo_shift; ox = r & (p.Wo - 1); }
       else { b = m / HoWo; const int r = m - b * HoWo; oy = r / p.Wo; ox = r - oy * p.Wo; }
-      by[j] = oy * p.S + p.dy0; bx[j] = ox * p.S + p.dx0; ib[j] = b * p.Hin * p.Win;
-    } else { by[j] = 0; bx[j] = 0; ib[j] = -1; }
-  }
-  int k0 = s_begin * 64;
-  int tap = k0 / p.Cin, ci = k0 - tap * p.Cin;
-  int ty = tap / p.TW, tx = tap - ty * p.TW;
-  // Per-row source pointers, recomputed only when the tap or the concat source changes (every
-  // Cin/64 or c0/64 steps); in between a step costs one 64-bit add per LDS-DMA: the kernel used to
-  // spend 3 vector instructions per MFMA on rebuilding these addresses every step.
-  const char* aptr[GA]; unsigned ainc[GA];
-  auto compute_ptrs = [&]() {
-    const int oy_ = ty * p.dys, ox_ = tx * p.dxs;
-    const bool second = ci >= p.c0;                     // wave-uniform: c0 % 64 == 0
-    const char* src = second ? p.in1 + (size_t)(ci - p.c0 + chunk * 8) * 2 : p.in0 + (size_t)(ci + chunk * 8) * 2;
-    const size_t ps = (size_t)(second ? p.ps1 : p.ps0) * 2;
-#pragma unroll
-    for (int j = 0; j < GA; ++j) {
-      int u = by[j] + oy_, v = bx[j] + ox_;
-      bool ok = ib[j] >= 0;
+    }
+    const int by = oy * p.S + p.dy0, bx = ox * p.S + p.dx0, ibase = b * p.Hin * p.Win;
+    for (int tp = tid >> 7; tp < ntaps; tp += (64 * NW) >> 7) {
+      const int tyy = tp / p.TW, txx = tp - tyy * p.TW;
+      int u = by + tyy * p.dys, v = bx + txx * p.dxs;
+      bool ok = mv;
       if (p.border == CSMRI_BORDER_REFLECT) { u = reflect_idx(u, Hv); v = reflect_idx(v, Wv); }
       else ok = ok && (unsigned)u < (unsigned)Hv && (unsigned)v < (unsigned)Wv;
       if (p.ups) { u >>= 1; v >>= 1; }
-      const int pix = ib[j] + u * p.Win + v;
+      tab[tp * 128 + row] = ok ? ibase + u * p.Win + v : -1;
+    }
+  }
+  __syncthreads();
+  int k0 = s_begin * 64;
+  int tap = k0 / p.Cin, ci = k0 - tap * p.Cin;
+  int ty = tap / p.TW, tx = tap - ty * p.TW;
+  const char* aptr[GA]; unsigned ainc[GA];
+  auto compute_ptrs = [&]() {
+    const bool second = ci >= p.c0;                     // wave-uniform: c0 % 64 == 0
+    const char* src = second ? p.in1 + (size_t)(ci - p.c0 + chunk * 8) * 2 : p.in0 + (size_t)(ci + chunk * 8) * 2;
+    const size_t ps = (size_t)(second ? p.ps1 : p.ps0) * 2;
+    const int tp = ty * p.TW + tx;
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+      const int pix = tab[tp * 128 + (j * NW + wid) * 8 + lrow];
+      const bool ok = pix >= 0;
       // byte offset: one 32-bit multiply when the tensor is < 2 GiB (host check), else 64-bit
       const char* g = p.off32 ? src + (unsigned)pix * (unsigned)ps : src + (size_t)pix * ps;
       aptr[j] = ok ? g : g_zero_page;
@@ -321,12 +329,13 @@ int gconv_glds_eligible(const csmri_gconv_desc* d) {
   if (d->Cin % 64 || d->Cout % 64) return 0;
   if (d->in1 && d->c0 % 64) return 0;
   if (d->in0_pix_stride % 8 || (d->in1 && d->in1_pix_stride % 8)) return 0;
+  if (d->TH * d->TW > 16) return 0;                     // rows of the source-pixel table
   return 1;
 }
 
 template <int BN, int NST, int NW = 4>
 static int launch_glds(const GParams& p, hipStream_t st) {
-  constexpr int lds = (128 + BN) * 128 * NST;
+  constexpr int lds = (128 + BN) * 128 * NST + 16 * 128 * 4;     // staging buffers + the (tap, row) source-pixel table
   dim3 grid(p.mtiles * p.ntiles, 1, p.nclass * p.splitk);
   auto kern = gconv_glds_kernel<BN, NST, NW>;
   CSMRI_SET_MAX_LDS(kern, lds);
