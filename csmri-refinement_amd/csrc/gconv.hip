@@ -226,9 +226,16 @@ __global__ void gconv_reduce_kernel(const GParams p) {
     const size_t zstride = (size_t)p.M * p.Cout;
     f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < p.splitk; ++z) v += *(const f32x4_t*)(slab + z * zstride);
-    int b = m / HoWo, r = m - b * HoWo, oy = r / p.Wo, ox = r - oy * p.Wo;
-    const int ooy = p.ooy + (p.nclass == 4 ? (cls >> 1) : 0), oox = p.oox + (p.nclass == 4 ? (cls & 1) : 0);
-    const OutPos op = gconv_out_pos(p, b, oy * p.osy + ooy, ox * p.osx + oox);
+    OutPos op;
+    if (p.dense_out) {                 // output position index == m: no decomposition (two integer divisions per vector)
+      op.base = p.out; op.opix = (size_t)m * p.ops; op.gpix = (size_t)m * p.gps; op.g_ok = true;
+    } else {
+      int b, oy, ox;
+      if (p.howo_shift >= 0) { b = m >> p.howo_shift; const int r = m & (HoWo - 1); oy = r >> p.wo_shift; ox = r & (p.Wo - 1); }
+      else { b = m / HoWo; const int r = m - b * HoWo; oy = r / p.Wo; ox = r - oy * p.Wo; }
+      const int ooy = p.ooy + (p.nclass == 4 ? (cls >> 1) : 0), oox = p.oox + (p.nclass == 4 ? (cls & 1) : 0);
+      op = gconv_out_pos(p, b, oy * p.osy + ooy, ox * p.osx + oox);
+    }
     if (p.bias) v += *(const f32x4_t*)(p.bias + n);
     if (p.slope != 1.f)
       for (int q = 0; q < 4; ++q) v[q] = v[q] < 0.f ? v[q] * p.slope : v[q];

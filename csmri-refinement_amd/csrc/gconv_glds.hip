@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * NW, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gc
     const int m = m0 + wm * WTM + j * 16 + r16;
     const bool mv = m < p.M;
     OutPos op; op.base = p.out; op.opix = 0; op.gpix = 0; op.g_ok = true;
-    if (mv) {
+    if (mv && p.splitk == 1) {         // (a split launch stores slab rows indexed by m: no output position needed)
       if (p.dense_out) {               // position index == m: no decomposition
         op.opix = (size_t)m * p.ops; op.gpix = (size_t)m * p.gps;
       } else {
