@@ -68,7 +68,9 @@ __global__ __launch_bounds__(64 * NW, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gc
       else { b = m / HoWo; const int r = m - b * HoWo; oy = r / p.Wo; ox = r - oy * p.Wo; }
     }
     const int by = oy * p.S + p.dy0, bx = ox * p.S + p.dx0, ibase = b * p.Hin * p.Win;
-    for (int tp = tid >> 7; tp < ntaps; tp += (64 * NW) >> 7) {
+    // (a split-K slice only visits the taps of its own K range)
+    const int tap_lo = (s_begin * 64) / p.Cin, tap_hi = min(ntaps - 1, (max(s_end, s_begin + 1) * 64 - 1) / p.Cin);
+    for (int tp = tap_lo + (tid >> 7); tp <= tap_hi; tp += (64 * NW) >> 7) {
       const int tyy = tp / p.TW, txx = tp - tyy * p.TW;
       int u = by + tyy * p.dys, v = bx + txx * p.dxs;
       bool ok = mv;
