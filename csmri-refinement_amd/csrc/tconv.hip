@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
   t -= b * tiles_x * tiles_y;
   const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
   const int y0 = tyi * 16, x0 = txi * 16, n0 = blockIdx.y * BN;
-  const int TPW = 16 + p.TW - 1, TPH = 16 + p.TH - 1;
+  const int S = p.S;                                // 1, or 2 for the 8-channel first layers (patch = 15 S + taps wide)
+  const int TPW = 15 * S + p.TW, TPH = 15 * S + p.TH;
   const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
   const int npix = TPH * TPW, NG = (npix + 63) >> 6, PLANE = NG << 10;
   char* wl = smem + p.nsteps;                       // weight tiles follow the patch planes
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
       if (VPP < 4) { const int first = (grp * VPP) & 3; if (wv < first || wv >= first + VPP) continue; }
       const int P = (grp << 6) + lane;
       const int py = (int)__umulhi((unsigned)P, magic), px = P - py * TPW;
-      int u = y0 + p.dy0 + py, w = x0 + p.dx0 + px;
+      int u = y0 * S + p.dy0 + py, w = x0 * S + p.dx0 + px;
       if (p.border == CSMRI_BORDER_REFLECT) {
         u = u < 0 ? -u : u; u = min(u, 2 * (Hv - 1) - u);
         w = w < 0 ? -w : w; w = min(w, 2 * (Wv - 1) - w);
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
   const int gplane = CIN >= 32 ? g : (g % VPP), gshift = CIN >= 32 ? 0 : g / VPP;
   int abase[4], wbase[FN];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) abase[f] = gplane * PLANE + (((4 * wv + f) * TPW + r16 + gshift) << 4);
+  for (int f = 0; f < 4; ++f) abase[f] = gplane * PLANE + (((4 * wv + f) * S * TPW + r16 * S + gshift) << 4);
 #pragma unroll
   for (int i = 0; i < FN; ++i) wbase[i] = tile_off(i * 16 + r16, g);
   int ty = 0, txg = 0, cb = 0;
@@ -250,15 +251,18 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
 }
 
 // ---------------------------------------------------------------------------------------------
+static int tc_npix(const csmri_gconv_desc* d) { return (15 * d->in_s + d->TH) * (15 * d->in_s + d->TW); }
 int tconv_eligible(const csmri_gconv_desc* d) {
-  if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
+  if (d->dtype != CSMRI_BF16 || d->dy_step != 1 || d->dx_step != 1) return 0;
+  // stride 2: the discriminator's first layer (one real input channel padded to 8; reference models/discriminators.py:137-150)
+  if (!(d->in_s == 1 || (d->in_s == 2 && d->Cin == 8 && !d->upsample && !d->in1))) return 0;
   if ((d->nclass > 1) || d->splitk > 1) return 0;
   if (!(d->Cin == 8 || d->Cin == 16 || d->Cin == 32 || d->Cin == 64)) return 0;
   const int tpc = d->Cin >= 32 ? 1 : 32 / d->Cin;
   if (d->TW % tpc) return 0;
   if (d->out_sy != 1 || d->out_sx != 1) return 0;
   if ((long long)d->Ho * d->Wo < 64 * 64) return 0;            // small maps: generic / split-K path
-  const size_t lds = (size_t)(d->Cin / 8) * (((16 + d->TH - 1) * (16 + d->TW - 1) + 63) / 64) * 1024;
+  const size_t lds = (size_t)(d->Cin / 8) * ((tc_npix(d) + 63) / 64) * 1024;
   if (lds > 96 * 1024) return 0;
   return 1;
 }
@@ -270,7 +274,7 @@ int tconv_stats_rows(const csmri_gconv_desc* d) {
 template <int CIN, int FN, bool STREAM>
 static int launch_tconv(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
   GParams p = p0;
-  const int npix_ = (16 + d->TH - 1) * (16 + d->TW - 1);
+  const int npix_ = tc_npix(d);
   const int patch = (CIN / 8) * ((npix_ + 63) / 64) * 1024;      // planes of 64-pixel groups
   const int tpc = CIN >= 32 ? 1 : 32 / CIN, kch = CIN >= 32 ? CIN / 32 : 1;
   const int nq = d->TH * (d->TW / tpc) * kch;
@@ -291,7 +295,7 @@ int tconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st) {
   // whole filter resident in LDS when patch + weights stay under 64 KiB (>= 2 workgroups/CU)
   const int tpc_ = d->Cin >= 32 ? 1 : 32 / d->Cin, kch_ = d->Cin >= 32 ? d->Cin / 32 : 1;
   const int nq_ = d->TH * (d->TW / tpc_) * kch_;
-  const int patch_ = (d->Cin / 8) * (((16 + d->TH - 1) * (16 + d->TW - 1) + 63) / 64) * 1024;
+  const int patch_ = (d->Cin / 8) * ((tc_npix(d) + 63) / 64) * 1024;
   const bool stream = patch_ + nq_ * fn * 16 * 64 > 64 * 1024;
 #define TC(C_, F_) do { if (stream) return launch_tconv<C_, F_, true>(p, d, st); return launch_tconv<C_, F_, false>(p, d, st); } while (0)
 #define TCC(C_) do { if (fn == 4) TC(C_, 4); else if (fn == 2) TC(C_, 2); else TC(C_, 1); } while (0)
@@ -309,7 +313,7 @@ void tconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n) {
   const int fn = tconv_fn(d);
   const int tpc_ = d->Cin >= 32 ? 1 : 32 / d->Cin, kch_ = d->Cin >= 32 ? d->Cin / 32 : 1;
   const int nq_ = d->TH * (d->TW / tpc_) * kch_;
-  const int patch_ = (d->Cin / 8) * (((16 + d->TH - 1) * (16 + d->TW - 1) + 63) / 64) * 1024;
+  const int patch_ = (d->Cin / 8) * ((tc_npix(d) + 63) / 64) * 1024;
   const bool stream = patch_ + nq_ * fn * 16 * 64 > 64 * 1024;
   snprintf(buf, n, "tconv_kernel<%d, %d, %s>", d->Cin, fn, stream ? "true" : "false");
 }
