@@ -382,6 +382,10 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
     est = None
     while True:
       n_chunk = 10 if est is None else max(10, min(200, int((args.settle_s - (time.perf_counter() - t_s)) / est)))
+      if ws > 1:                                      # every rank runs the SAME number of steps (a step holds collectives)
+        nc = torch.tensor([float(n_chunk)], device=dev)
+        torch.distributed.all_reduce(nc, op=torch.distributed.ReduceOp.MAX)
+        n_chunk = int(nc.item())
       t_c = time.perf_counter()
       runner.train_epoch(loader_factory(n_chunk), 1, steps_per_train_summary=10 ** 9)
       torch.cuda.synchronize()
