@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""How much gradient fidelity does a 16-bit activation format cost on THIS training step?
+"""(test infrastructure: lives under tests/ because it imports the oracle)
+How much gradient fidelity does a 16-bit activation format cost on THIS training step?
 
 Runs the CPU oracle's GAN step (oracle/csmri_oracle.py, fp32) three times on the same weights,
 batch and injected dropout masks: plain fp32, and with every tensor the HIP path stores in the
@@ -8,7 +9,7 @@ max-pool outputs, weights; gradients of the same tensors on the way back; fp32 a
 BatchNorm statistics, fp32 losses, fp32 weight gradients).  Prints per-tensor gradient cosine /
 relative L2 against the fp32 run -- the error floor ANY implementation with that storage format has.
 
-  python tools/lowprec_sensitivity.py [--size 128] [--batch 4] [--small]
+  python tests/lowprec_sensitivity.py [--size 128] [--batch 4] [--small]
 
 Test infrastructure (uses the oracle): never imported by the product."""
 import argparse

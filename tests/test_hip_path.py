@@ -867,7 +867,7 @@ def test_full_width_256_b8_bf16_step_vs_fp32_oracle(env):
   Gradients: this step's parameter gradients are cancellation-heavy (D's loss pairs +sigma/N on the fake
   half with -(0.9 - sigma)/N on a real half that looks almost the same; BatchNorm backward subtracts
   batch means; the VGG loss differentiates f(pred) - f(target)), so rounding the stored activations to
-  bf16 moves them by 5-60 % in ANY implementation -- tools/lowprec_sensitivity.py, DESIGN.md section 5.
+  bf16 moves them by 5-60 % in ANY implementation -- tests/lowprec_sensitivity.py, DESIGN.md section 5.
   The bound is therefore the storage format's own floor, measured here by the oracle with bf16 storage
   emulated: per tensor, the HIP deviation from the fp32 oracle may not exceed 2 x the emulated
   deviation (or 2e-2).  Kernel exactness at these very shapes is pinned separately
