@@ -15,19 +15,23 @@ N>1 is launched by the driver as torch.distributed.run with one rank per GPU (RC
   MSE loss on 64 slices/GPU of 256x256: 5 conv blocks + 5 data-consistency layers forward, their
   adjoints backward, Adam.
 
-The batches are resident in HBM when the timed region starts (8 distinct batches cycled); --host-input is the
-PCIe-inclusive A/B: pinned host batches whose H2D copy is issued on a copy stream inside the timed region (the
-copy of batch t+1 runs under step t; DESIGN.md section 6 holds that rate).  After the W warm-up steps the replay
-settles for --settle-s seconds (untimed), then EXACTLY K steps are timed.  Rank 0 prints ONE JSON line; on the
-default invocation (c3, bf16, one GPU) it also carries `other_configs`: short legs of C2 and C5.
+Input (the metric "includes H2D of the batch", reference training/base_runner.py:29-41): the batches
+start in PINNED HOST memory (8 distinct batches cycled) and the H2D copy of batch t+1 is issued on a copy stream
+while step t runs, INSIDE the timed region -- that is `value`.  The same K steps are then timed once more with the
+batches resident in HBM (--device-resident makes that the only leg) and both rates are printed as `input_ab`
+{host, resident}, so the PCIe cost is on the line.  After the W warm-up steps the replay settles for --settle-s
+seconds (untimed; the step count is reported as `settle_steps` and included in `warmup_total_steps`), then EXACTLY
+K steps are timed.  Rank 0 prints ONE JSON line; on the default invocation (c3, bf16, one GPU) it also carries
+`other_configs`: short legs of C2 and C5.
 
 Extra legs (rank 0, outside the timed region):
   roofline      HIP-event brackets around every conv-library launch over instrumented eager steps of the
                 same workload; the dominant kernel's algorithmic FLOP/s vs the dense MFMA peak of the dtype
   roofline_hbm  the same brackets around the HBM-bound entry points (data consistency, BatchNorm passes,
                 Adam) with their algorithmic bytes vs 8 TB/s
-  cpu_baseline  the CPU oracle's (plain torch fp32) step on the SAME batch (N=1 only), timed at 32 threads
-                and at os.cpu_count() threads, plus the PSNR of both paths on the same batch/weights.
+  cpu_baseline  the CPU oracle's (plain torch fp32) step on the SAME batch (N=1 only): one timed step at 32 and at
+                64 threads picks the thread count, then >= 5 timed steps at that count; plus the PSNR of both
+                paths on the same batch/weights.
 """
 import argparse
 import json
@@ -66,9 +70,11 @@ def parse():
   p.add_argument('--no-overlap', action='store_true', help='keep the VGG branch on the main stream')
   p.add_argument('--cpu-all-threads', action='store_true',
                  help='also time the CPU baseline at os.cpu_count() threads (256 on the GPU box: ~3 min per step)')
-  p.add_argument('--host-input', action='store_true',
-                 help='A/B: batches start in pinned host memory, H2D on a copy stream INSIDE the timed region '
-                      '(default: batches resident in HBM when the timed region starts, as the metric is defined)')
+  p.add_argument('--device-resident', action='store_true',
+                 help='A/B: batches resident in HBM when the timed region starts (default: pinned host batches, '
+                      'H2D on a copy stream INSIDE the timed region, as SURVEY 8d defines the metric)')
+  p.add_argument('--no-input-ab', action='store_true',
+                 help='skip the second timed pass (batches resident in HBM) that fills `input_ab`')
   p.add_argument('--settle-s', type=float, default=0.6,
                  help='untimed graph-replay settling after the W warm-up steps, seconds (0 = none)')
   p.add_argument('--no-other-configs', action='store_true',
@@ -107,15 +113,18 @@ class PinnedHostLoader(object):
   step t runs (4 rotating device buffer sets).  The consumer's stream waits for the copy's event."""
 
   _pinned = {}          # host batches are pinned ONCE (page-locking ~1 GB takes most of a second)
+  _resident = {}        # device copies of the resident A/B leg, made once
 
   def __init__(self, host_batches, n, device, resident=False):
     import torch
     self.n, self.batch_size = n, host_batches[0]['inp'].shape[0]
     self.resident = resident
-    if resident:
-      self.dev = [{k: v.to(device) for k, v in b.items()} for b in host_batches]
-      return
     key = id(host_batches)
+    if resident:
+      if key not in PinnedHostLoader._resident:
+        PinnedHostLoader._resident[key] = [{k: v.to(device) for k, v in b.items()} for b in host_batches]
+      self.dev = PinnedHostLoader._resident[key]
+      return
     if key not in PinnedHostLoader._pinned:
       PinnedHostLoader._pinned[key] = [{k: v.pin_memory() for k, v in b.items()} for b in host_batches]
     self.host = PinnedHostLoader._pinned[key]
@@ -183,18 +192,18 @@ def _thread_counts(all_threads):
   return sorted(counts)
 
 
-def cpu_baseline_c3(runner, host_batch, steps=2, all_threads=False):
-  """The oracle's GAN step on the host cores: same weights, the SAME batch (all slices), timed per thread
-  count of _thread_counts()."""
+def cpu_baseline_c3(runner, host_batch, steps=5, all_threads=False):
+  """The oracle's GAN step on the host cores: same weights, the SAME batch (all slices).  One timed step per thread
+  count of _thread_counts() picks the best count; the reported value is `steps` (>= 5) timed steps at
+  that count."""
   sys.path.insert(0, os.path.join(ROOT, 'oracle'))
   import torch
   import csmri_oracle as O
   b = host_batch['inp'].shape[0]
   PV = {k: v.detach().cpu().clone() for k, v in
         runner.gen_criteria['VGG19'].criterion.vgg.state_dict().items() if k.startswith('blocks')}
-  out = {}
-  for threads in _thread_counts(all_threads):
-    torch.set_num_threads(threads)
+
+  def fresh():
     PG, SG = _split_sd(runner.gen.state_dict())
     PD, SD = _split_sd(runner.disc.state_dict())
     PG = {k: (v.requires_grad_(True) if not k.startswith('pretrained_model') else v) for k, v in PG.items()}
@@ -203,16 +212,30 @@ def cpu_baseline_c3(runner, host_batch, steps=2, all_threads=False):
     dopt = O.make_adam(PD.values(), 2e-4, 0.5, 0.999)
     batch = {k: v.clone() for k, v in host_batch.items()}
     pool = O.ImagePool(80)
-    O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=pool)          # warm-up
+    return lambda: O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=pool)
+
+  probe = {}
+  for threads in _thread_counts(all_threads):
+    torch.set_num_threads(threads)
+    step = fresh()
+    step()                                       # warm-up
     t0 = time.time()
-    for _ in range(steps):
-      O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=pool)
-    out[threads] = b * steps / (time.time() - t0)
-  best = max(out, key=out.get)
-  return {'value': round(out[best], 4), 'unit': 'slices/s', 'cores': best, 'kind': 'port', 'cpu': _cpu_model(),
-          'by_threads': {str(k): round(v, 4) for k, v in out.items()}, 'host_threads': os.cpu_count(),
-          'sample': 'oracle (plain torch fp32) GAN step on the same %d slices of 256x256 as the GPU run, '
-                    '%d timed steps after 1 warm-up, per thread count' % (b, steps)}
+    step()
+    probe[threads] = b / (time.time() - t0)
+  best = max(probe, key=probe.get)
+  torch.set_num_threads(best)
+  step = fresh()
+  step()
+  t0 = time.time()
+  for _ in range(steps):
+    step()
+  value = b * steps / (time.time() - t0)
+  return {'value': round(value, 4), 'unit': 'slices/s', 'cores': best, 'kind': 'port', 'cpu': _cpu_model(),
+          'probe_by_threads': {str(k): round(v, 4) for k, v in probe.items()}, 'host_threads': os.cpu_count(),
+          'timed_steps': steps,
+          'sample': 'oracle (plain torch fp32) GAN step on the same %d slices of 256x256 as the GPU run: one timed '
+                    'step per thread count picks the count, then %d timed steps after 1 warm-up at that count'
+                    % (b, steps)}
 
 
 def psnr_probe_c3(runner, host_batch, scale):
@@ -232,29 +255,42 @@ def psnr_probe_c3(runner, host_batch, scale):
   return O.psnr_batch(pred, host_batch['target']), O.psnr_batch(want['pred'], host_batch['target'])
 
 
-def cpu_baseline_c2(runner, host_batch, sample_b=16, steps=3, all_threads=False, fast=False):
+def cpu_baseline_c2(runner, host_batch, sample_b=16, steps=5, all_threads=False, fast=False):
   sys.path.insert(0, os.path.join(ROOT, 'oracle'))
   import torch
   import csmri_oracle as O
-  out, psnr = {}, None
   batch = {k: v[:sample_b].clone() for k, v in host_batch.items()}
-  for threads in ([min(32, os.cpu_count() or 1)] if fast else _thread_counts(all_threads)):
-    torch.set_num_threads(threads)
+
+  def fresh():
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in runner.model.state_dict().items()}
     opt = O.make_adam(P.values(), 2e-4, 0.9, 0.999)
-    if psnr is None:
-      with torch.no_grad():
-        psnr = O.psnr_batch(O.recnet_forward(P, batch['inp'], batch['kspace'], batch['mask'], 5), batch['target'])
-    O.recnet_mse_step(P, opt, batch, 5)
+    return P, (lambda: O.recnet_mse_step(P, opt, batch, 5))
+
+  probe = {}
+  counts = [min(32, os.cpu_count() or 1)] if fast else _thread_counts(all_threads)
+  for threads in counts:
+    torch.set_num_threads(threads)
+    _, step = fresh()
+    step()
     t0 = time.time()
-    for _ in range(steps):
-      O.recnet_mse_step(P, opt, batch, 5)
-    out[threads] = sample_b * steps / (time.time() - t0)
-  best = max(out, key=out.get)
-  return {'value': round(out[best], 4), 'unit': 'slices/s', 'cores': best, 'kind': 'port', 'cpu': _cpu_model(),
-          'by_threads': {str(k): round(v, 4) for k, v in out.items()}, 'host_threads': os.cpu_count(),
-          'sample': 'oracle (plain torch fp32) RecNet(5,3,32) MSE step, first %d slices of the batch, %d timed '
-                    'steps after 1 warm-up, per thread count' % (sample_b, steps)}, psnr
+    step()
+    probe[threads] = sample_b / (time.time() - t0)
+  best = max(probe, key=probe.get)
+  torch.set_num_threads(best)
+  P, step = fresh()
+  with torch.no_grad():
+    psnr = O.psnr_batch(O.recnet_forward(P, batch['inp'], batch['kspace'], batch['mask'], 5), batch['target'])
+  step()
+  t0 = time.time()
+  for _ in range(steps):
+    step()
+  value = sample_b * steps / (time.time() - t0)
+  return {'value': round(value, 4), 'unit': 'slices/s', 'cores': best, 'kind': 'port', 'cpu': _cpu_model(),
+          'probe_by_threads': {str(k): round(v, 4) for k, v in probe.items()}, 'host_threads': os.cpu_count(),
+          'timed_steps': steps,
+          'sample': 'oracle (plain torch fp32) RecNet(5,3,32) MSE step, first %d slices of the batch: one timed step '
+                    'per thread count picks the count, then %d timed steps after 1 warm-up at that count'
+                    % (sample_b, steps)}, psnr
 
 
 def roofline(runner, loader_factory, dtype, steps=2, config='c3'):
@@ -297,9 +333,11 @@ def roofline(runner, loader_factory, dtype, steps=2, config='c3'):
   # HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very
   # command (tools/pmc_bench.sh; FETCH_SIZE doubled per the gfx950 correction), committed under profiles/
   traffic, traffic_src = None, None
-  for tname in ('r03_pmc_bench_traffic.json', 'r02_pmc_bench_traffic.json', 'r01_pmc_bench_traffic.json'):
+  tnames = {'c3': ('r04_pmc_bench_traffic.json', 'r03_pmc_bench_traffic.json', 'r02_pmc_bench_traffic.json'),
+            'c2': ('r04_pmc_bench_traffic_c2.json', 'r03_pmc_bench_traffic_c2.json')}.get(config, ())
+  for tname in tnames:
     tpath = os.path.join(ROOT, 'profiles', tname)
-    if config == 'c3' and dtype == 'bf16' and traffic is None and os.path.exists(tpath):   # the PMC passes ran this workload
+    if dtype == 'bf16' and traffic is None and os.path.exists(tpath):   # the PMC passes ran this workload
       for name, rec in json.load(open(tpath)).items():
         if dom in name:
           traffic = round(rec['fetch_bytes_per_launch'] + rec['write_bytes_per_launch'])
@@ -342,9 +380,9 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
     host_batches = [synth_batch(batch, size, size, acc=4, seed=conf.seed + 97 * rank + 100000 * i)
                     for i in range(N_HOST_BATCHES)]
   dev = torch.device('cuda', torch.cuda.current_device())
-  resident = not args.host_input
+  resident = bool(args.device_resident)
 
-  def loader_factory(n):
+  def loader_factory(n, resident=resident):
     return PinnedHostLoader(host_batches, n, dev, resident=resident)
 
   def request(loader, volatile=False):      # batches come off the loader as this rank's shard, on the device
@@ -399,22 +437,32 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
         break
   if min_timed_s > 0 and settle_steps > 0:
     steps = max(steps, int(1.35 * min_timed_s / est) + 1)     # (est includes per-chunk sync overhead: margin)
-  if ws > 1:
-    torch.distributed.barrier()
-  torch.cuda.synchronize()
-  timed_loader = loader_factory(steps)          # buffers and streams exist before the clock starts
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  losses, metrics = runner.train_epoch(timed_loader, 1, steps_per_train_summary=10 ** 9)
-  torch.cuda.synchronize()
-  if ws > 1:
-    torch.distributed.barrier()
-  torch.cuda.synchronize()
-  dt = time.perf_counter() - t0
-  if ws > 1:
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
+
+  def timed(resident_leg):
+    """EXACTLY `steps` steps between barrier + synchronize pairs; max over ranks."""
+    if ws > 1:
+      torch.distributed.barrier()
+    torch.cuda.synchronize()
+    timed_loader = loader_factory(steps, resident_leg)          # buffers and streams exist before the clock starts
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = runner.train_epoch(timed_loader, 1, steps_per_train_summary=10 ** 9)
+    torch.cuda.synchronize()
+    if ws > 1:
+      torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt_ = time.perf_counter() - t0
+    if ws > 1:
+      t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+      torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+      dt_ = float(t.item())
+    return dt_, res
+
+  dt, (losses, metrics) = timed(resident)
+  dt_resident = None
+  if not resident and not args.no_input_ab:
+    # the A/B leg: the same K steps with the batches already in HBM (its rate is reported, never `value`)
+    dt_resident, _ = timed(True)
 
   # the instrumented roofline pass trains too (its steps all-reduce): every rank takes part
   prefetch_on = bool(getattr(runner, 'prefetch_pretrained', False))
@@ -447,13 +495,17 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
     mode = 'eager' if no_graphs else 'hipGraph replay (one graph per step)'
   line = {
       'metric': metric, 'value': round(value, 2), 'unit': 'slices/s',
-      'n_gpus': ws, 'steps': steps, 'warmup': warmup,
+      'n_gpus': ws, 'steps': steps, 'warmup': warmup, 'warmup_total_steps': warmup + settle_steps,
       'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
       'input': 'batches resident in HBM when the timed region starts (%d distinct batches cycled)' % N_HOST_BATCHES
                if resident else
                'pinned host batches, H2D on a copy stream inside the timed region (%d distinct batches cycled)'
                % N_HOST_BATCHES,
+      'input_ab': None if dt_resident is None else
+                  {'host': round(slices / dt, 2), 'resident': round(slices / dt_resident, 2), 'unit': 'slices/s',
+                   'note': 'value = host (H2D of every batch inside the timed region); resident = the same K steps '
+                           'timed again with the batches already in HBM'},
       'timed_region_s': round(dt, 3), 'settle_steps': settle_steps,
       'prefetch': 'frozen RecNet forward of batch t+1 on a side stream during step t' if prefetch_on else None,
       'launch_mode': mode,
@@ -490,7 +542,7 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
     else:
       fast = args.other_cpu_fast and config != args.config
       base, psnr_cpu = cpu_baseline_c2(ref_runner, host_batches[0], all_threads=args.cpu_all_threads,
-                                       steps=1 if fast else 3, fast=fast)
+                                       steps=3 if fast else 5, fast=fast)
       line['cpu_baseline'] = base
       with torch.no_grad():
         ref_runner.model.train()
@@ -532,7 +584,7 @@ def main():
         o = run_leg(args, cfg, 'bf16', DEFAULT_BATCH[cfg], 20, 5, 1, 0, want_roofline=not args.no_roofline,
                     want_cpu=not args.no_cpu_baseline, min_timed_s=0.5)
         keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'settle_steps', 'ms_per_step', 'dtype', 'config',
-                'algorithmic_tflops', 'launch_mode', 'input', 'roofline', 'roofline_hbm', 'psnr_delta_db',
+                'algorithmic_tflops', 'launch_mode', 'input', 'input_ab', 'roofline', 'roofline_hbm', 'psnr_delta_db',
                 'psnr_hip_db', 'psnr_cpu_db', 'cpu_baseline', 'final_losses')
         others.append({k: o[k] for k in keep if k in o})
       except Exception as e:                      # the headline must survive a failing side leg

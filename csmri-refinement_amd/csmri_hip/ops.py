@@ -876,7 +876,7 @@ def _grad_targets(layer):
 def convblock_fused_backward(plan, saved, g, need_dx, out_complex):
   """The whole backward of a fused conv block in one launch (csrc/convblock_bwd.hip) + the slab reduction of its three
   weight gradients; returns (ok, dx).  ``saved`` = [x, a1, a2, _]; ``g``: gradient of the block output."""
-  if not FUSED_CONVBLOCK_BWD or len(plan) != 3 or PROFILE is not None:
+  if not FUSED_CONVBLOCK_BWD or len(plan) != 3:
     return False, None
   layers = [l for l, _ in plan]
   slopes = [s for _, s in plan]
@@ -935,7 +935,12 @@ def convblock_fused_backward(plan, saved, g, need_dx, out_complex):
     descs.append((wd, slab, dw, db))
   if LAUNCH_LOG is not None:
     LAUNCH_LOG.append(('convblock', 'convblock_bwd_kernel', z))
-  lib.call('csmri_convblock_fused_bwd', C.byref(d), stream())
+  # algorithmic FLOPs of the launch: the three weight gradients + the data gradients of layers 3 and 2 (+ layer 1's
+  # when dX is wanted), 2 per MAC
+  per_pix = 9.0 * (l0.cin * l0.cout + layers[1].cin * layers[1].cout + layers[2].cin * layers[2].cout)
+  flops = 2.0 * b * h * w * (2.0 * per_pix - (0.0 if need_dx else 9.0 * l0.cin * l0.cout))
+  with _Timed('convblock_bwd_kernel', flops):
+    lib.call('csmri_convblock_fused_bwd', C.byref(d), stream())
   fq = _WGRAD['finish']
   want = WGRAD_FINISH_MULTI == '1' or (WGRAD_FINISH_MULTI == 'auto' and _WGRAD['stream'] is None)
   if want and GRAD_READY_HOOK is None and _ensure_flush_callback():

@@ -739,7 +739,11 @@ class AdversarialRunner(BaseRunner):
     new = [o.param_groups[0]['lr'] for o in (self.gen_optimizer, self.disc_optimizer) if o is not None]
     if new != old_lrs and getattr(self, '_graph', None) is not None:
       example = {k: v.clone() for k, v in self._graph['static'].items()}
+      # drop the old graphs (incl. the look-ahead graph) and their pool BEFORE the new capture
       self.disable_graphs()
+      import gc
+      gc.collect()
+      torch.cuda.empty_cache()
       self.enable_graphs(example, warmup=0)
 
   # -- the reference's control flow, literally: used whenever a network is disabled by a pretraining

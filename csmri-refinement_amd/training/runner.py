@@ -63,6 +63,8 @@ class Runner(BaseRunner):
     self.val_metric_fns = val_metric_fns or {}
     self.train_model_input_fn = self._get_model_input_fn(model, train_input_batch_transform)
     self.test_model_input_fn = self._get_model_input_fn(model, test_input_batch_transform)
+    # loss weights are configuration constants: read back once, here (never under a graph capture)
+    self._host_weights = [float(w) for w in self.loss_weights.detach().cpu()] if self.criteria else None
 
   def get_named_outputs(self, data):
     batch, out = data[0], data[1]
@@ -108,7 +110,12 @@ class Runner(BaseRunner):
     G = getattr(self, '_graph', None)
     if G is not None and self._lr() != old_lr:
       example = {k: v.clone() for k, v in G['static'].items()}
+      # drop the old graph and its private pool BEFORE the new capture (otherwise peak memory doubles at batch 64)
       self.disable_graphs()
+      del G
+      import gc
+      gc.collect()
+      torch.cuda.empty_cache()
       self.enable_graphs(example, warmup=0)
 
   def predict(self, batch):

@@ -28,7 +28,12 @@ def _check_headline(d, steps, warmup):
   assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
   assert d['dtype'] == 'bf16' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
   assert abs(d['value'] - 8 * steps / (d['ms_per_step'] * steps * 1e-3)) < 0.02 * d['value']
-  assert 'resident in HBM' in d['input']
+  # the metric includes the H2D of every batch (reference training/base_runner.py:29-41); the resident
+  # A/B leg is reported beside it, never as `value`
+  assert 'H2D on a copy stream inside the timed region' in d['input']
+  ab = d['input_ab']
+  assert abs(ab['host'] - d['value']) < 1e-6 * d['value'] + 0.02 and ab['resident'] > 0
+  assert d['warmup_total_steps'] == d['warmup'] + d['settle_steps']
   rl = d['roofline']
   for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
     assert k in rl, k
@@ -47,9 +52,13 @@ def test_bench_json_line_schema_with_other_configs():
   assert len(others) == 2 and not any('error' in o for o in others), others
   c2, c5 = others
   assert 'C2' in c2['config']['workload'] and 'C5' in c5['config']['workload']
+  # the C2 leg's roofline describes the kernel the timed step runs (the fused conv-block backward), not the per-layer
+  # backward it replaces
+  assert c2['roofline']['kernel'] == 'convblock_bwd_kernel', c2['roofline']
   for o in others:
-    for k in ('config', 'value', 'ms_per_step', 'dtype', 'roofline', 'roofline_hbm'):
+    for k in ('config', 'value', 'ms_per_step', 'dtype', 'roofline', 'roofline_hbm', 'input', 'input_ab'):
       assert k in o, k
+    assert 'H2D on a copy stream inside the timed region' in o['input']
     assert o['dtype'] == 'bf16' and o['value'] > 0 and o['steps'] * o['ms_per_step'] >= 450.0    # >= 0.5 s timed (10 % slack)
     b = o['config']['per_gpu_batch']
     assert abs(o['value'] - b / (o['ms_per_step'] * 1e-3)) < 0.02 * o['value']

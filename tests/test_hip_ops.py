@@ -646,6 +646,63 @@ def test_convblock_fused_backward(hip, shape, complex_out, need_dx):
     assert float(xd.grad[..., 2:].float().abs().max()) == 0.0
 
 
+def test_convblock_fused_forward_backward_at_bench_shape(hip):
+  """The C2 benchmark's own shape -- 64 slices of 256 x 256 (bench.py --config c2), where
+  csmri_convblock_fused_bwd_splits(b, h, w) and the persistent-worker tiling differ from the small cases above --
+  with ABSOLUTE bounds against torch autograd on the CPU (reference models/recnet.py:29-62 under loss.backward() of
+  training/runner.py:163) on the same bf16-rounded operands and saved activations:
+    forward  relative L2 <= 1e-2 (bf16 intermediates), dense complex fp32 output;
+    backward dX relative L2 <= 4e-3 (dA2, dA1 and dX are each rounded to bf16 once), dW / db <= 3e-3 (fp32 sums of
+    ~4 M products of bf16-rounded factors)."""
+  ops = hip.ops
+  b, h, w = 64, 256, 256
+  g = torch.Generator().manual_seed(64256)
+  ws = [torch.randn(32, 2, 3, 3, generator=g) * 0.4, torch.randn(32, 32, 3, 3, generator=g) * 0.08,
+        torch.randn(2, 32, 3, 3, generator=g) * 0.08]
+  bs = [torch.randn(32, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(2, generator=g) * 0.1]
+  x = torch.randn(b, 2, h, w, generator=g)
+  gy = torch.randn(b, 2, h, w, generator=g)
+  params = [(torch.nn.Parameter(wt.clone().cuda()), torch.nn.Parameter(bi.clone().cuda())) for wt, bi in zip(ws, bs)]
+  plan = [(ops.ConvLayer(wp, bp, 1, (1, 1, 1, 1), 'zero', torch.bfloat16), 0.01 if i < 2 else 1.0)
+          for i, (wp, bp) in enumerate(params)]
+  xd = to_dev_nhwc(x, torch.bfloat16).requires_grad_(True)
+  log = ops.LAUNCH_LOG = []
+  try:
+    y = ops.ConvActStack.apply(xd, plan, ('complex', torch.float32), *[t for pr in params for t in pr])
+    y.backward(to_dev_nhwc(gy, torch.float32)[..., :2].contiguous())
+    ops.join_wgrad_stream()
+    torch.cuda.synchronize()
+  finally:
+    ops.LAUNCH_LOG = None
+  names = [e[1] for e in log]
+  assert names == ['convblock_fwd_kernel<true>', 'convblock_bwd_kernel'], names
+  assert log[1][2] == hip.lib.raw('csmri_convblock_fused_bwd_splits')(b, h, w)
+  got_y = y.detach().permute(0, 3, 1, 2).float().cpu()
+  got = [from_dev_nhwc(xd.grad, 2)] + [t.grad.cpu().clone() for pr in params for t in pr]
+  assert float(xd.grad[..., 2:].float().abs().max()) == 0.0
+  del y, xd
+  torch.cuda.empty_cache()
+  # oracle
+  xr = x.bfloat16().float().requires_grad_(True)
+  wr = [wt.bfloat16().float().requires_grad_(True) for wt in ws]
+  br = [bi.clone().requires_grad_(True) for bi in bs]
+  r = xr
+  for i in range(3):
+    r = F.conv2d(F.pad(r, (1, 1, 1, 1)), wr[i], br[i])
+    if i < 2:
+      r = F.leaky_relu(r, 0.01)
+      r = r + (r.detach().bfloat16().float() - r.detach())      # value rounded to bf16, gradient straight through
+  e_y = rel_l2(got_y, r.detach())
+  print('convblock bench shape fwd vs oracle rel_l2 %.3e' % e_y)
+  assert e_y < 1e-2
+  r.backward(gy.bfloat16().float())
+  want = [xr.grad] + [t.grad for pr in zip(wr, br) for t in pr]
+  for lab, a, o in zip(['dx', 'dw1', 'db1', 'dw2', 'db2', 'dw3', 'db3'], got, want):
+    e = rel_l2(a, o)
+    print('convblock bench shape bwd %-4s vs CPU autograd rel_l2 %.3e' % (lab, e))
+    assert e < (4e-3 if lab == 'dx' else 3e-3), (lab, e)
+
+
 def test_layout_roundtrip(hip):
   ops = hip.ops
   x = torch.randn(2, 3, 8, 12)

@@ -899,6 +899,88 @@ def test_full_width_256_b8_bf16_step_vs_fp32_oracle(env):
   assert not bad, bad
 
 
+def test_c2_recnet5_bf16_train_step_vs_oracle(env):
+  """BASELINE config C2 as benchmarked (bench.py --config c2: RecNet(5 blocks, 3 convs, 32 filters), 256 x 256, bf16
+  compute -- the fused conv-block forward / backward kernels and the bf16-gradient DC adjoints are ON, which the fp32 F3
+  test does not reach), one Runner._train_step (reference training/runner.py:154-178) on 16 slices against the fp32 CPU
+  oracle O.recnet_mse_step from the same weights:
+    loss within 2e-3 relative, training PSNR within 0.01 dB (north_star's tolerance);
+    every gradient tensor (30 of them, through 5 cascades and 5 DC adjoints): deviation from the fp32 oracle at most
+    2 x the deviation of the oracle with bf16 storage emulated (oracle/csmri_lowprec.py: the format's own floor), or
+    2e-2; and cos >= 0.99 for every tensor;
+    the post-step parameters move by Adam's lr in the oracle's direction for >= 99 % of the well-conditioned elements."""
+  Configuration, set_dtype = env
+  from training import build_runner
+  import utils
+  set_dtype('bf16')
+  conf = recnet_conf(Configuration, 5, 'bf16')
+  B = 16
+  conf.batch_size = B
+  utils.set_random_seeds(conf.seed)
+  runner = build_runner(conf, 'standard', '0', 'train')
+  P0 = {k: v.detach().cpu().clone() for k, v in runner.model.state_dict().items()}
+  batch = O.synth_batch(B, 256, 256, acc=4, seed=2256)
+  grads = {}
+  opt = runner.optimizer
+  orig, names = opt.apply, {id(p): n for n, p in runner.model.named_parameters()}
+
+  def apply():
+    grads.update({names[id(p)]: p.grad.detach().float().cpu().clone() for p in opt.params})
+    orig()
+  opt.apply = apply
+  from csmri_hip import ops
+  log = ops.LAUNCH_LOG = []
+  try:
+    losses, metrics = runner.train_epoch(Loader([batch]), 1)
+    torch.cuda.synchronize()
+  finally:
+    ops.LAUNCH_LOG = None
+  kinds = [e[1] for e in log if e[0] == 'convblock']
+  assert kinds.count('convblock_fwd_kernel<true>') == 5 and kinds.count('convblock_bwd_kernel') == 5, kinds
+
+  def oracle(emulate):
+    P = {k: v.clone().requires_grad_(True) for k, v in P0.items()}
+    opt_o = O.make_adam(P.values(), conf.optimizer['learning_rate'], 0.9, 0.999)
+    got = {}
+    orig_step = opt_o.step
+
+    def step():
+      got.update({k: v.grad.detach().clone() for k, v in P.items()})
+      orig_step()
+    opt_o.step = step
+    with LP.emulate(emulate):
+      res, _ = O.recnet_mse_step(P, opt_o, batch, 5)
+    return res, got, {k: v.detach() for k, v in P.items()}
+  ref, g_ref, P_ref = oracle(None)
+  emu, g_emu, _ = oracle('bf16')
+  rel = abs(losses['loss_MSE'].value - ref['loss_MSE']) / ref['loss_MSE']
+  rel_e = abs(emu['loss_MSE'] - ref['loss_MSE']) / ref['loss_MSE']
+  dpsnr = abs(metrics['psnr'].value - ref['psnr'])
+  print('C2 bf16 step: loss hip %.7e oracle %.7e rel %.3e (bf16-storage floor %.3e); psnr hip %.4f oracle %.4f' %
+        (losses['loss_MSE'].value, ref['loss_MSE'], rel, rel_e, metrics['psnr'].value, ref['psnr']))
+  assert rel < 2e-3 and dpsnr < 0.01, (rel, dpsnr)
+  bad, worst = [], (1.0, '')
+  for k, gr in g_ref.items():
+    cos, err = _cos_err(grads[k].reshape(gr.shape), gr)
+    cos_e, err_e = _cos_err(g_emu[k], gr)
+    print('C2 grad %-34s hip cos %.5f rel_l2 %.3e | floor cos %.5f rel_l2 %.3e' % (k, cos, err, cos_e, err_e))
+    if err > max(2.0 * err_e, 2e-2) or (gr.numel() > 2 and cos < 0.99):
+      bad.append((k, cos, err, err_e))
+    if gr.numel() > 2 and cos < worst[0]:
+      worst = (cos, k)
+  print('C2 bf16 step: worst gradient cosine %.5f (%s)' % worst)
+  assert not bad, bad
+  # Adam's first step moves every element by ~lr against its gradient's sign: the elements whose oracle gradient is
+  # well above the format's noise (>= 5 % of the tensor's maximum) must move the oracle's way (>= 99 % of them)
+  lr = conf.optimizer['learning_rate']
+  cur = runner.model.state_dict()
+  for k, v in P_ref.items():
+    well = g_ref[k].abs() > 5e-2 * g_ref[k].abs().max()
+    d_h, d_o = (cur[k].cpu() - P0[k])[well], (v - P0[k])[well]
+    agree = float(((d_h - d_o).abs() < 0.25 * lr).float().mean())
+    assert agree >= 0.99, (k, agree)
+
+
 @pytest.mark.parametrize('scale', [0.02, 0.25])
 def test_bf16_psnr_where_the_unet_contributes(env, scale):
   """The 0.01 dB criterion with the U-Net switched ON (SURVEY A-10: at the reference's

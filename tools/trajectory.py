@@ -11,7 +11,11 @@ same image-pool decisions (python `random`, re-seeded), eager launches:
   c3   2-refinement GAN step; the frozen RecNet(3,3,32) is first trained for --pretrain-steps fp32 MSE steps and
        handed to both runs through the reference's pretrained_weights mechanism
 `--dtypes fp32,bf16,fp32p`: fp32p is the CONTROL, the fp32 run again from initial weights perturbed by 1e-6 relative --
-how far two fp32 trajectories drift apart by themselves.
+how far two fp32 trajectories drift apart by themselves.  `fp32p1`, `fp32p2`, ..., `bf16p1`, ...: further members of
+the ensemble (perturbation seed k); `--ensemble N` appends N perturbed members per dtype and `summary.ensemble`
+compares the two DISTRIBUTIONS of the final held-out PSNR (mean, standard deviation, Welch t) -- one pair of
+trajectories on the steep part of a learning curve differs by a time shift of a few steps, which is not a statement
+about the format.
 
 Recorded per dtype: every step's losses and training PSNR (curves down-sampled to <= 250 points), and at the end
 the PSNR of the trained model on held-out batches (train-mode BatchNorm for the GAN generator as during training,
@@ -99,14 +103,18 @@ def psnr_of(runner, batches, train_mode):
 
 def run(config, dtype, args, train, held, pretrained, dev):
   import torch
-  perturbed = dtype == 'fp32p'
+  # 'fp32p', 'fp32p3', 'bf16p2' ...: the run from initial weights perturbed by 1e-6 relative, perturbation seed k
+  import re
+  m = re.match(r'^(fp32|bf16|fp8)p(\d*)$', dtype)
+  perturbed = m is not None
+  pseed = 0
   if perturbed:
-    dtype = 'fp32'
+    dtype, pseed = m.group(1), int(m.group(2) or 0)
   runner, conf = build(config, dtype, args.batch, args.width, args.seed, pretrained)
   if perturbed:
     # CONTROL: the fp32 run again from initial weights moved by 1e-6 relative (a few fp32 ulps): how far two fp32
     # trajectories drift apart by themselves -- the yardstick for the bf16 run's distance
-    gen = torch.Generator(device='cpu').manual_seed(args.seed + 77)
+    gen = torch.Generator(device='cpu').manual_seed(args.seed + 77 + 1009 * pseed)
     with torch.no_grad():
       for net in (getattr(runner, 'gen', None), getattr(runner, 'disc', None), getattr(runner, 'model', None)):
         if net is None:
@@ -159,6 +167,9 @@ def main(argv=None):
   p.add_argument('--width', default='full', choices=['full', 'reduced'])
   p.add_argument('--dtypes', default='fp32,bf16')
   p.add_argument('--seed', type=int, default=1)
+  p.add_argument('--ensemble', type=int, default=0,
+                 help='append this many perturbed members (fp32p1.., bf16p1..) per base dtype in --dtypes')
+  p.add_argument('--variant', default='', help='free-text tag of the product variant under test (recorded)')
   p.add_argument('--out', default=None)
   args = p.parse_args(argv)
   if args.batch <= 0:
@@ -182,7 +193,11 @@ def main(argv=None):
     info['pretrained_recnet_psnr_heldout'] = psnr_of(r, held, True)
     del r
   results = {}
-  for dt in args.dtypes.split(','):
+  dts = args.dtypes.split(',')
+  if args.ensemble > 0:
+    for base in [d for d in dts if d in ('fp32', 'bf16')]:
+      dts += ['%sp%d' % (base, k) for k in range(1, args.ensemble + 1)]
+  for dt in dts:
     results[dt], _, _ = run(args.config, dt, args, train, held, pretrained, dev)
   ref = results['fp32']
   summary = {}
@@ -203,8 +218,29 @@ def main(argv=None):
         s['max_rel_delta_smoothed_' + k] = max(abs(a[i] - b[i]) / max(abs(a[i]), 1e-12) for i in tail)
         s['final_rel_delta_smoothed_' + k] = abs(a[-1] - b[-1]) / max(abs(a[-1]), 1e-12)
     summary[dt] = s
+  # ensemble view: members of a base dtype = the unperturbed run + its perturbed replicas
+  import math
+  import re
+  ens = {}
+  for dt, r in results.items():
+    base = re.match(r'^(fp32|bf16|fp8)', dt).group(1)
+    ens.setdefault(base, []).append(r['final_psnr_heldout_eval'])
+  ens_summary = {}
+  for base, v in ens.items():
+    n = len(v)
+    mean = sum(v) / n
+    var = sum((x - mean) ** 2 for x in v) / (n - 1) if n > 1 else 0.0
+    ens_summary[base] = {'n': n, 'mean_final_psnr_heldout_eval_db': mean, 'std_db': math.sqrt(var),
+                         'min_db': min(v), 'max_db': max(v), 'members_db': [round(x, 5) for x in v]}
+  if 'fp32' in ens_summary and 'bf16' in ens_summary and min(ens_summary['fp32']['n'], ens_summary['bf16']['n']) > 1:
+    a, b = ens_summary['fp32'], ens_summary['bf16']
+    se = math.sqrt(a['std_db'] ** 2 / a['n'] + b['std_db'] ** 2 / b['n'])
+    ens_summary['bf16_minus_fp32'] = {'delta_of_means_db': b['mean_final_psnr_heldout_eval_db'] - a['mean_final_psnr_heldout_eval_db'],
+                                      'standard_error_db': se,
+                                      'welch_t': (b['mean_final_psnr_heldout_eval_db'] - a['mean_final_psnr_heldout_eval_db']) / se if se > 0 else None}
+  summary['ensemble'] = ens_summary
   stride = max(1, args.steps // 250)
-  out = {'config': args.config, 'steps': args.steps, 'batch': args.batch, 'size': args.size, 'width': args.width,
+  out = {'config': args.config, 'variant': args.variant, 'steps': args.steps, 'batch': args.batch, 'size': args.size, 'width': args.width,
          'distinct_train_batches': args.distinct, 'heldout_batches': args.heldout, 'seed': args.seed,
          'smoothing_window_steps': w, 'curve_stride': stride, 'info': info, 'summary': summary,
          'runs': {dt: dict(r, curves={k: [round(x, 7) for x in v[::stride]] for k, v in r['curves'].items()})
