@@ -108,6 +108,47 @@ def build_runner(config, dtype, batch):
     return _build(conf, kind, '0', 'train'), conf
 
 
+NUMA_INFO = {}
+
+
+class _near_gpu(object):
+  """Run the enclosed host allocations on the CPUs of the GPU's NUMA node (first-touch places the pinned pages there),
+  then restore the thread's affinity.  Best effort: does nothing when sysfs does not say where the GPU sits."""
+
+  def __init__(self, device):
+    self.device, self.old = device, None
+
+  def __enter__(self):
+    try:
+      import torch
+      props = torch.cuda.get_device_properties(self.device)
+      bdf = '%04x:%02x:%02x.0' % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+      node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read())
+      NUMA_INFO.update(gpu_pci=bdf, gpu_numa_node=node)
+      if node < 0:
+        return self
+      cpus = set()
+      for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+        a, _, b = part.partition('-')
+        cpus.update(range(int(a), int(b or a) + 1))
+      self.old = os.sched_getaffinity(0)
+      use = cpus & self.old
+      if use:
+        os.sched_setaffinity(0, use)
+        NUMA_INFO['pinned_on_node'] = node
+    except Exception as e:          # no sysfs entry, no permission: plain pinning
+      NUMA_INFO['error'] = repr(e)
+    return self
+
+  def __exit__(self, *exc):
+    if self.old is not None:
+      try:
+        os.sched_setaffinity(0, self.old)
+      except OSError:
+        pass
+    return False
+
+
 class PinnedHostLoader(object):
   """Synthetic batches in PINNED HOST memory; batch t+1 is copied host->device on a copy stream while
   step t runs (4 rotating device buffer sets).  The consumer's stream waits for the copy's event."""
@@ -126,7 +167,8 @@ class PinnedHostLoader(object):
       self.dev = PinnedHostLoader._resident[key]
       return
     if key not in PinnedHostLoader._pinned:
-      PinnedHostLoader._pinned[key] = [{k: v.pin_memory() for k, v in b.items()} for b in host_batches]
+      with _near_gpu(device):        # page-lock on the GPU's own NUMA node (2-socket hosts: H2D from the far node is slower)
+        PinnedHostLoader._pinned[key] = [{k: v.pin_memory() for k, v in b.items()} for b in host_batches]
     self.host = PinnedHostLoader._pinned[key]
     self.copy_stream = torch.cuda.Stream()
     self.dev = [{k: torch.empty_like(v, device=device) for k, v in host_batches[0].items()} for _ in range(4)]
@@ -506,6 +548,7 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
                   {'host': round(slices / dt, 2), 'resident': round(slices / dt_resident, 2), 'unit': 'slices/s',
                    'note': 'value = host (H2D of every batch inside the timed region); resident = the same K steps '
                            'timed again with the batches already in HBM'},
+      'host_numa': dict(NUMA_INFO) or None,
       'timed_region_s': round(dt, 3), 'settle_steps': settle_steps,
       'prefetch': 'frozen RecNet forward of batch t+1 on a side stream during step t' if prefetch_on else None,
       'launch_mode': mode,

@@ -796,6 +796,26 @@ class ConvAct(torch.autograd.Function):
     return gx0, gx1, None, None, None, None, None
 
 
+class ConvActReplay(torch.autograd.Function):
+  """A sub-batch of a ConvAct call that has ALREADY run on a larger stacked batch (the discriminator's grouped pass):
+  forward launches nothing and returns the sub-batch's rows of the stored output; backward is ConvAct's own on those
+  rows.  ``w_req``: whether this sub-batch contributes weight gradients."""
+
+  @staticmethod
+  def forward(ctx, x0, x1, weight, bias, layer, act_slope, y_holder, w_req):
+    y_rows = y_holder[0]               # (in a list: a tensor argument returned as it is would be aliased to the input)
+    ctx.layer, ctx.act_slope = layer, act_slope
+    ctx.c0 = x0.shape[3]
+    ctx.in_hw = (x0.shape[1], x0.shape[2])
+    ctx.save_for_backward(x0, x1, y_rows)
+    ctx.w_req = bool(w_req) and weight.requires_grad
+    return y_rows
+
+  @staticmethod
+  def backward(ctx, gy):
+    return ConvAct.backward(ctx, gy)[:4] + (None, None, None, None)
+
+
 # RecNet conv blocks of the supported shape run as one launch (csmri_convblock_fused_fwd); tests turn it off for A/B
 FUSED_CONVBLOCK = True
 
@@ -1087,7 +1107,8 @@ class ConvBnAct(torch.autograd.Function):
   module had been called once per sub-batch, in order)."""
 
   @staticmethod
-  def forward(ctx, x0, x1, weight, gamma, beta, layer, bn, slope, training, dropmask, groups=1):
+  def run_forward(x0, x1, layer, bn, slope, training, dropmask, groups=1):
+    """The forward launches; returns (y, z, mean, invstd, snap)."""
     ho, wo = layer.out_hw(x0.shape[1], x0.shape[2])
     m = x0.shape[0] * ho * wo
     small = m < 32768
@@ -1098,6 +1119,11 @@ class ConvBnAct(torch.autograd.Function):
     if stats is not None and stats.shape[0] % groups:
       stats = None
     z, mean, invstd, snap = _bn_forward(y, stats, bn, layer.cout, slope, training, dropmask, groups)
+    return y, z, mean, invstd, snap
+
+  @staticmethod
+  def forward(ctx, x0, x1, weight, gamma, beta, layer, bn, slope, training, dropmask, groups=1):
+    y, z, mean, invstd, snap = ConvBnAct.run_forward(x0, x1, layer, bn, slope, training, dropmask, groups)
     ctx.layer, ctx.bn, ctx.slope, ctx.training, ctx.groups = layer, bn, slope, training, groups
     ctx.c0 = x0.shape[3]
     ctx.in_hw = (x0.shape[1], x0.shape[2])
@@ -1164,6 +1190,30 @@ class ConvBnAct(torch.autograd.Function):
       if GRAD_READY_HOOK is not None and not _wgrad_deferred_mode():
         GRAD_READY_HOOK(layer)
     return gx0, gx1, None, None, None, None, None, None, None, None, None
+
+
+class ConvBnActReplay(torch.autograd.Function):
+  """Groups [lo, hi) of a grouped ConvBnAct pass that has ALREADY run (``rec`` = the tuple ConvBnAct.run_forward
+  returned for the whole stacked batch, ``n`` images per group): forward launches nothing and returns those groups'
+  rows of the stored activation; backward is ConvBnAct's own two-pass BatchNorm backward / data gradient / weight
+  gradient on those rows with those groups' statistics.  This is how ONE discriminator pass over
+  [pool-fake; real; current-fake] serves the two backward passes of a training step (the discriminator loss
+  differentiates groups 0-1 w.r.t. the weights, the generator loss group 2 w.r.t. its input): reference
+  training/adversarial_runner.py:332,338,354 are three module calls whose results do not depend on each other."""
+
+  @staticmethod
+  def forward(ctx, x0, x1, weight, gamma, beta, layer, bn, slope, dropmask_rows, rec, n, lo, hi, w_req):
+    y, z, mean, invstd, snap = rec
+    ctx.layer, ctx.bn, ctx.slope, ctx.training, ctx.groups = layer, bn, slope, True, hi - lo
+    ctx.c0 = x0.shape[3]
+    ctx.in_hw = (x0.shape[1], x0.shape[2])
+    ctx.save_for_backward(x0, x1, y[lo * n:hi * n], snap, mean[lo:hi], invstd[lo:hi], dropmask_rows)
+    ctx.w_req = bool(w_req) and weight.requires_grad
+    return z[lo * n:hi * n]
+
+  @staticmethod
+  def backward(ctx, gz):
+    return ConvBnAct.backward(ctx, gz)[:5] + (None,) * 9
 
 
 def maxpool2_fwd(x):
@@ -1486,15 +1536,20 @@ def complex_abs_raw(x, dtype, mode, out=None):
 
 class ComplexAbs(torch.autograd.Function):
   """|x| of interleaved complex fp32 [B,H,W,2] -> NHWC [B,H,W,8] of ``dtype``.
-  mode 0: channel 0 = |x|; mode 3: channels 0..2 = (|x|-mean_c)/std_c (VGG input)."""
+  mode 0: channel 0 = |x|; mode 3: channels 0..2 = (|x|-mean_c)/std_c (VGG input).
+  ``holder``: optional one-element list with a dense [B,H,W,8] tensor of ``dtype`` that receives the result (e.g. one
+  group of a stacked batch, instead of a torch.cat of results); it is also what the call returns.  ``filled``: that
+  tensor already holds the result (no launch; only the autograd link is made)."""
 
   @staticmethod
-  def forward(ctx, x, dtype, mode):
+  def forward(ctx, x, dtype, mode, holder=None, filled=False):
     assert x.is_contiguous() and x.dtype == torch.float32
     b, h, w, _ = x.shape
-    out = torch.empty(b, h, w, 8, dtype=dtype, device=x.device)
-    lib.call('csmri_complex_abs', x.data_ptr(), b * h * w, out.data_ptr(), dt_of(out), 8, 8, mode,
-             stream())
+    if filled:                       # the holder's tensor already IS |x| (complex_abs_raw wrote it): link only
+      out = holder[0]
+      assert out.dtype == dtype and tuple(out.shape) == (b, h, w, 8)
+    else:
+      out = complex_abs_raw(x, dtype, mode, holder[0] if holder is not None else None)
     ctx.save_for_backward(x)
     ctx.mode = mode
     return out
@@ -1507,7 +1562,7 @@ class ComplexAbs(torch.autograd.Function):
     dx = torch.empty_like(x)
     lib.call('csmri_complex_abs_bwd', x.data_ptr(), b * h * w, g.data_ptr(), dt_of(g), g.stride(2),
              3 if ctx.mode == 3 else 1, ctx.mode, dx.data_ptr(), 0, stream())
-    return dx, None, None
+    return dx, None, None, None, None
 
 
 class RefineCombine(torch.autograd.Function):

@@ -36,10 +36,15 @@ class GANLoss(nn.Module):
     if self.loss_type == 'gen':
       return ops.BCELogits.apply(out_disc_fake['logits'], self.gen_label)
     pair = out_disc_fake.get('_pair_logits')
-    if pair is not None and pair is out_disc_real.get('_pair_logits') and pair.is_cuda:
-      # the two halves of ONE batched [fake; real] pass: one launch on the un-split logits (no slice nodes in the
-      # autograd graph: their backward was two fills, two copies and an add)
-      return ops.BCELogitsPair.apply(pair, self.disc_fake_label, self.disc_real_label)
+    if pair is not None and pair is out_disc_real.get('_pair_logits') and pair.is_cuda and \
+        {out_disc_fake.get('_pair_half'), out_disc_real.get('_pair_half')} == {0, 1}:
+      # the two halves of ONE batched pass: one launch on the un-split logits (no slice nodes in the autograd graph:
+      # their backward was two fills, two copies and an add).  Each half gets the label of the dict it came from --
+      # whichever way round the two were stacked
+      labels = [None, None]
+      labels[out_disc_fake['_pair_half']] = self.disc_fake_label
+      labels[out_disc_real['_pair_half']] = self.disc_real_label
+      return ops.BCELogitsPair.apply(pair, labels[0], labels[1])
     return (ops.BCELogits.apply(out_disc_fake['logits'], self.disc_fake_label) +
             ops.BCELogits.apply(out_disc_real['logits'], self.disc_real_label))
 

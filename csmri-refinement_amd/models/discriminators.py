@@ -10,6 +10,8 @@ sets (fc layers, weight norm, instance norm, average pooling) raise.
 features are NHWC device tensors (post-dropout, as the reference's in-place
 Dropout2d makes them -- SURVEY A-7); ``feature_channels`` gives the real channel
 count of each for the feature-matching loss."""
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -115,7 +117,10 @@ class CNNDiscriminator(nn.Module):
     """All Dropout2d masks of one forward in ONE launch (csmri_dropout2d_mask: Philox4x32-10 keyed by a per-module
     seed, the call counter in device memory so that a replayed hipGraph draws fresh masks); one contiguous [B,C]
     view per dropout layer, in layer order.  The seed comes from torch's CPU generator at first use
-    (torch.manual_seed makes runs reproducible)."""
+    (torch.manual_seed makes runs reproducible; with several ranks training.distributed.decorrelate_rng_streams has
+    re-seeded that generator per rank, so every rank draws its own masks).  The (seed, call counter) pair is not part
+    of state_dict(): like the reference, whose checkpoints hold no RNG state (utils/checkpoints.py:9-40), a resumed
+    run starts a new mask sequence."""
     cs = [f for _, bn, drop, f in self._layers if bn is not None and drop]
     if self.injected_dropout or not cs or any(c % 8 for c in cs) or device.type != 'cuda':
       return None
@@ -169,6 +174,74 @@ class CNNDiscriminator(nn.Module):
       out['features'] = feats + [lg]
       out['feature_channels'] = chans + [1]
     return out
+
+
+  def forward_grouped(self, nhwc, groups, subs):
+    """ONE pass over ``groups`` stacked module calls (reference training/adversarial_runner.py:332,338,354: the three
+    discriminator forwards of a training step read the same weights and do not depend on each other), returned as one
+    output dict per entry of ``subs`` = [(lo, hi, x_rows, wgrad, stream)]: groups [lo, hi) as a differentiable function
+    of ``x_rows`` (a tensor holding exactly those groups' rows of ``nhwc``; it may carry a gradient) whose backward
+    runs on those rows only -- with (``wgrad``) or without the weight gradients.  BatchNorm statistics, running-statistics
+    updates and Dropout2d draws are per group, in group order: the same numbers as ``groups`` separate calls."""
+    assert self.training and nhwc.shape[0] % groups == 0
+    ensure_pack_group(self)
+    n = nhwc.shape[0] // groups
+    drawn = self._draw_masks(nhwc.shape[0], nhwc.device)
+    n_drop = sum(1 for _, bn_, d_, _ in self._layers if bn_ is not None and d_)
+    recs, di, x = [], 0, nhwc
+    with torch.no_grad():
+      for conv, bn, drop, f in self._layers:
+        if bn is None:
+          y, _ = ops.conv_forward(conv.layer, x, None, True, self.slope, False, None)
+          recs.append((y, None))
+          x = y
+        else:
+          mask = None
+          if drop:
+            if drawn is not None:
+              mask = drawn.pop(0)
+              self.last_dropout_masks.append(mask)
+            else:
+              mask = self._dropmask(x.shape[0], f, x.device, groups, di, n_drop)
+            di += 1
+          rec = ops.ConvBnAct.run_forward(x, None, conv.layer, bn.state(True, groups), self.slope, True, mask, groups)
+          recs.append((rec, mask))
+          x = rec[1]
+      fin = self.final_conv['0']
+      lg_all, _ = ops.conv_forward(fin.layer, x, None, True, 1.0, False, torch.float32)
+    outs = []
+    for lo, hi, x_rows, wgrad, sub_stream in subs:
+      # ``sub_stream``: the stream this sub-graph is built on (autograd runs a node's backward on the stream its
+      # forward ran on); ``x_rows`` may be a callable that makes the input there
+      ctx = contextlib.nullcontext()
+      if sub_stream is not None:
+        sub_stream.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(sub_stream)
+      with ctx:
+        if callable(x_rows):
+          x_rows = x_rows()
+        assert x_rows.shape[0] == (hi - lo) * n
+        feats, chans, x = [], [], x_rows
+        for (conv, bn, drop, f), (rec, mask) in zip(self._layers, recs):
+          if bn is None:
+            x = ops.ConvActReplay.apply(x, None, conv.weight, conv.bias, conv.layer, self.slope,
+                                        [rec[lo * n:hi * n]], wgrad)
+          else:
+            x = ops.ConvBnActReplay.apply(x, None, conv.weight, bn.weight, bn.bias, conv.layer,
+                                          ops.BNState(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                                      bn.momentum),
+                                          self.slope, mask[lo * n:hi * n] if mask is not None else None, rec, n, lo, hi,
+                                          wgrad)
+          feats.append(x)
+          chans.append(f)
+        lg = ops.ConvActReplay.apply(x, None, fin.weight, fin.bias, fin.layer, 1.0, [lg_all[lo * n:hi * n]], wgrad)
+        logits = ops.ToNCHW.apply(lg, 1)
+        out = {'prob': _Sigmoid.apply(logits), 'logits': logits}
+        if self.compute_features:
+          out['features'] = feats + [lg]
+          out['feature_channels'] = chans + [1]
+      outs.append(out)
+    return outs
 
 
 class _Sigmoid(torch.autograd.Function):

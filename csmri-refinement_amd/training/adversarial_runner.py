@@ -18,6 +18,7 @@ exist, its gradient bucket is all-reduced on RCCL's stream while the third D for
 and the two VGG forwards run, and loss scalars stay on the device (one readback per
 logging interval instead of one blocking .data[0] per loss)."""
 from collections import OrderedDict
+import contextlib
 import logging
 
 import torch
@@ -64,6 +65,7 @@ def build_runner(conf, cuda, mode):
     initialize_pretrained_model(disc_conf, disc_model, cuda, conf.file)
   dist_utils.broadcast_module(gen_model)
   dist_utils.broadcast_module(disc_model)
+  dist_utils.decorrelate_rng_streams(conf.seed)
 
   gen_opt_conf = Configuration.from_dict(conf.generator_optimizer, conf)
   disc_opt_conf = Configuration.from_dict(conf.discriminator_optimizer, conf)
@@ -101,6 +103,7 @@ def _split_disc_output(out, b):
   first, second = {}, {}
   if torch.is_tensor(out.get('logits')) and out['logits'].shape[0] == 2 * b:
     first['_pair_logits'] = second['_pair_logits'] = out['logits']
+    first['_pair_half'], second['_pair_half'] = 0, 1       # (GANLoss assigns its labels by these, not by position)
   for k, v in out.items():
     if torch.is_tensor(v):
       first[k], second[k] = v[:b], v[b:]
@@ -194,6 +197,7 @@ class AdversarialRunner(BaseRunner):
     self._metric_stream = None
     self.vgg_early = None                 # None: decided at the first step (True on a single GPU)
     self.batch_disc_passes = True         # D(fake) and D(real) of the D phase as one grouped pass
+    self.batch_three_disc_passes = True   # ... together with the generator phase's D(fake): one pass of three groups
 
   # -- reference surface -------------------------------------------------------
   def get_named_outputs(self, data):
@@ -293,35 +297,63 @@ class AdversarialRunner(BaseRunner):
       self._fork_vgg(st, out_gen, batch)
     pair = None
     tgt = batch['target']
-    if self.batch_disc_passes and tgt.is_cuda and tgt.dim() == 4 and tgt.shape[1] == 2 and \
-        hasattr(self.disc_input_fn, 'out_dtype'):
-      # [fake; real] of the batched discriminator pass: the two inputs are written straight into the halves of
-      # one tensor (no torch.cat of their results)
-      b, _, h, w = tgt.shape
-      pair = torch.empty(2 * b, h, w, 8, dtype=self.disc_input_fn.out_dtype(), device=tgt.device)
-    in_fake = self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False, detach=True,
-                                 pool_decisions=self.pool_decisions, **({} if pair is None else {'out': pair[:b]}))
-    in_real = self.disc_input_fn(tgt, gen_inp[0], out_gen, is_real_input=True, detach=True,
-                                 **({} if pair is None else {'out': pair[b:]}))
-    if self.batch_disc_passes:
-      # the two passes of reference :333-341 as ONE pass over [fake; real] with per-half BatchNorm
-      # statistics and dropout draws (identical results, half the launches on D's small maps)
-      out_fake_d, out_real = _split_disc_output(
-          self.disc(nhwc=pair if pair is not None else torch.cat([in_fake, in_real], 0), groups=2), in_fake.shape[0])
-    else:
-      out_fake_d = self.disc(nhwc=in_fake)
-      out_real = self.disc(nhwc=in_real)
-    st['out_disc_real'] = out_real
     st['out_disc_fake_early'] = None
-    if self.overlap_streams and self.vgg_early and self.third_pass_early:
-      # single GPU: the third D forward (reference :354-357; same D weights, it only has to
-      # follow the two passes above for the BatchNorm running statistics) runs on its own stream
-      # next to the D loss and backward below -- two chains of small kernels share the chip
-      if self._side_stream3 is None:
-        self._side_stream3 = ops.named_stream('third')
-      self._side_stream3.wait_stream(torch.cuda.current_stream())
-      with torch.cuda.stream(self._side_stream3):
-        st['out_disc_fake_early'] = self._third_disc_pass(st)
+    can_stack = tgt.is_cuda and tgt.dim() == 4 and tgt.shape[1] == 2 and hasattr(self.disc_input_fn, 'out_dtype')
+    if self.batch_disc_passes and self.batch_three_disc_passes and can_stack:
+      # ALL THREE discriminator forwards of the step (reference :332, :338, :354 -- same weights, no dependence on
+      # each other) as ONE pass over [pool-fake; real; current-fake]: per-group BatchNorm statistics, running-statistics
+      # updates and dropout draws in the reference's order.  The discriminator loss then differentiates groups 0-1
+      # w.r.t. the weights, the generator losses group 2 w.r.t. its input (CNNDiscriminator.forward_grouped); |pred|
+      # is computed once and feeds both the history pool and group 2.
+      b, _, h, w = tgt.shape
+      x_all = torch.empty(3 * b, h, w, 8, dtype=self.disc_input_fn.out_dtype(), device=tgt.device)
+      fn = self.disc_input_fn
+      mag = fn.magnitude(out_gen, x_all[2 * b:])
+      fn(out_gen, gen_inp[0], out_gen, is_real_input=False, detach=True, pool_decisions=self.pool_decisions,
+         out=x_all[:b], mag=mag)
+      fn(tgt, gen_inp[0], out_gen, is_real_input=True, detach=True, out=x_all[b:2 * b])
+      live_stream = None
+      if self.overlap_streams and self.vgg_early and self.third_pass_early:
+        # the generator-loss graph of group 2 is BUILT on its own stream (its forward launches only the tiny logit
+        # conversions), so autograd runs its backward there, next to the VGG branch's (as the separate third pass did)
+        if self._side_stream3 is None:
+          self._side_stream3 = ops.named_stream('third')
+        live_stream = self._side_stream3
+      out_pair, out_cur = self.disc.forward_grouped(
+          x_all, 3, [(0, 2, x_all[:2 * b], True, None),
+                     (2, 3, lambda: fn.link(out_gen, x_all[2 * b:]), False, live_stream)])
+      out_fake_d, out_real = _split_disc_output(out_pair, b)
+      st['out_disc_fake_early'] = out_cur
+      st['_live_stream'] = live_stream
+    else:
+      if self.batch_disc_passes and can_stack:
+        # [fake; real] of the batched discriminator pass: the two inputs are written straight into the halves of
+        # one tensor (no torch.cat of their results)
+        b, _, h, w = tgt.shape
+        pair = torch.empty(2 * b, h, w, 8, dtype=self.disc_input_fn.out_dtype(), device=tgt.device)
+      in_fake = self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False, detach=True,
+                                   pool_decisions=self.pool_decisions, **({} if pair is None else {'out': pair[:b]}))
+      in_real = self.disc_input_fn(tgt, gen_inp[0], out_gen, is_real_input=True, detach=True,
+                                   **({} if pair is None else {'out': pair[b:]}))
+      if self.batch_disc_passes:
+        # the two passes of reference :333-341 as ONE pass over [fake; real] with per-half BatchNorm
+        # statistics and dropout draws (identical results, half the launches on D's small maps)
+        out_fake_d, out_real = _split_disc_output(
+            self.disc(nhwc=pair if pair is not None else torch.cat([in_fake, in_real], 0), groups=2), in_fake.shape[0])
+      else:
+        out_fake_d = self.disc(nhwc=in_fake)
+        out_real = self.disc(nhwc=in_real)
+      if self.overlap_streams and self.vgg_early and self.third_pass_early:
+        # single GPU: the third D forward (reference :354-357; same D weights, it only has to
+        # follow the two passes above for the BatchNorm running statistics) runs on its own stream
+        # next to the D loss and backward below -- two chains of small kernels share the chip
+        if self._side_stream3 is None:
+          self._side_stream3 = ops.named_stream('third')
+        self._side_stream3.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side_stream3):
+          st['out_disc_fake_early'] = self._third_disc_pass(st)
+        st['_live_stream'] = self._side_stream3
+    st['out_disc_real'] = out_real
     names, vals, disc_losses = [], [], []
     for name, criterion in self.disc_adv_criteria.items():
       loss = criterion(out_fake_d, out_real)
@@ -341,8 +373,8 @@ class AdversarialRunner(BaseRunner):
     st['names'], st['vals'] = names, vals
     if st['side_results']:                       # a segment (graph) ends with every stream joined
       torch.cuda.current_stream().wait_stream(self._side_stream)
-    if st['out_disc_fake_early'] is not None:
-      torch.cuda.current_stream().wait_stream(self._side_stream3)
+    if st.get('_live_stream') is not None:
+      torch.cuda.current_stream().wait_stream(st['_live_stream'])
     self._fork_prefetch(st)
     self._join_prefetch(st, 1)
 
@@ -450,12 +482,13 @@ class AdversarialRunner(BaseRunner):
       ev_m.record(torch.cuda.current_stream())
     else:
       self._fork_train_metrics(st)
-    if st.get('out_disc_fake_early') is not None:
-      # the third D pass lives on its own stream: run D's Adam there too.  Only that pass's
+    live = st.get('_live_stream')
+    if live is not None:
+      # the generator-phase D pass lives on its own stream: run D's Adam there too.  Only that pass's
       # backward (data gradients through the UPDATED D, ordering A) needs the new weights; the
       # VGG backward and the rest of the generator backward start without waiting for it.
-      self._side_stream3.wait_stream(torch.cuda.current_stream())
-      with torch.cuda.stream(self._side_stream3):
+      live.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(live):
         self.disc_optimizer.apply()
     else:
       self.disc_optimizer.apply()
@@ -467,12 +500,12 @@ class AdversarialRunner(BaseRunner):
     ops.join_wgrad_stream()
     st['names'].append('gen_loss')
     st['vals'].append(st['total_gen'].detach())
-    if st.get('out_disc_fake_early') is not None:
+    if live is not None:
       # D's forward-mode packs for the NEXT step, behind the third pass's backward on its stream
       # (next to the rest of the generator backward) instead of in front of the next D forward
-      with torch.cuda.stream(self._side_stream3):
+      with torch.cuda.stream(live):
         self._repack_disc()
-      torch.cuda.current_stream().wait_stream(self._side_stream3)
+      torch.cuda.current_stream().wait_stream(live)
     if st.pop('_metrics_pending', False):
       torch.cuda.current_stream().wait_stream(self._metric_stream)
     self._join_prefetch(st, 3)

@@ -24,21 +24,28 @@ def _build_input_fn(method, dtype_fn, image_pool=None, pool_label_swapping=False
   if method not in ('simple-magnitude',):
     raise NotImplementedError("discriminator input_method '%s' is outside the hot path" % method)
 
-  def input_wrapper(prediction_or_target, inp, out_gen, is_real_input, detach=False,
-                    pool_decisions=None, out=None):
-    """``out`` (detached inputs only): a dense [B,H,W,8] tensor of the compute dtype that receives the result --
-    the runner hands the two halves of one batch to the fake / real calls instead of concatenating their results."""
+  def _pred_of(prediction_or_target):
     if isinstance(prediction_or_target, dict):
       fast = prediction_or_target.get('_nhwc')
-      pred = fast['pred'] if fast is not None else prediction_or_target['pred']
-    else:
-      pred = prediction_or_target
+      return fast['pred'] if fast is not None else prediction_or_target['pred']
+    return prediction_or_target
+
+  def input_wrapper(prediction_or_target, inp, out_gen, is_real_input, detach=False,
+                    pool_decisions=None, out=None, mag=None):
+    """``out`` (detached inputs only): a dense [B,H,W,8] tensor of the compute dtype that receives the result --
+    the runner hands the groups of one stacked batch to the fake / real calls instead of concatenating their
+    results.  ``mag`` (detached inputs only): the magnitude image if the caller already has it (the same |pred|
+    feeds the history pool and the generator-phase pass)."""
+    pred = _pred_of(prediction_or_target)
     xc = _as_complex_nhwc(pred, detach)
     if detach and xc.is_cuda:
       pooled = image_pool is not None and (not is_real_input or pool_label_swapping) and image_pool.pool_size > 0
-      mag = ops.complex_abs_raw(xc.contiguous(), dtype_fn(), 0, None if pooled else out)
+      if mag is None:
+        mag = ops.complex_abs_raw(xc.contiguous(), dtype_fn(), 0, None if pooled else out)
+      elif not pooled and out is not None:
+        mag = out.copy_(mag)
       return image_pool.query(mag, pool_decisions, out) if pooled else mag
-    assert out is None
+    assert out is None and mag is None
     mag = ops.ComplexAbs.apply(xc.contiguous(), dtype_fn(), 0)       # [B,H,W,8], channel 0
     if detach:
       mag = mag.detach()
@@ -46,6 +53,19 @@ def _build_input_fn(method, dtype_fn, image_pool=None, pool_label_swapping=False
         mag = image_pool.query(mag, pool_decisions)
     return mag
 
+  def magnitude(prediction_or_target, out):
+    """|image| into ``out`` ([B,H,W,8] of the compute dtype): no autograd, no history pool."""
+    xc = _as_complex_nhwc(_pred_of(prediction_or_target), True)
+    return ops.complex_abs_raw(xc.contiguous(), dtype_fn(), 0, out)
+
+  def link(prediction_or_target, filled):
+    """The differentiable (is_real_input=False, detach=False) input whose values ``magnitude`` has ALREADY written
+    to ``filled``: launches nothing, returns ``filled`` as a function of the prediction (backward: the magnitude's
+    derivative)."""
+    xc = _as_complex_nhwc(_pred_of(prediction_or_target), False)
+    return ops.ComplexAbs.apply(xc.contiguous(), dtype_fn(), 0, [filled], True)
+
+  input_wrapper.magnitude, input_wrapper.link = magnitude, link
   input_wrapper.out_dtype = dtype_fn
 
   return input_wrapper

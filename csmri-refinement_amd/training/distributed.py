@@ -224,3 +224,19 @@ def broadcast_module(module, src=0):
     return
   for t in list(module.parameters()) + list(module.buffers()):
     dist.broadcast(t.data, src)
+
+
+def decorrelate_rng_streams(seed):
+  """Data parallelism: after the replicas have been built from the SAME seed (identical initial weights, then
+  broadcast), give every rank its own random streams for what stays per rank -- Dropout2d masks (the Philox key of
+  models/discriminators.py is drawn from torch's CPU generator at first use) and the image pool's swap decisions
+  (python `random`).  The reference's single-process DataParallel drew independent masks across the global batch
+  (utils/custom_data_parallel.py:26-35); identical streams on every rank would apply the same masks and the same
+  pool swaps to every shard.  No-op on one rank, so single-GPU runs keep the seeds of utils.set_random_seeds."""
+  if world_size() <= 1:
+    return
+  import random
+  r = rank()
+  mixed = (int(seed) + 0x9E3779B97F4A7C15 * (r + 1)) % (2 ** 63 - 1)
+  random.seed(mixed)
+  torch.manual_seed(mixed)

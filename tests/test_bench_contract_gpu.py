@@ -59,7 +59,7 @@ def test_bench_json_line_schema_with_other_configs():
     for k in ('config', 'value', 'ms_per_step', 'dtype', 'roofline', 'roofline_hbm', 'input', 'input_ab'):
       assert k in o, k
     assert 'H2D on a copy stream inside the timed region' in o['input']
-    assert o['dtype'] == 'bf16' and o['value'] > 0 and o['steps'] * o['ms_per_step'] >= 450.0    # >= 0.5 s timed (10 % slack)
+    assert o['dtype'] == 'bf16' and o['value'] > 0 and o['steps'] * o['ms_per_step'] >= 400.0    # ~0.5 s timed (the step count comes from the settle phase's rate)
     b = o['config']['per_gpu_batch']
     assert abs(o['value'] - b / (o['ms_per_step'] * 1e-3)) < 0.02 * o['value']
 

@@ -40,6 +40,16 @@ def _worker(rank, world, port, q):
     lin.weight.fill_(float(rank))
   D.broadcast_module(lin, 0)
   assert float(lin.weight.abs().max()) == 0.0
+  # per-rank random streams for dropout keys / image-pool swaps: same seed in, different streams out, reproducibly
+  import random
+  D.decorrelate_rng_streams(1)
+  mine = torch.tensor([float(torch.randint(0, 2 ** 30, (1,)).item()), float(random.randint(0, 2 ** 30))])
+  both = [torch.zeros(2), torch.zeros(2)]
+  dist.all_gather(both, mine)
+  assert both[0][0] != both[1][0] and both[0][1] != both[1][1], both
+  D.decorrelate_rng_streams(1)
+  again = torch.tensor([float(torch.randint(0, 2 ** 30, (1,)).item()), float(random.randint(0, 2 ** 30))])
+  assert torch.equal(mine, again)
   dist.barrier()
   dist.destroy_process_group()
   q.put((rank, 'ok'))

@@ -530,6 +530,108 @@ def test_grouped_disc_pass_equals_two_passes(env, dtype, size, small):
       assert int(s1[k]) == int(s2[k]) == 2, k
 
 
+@pytest.mark.parametrize('dtype,size,small', [('fp32', 64, True), ('bf16', 64, True), ('bf16', 128, False)])
+def test_three_group_disc_pass_equals_three_passes(env, dtype, size, small):
+  """CNNDiscriminator.forward_grouped on [a; b; c] -- the training step's ONE discriminator pass over
+  [pool-fake; real; current-fake] -- against the reference's three module calls (training/adversarial_runner.py
+  :332,338,354; SURVEY A-3: three BatchNorm running-statistics updates, three dropout draws):
+    * outputs and features of every group;
+    * first backward (the discriminator loss: groups a, b): every parameter gradient; c's input receives nothing;
+    * the weights are then changed (as D's Adam does between the two backward passes, ordering A of SURVEY A-4) and
+      the second backward (the generator loss: group c, no weight gradients) must give the input gradient of c that
+      the separate third call gives under the same changed weights, and leave the parameter gradients untouched;
+    * running statistics after three updates in order, num_batches_tracked == 3."""
+  import copy
+  Configuration, set_dtype = env
+  from training import build_runner
+  from csmri_hip import ops
+  set_dtype(dtype)
+  runner = build_runner(gan_conf(Configuration, dtype, small=small), 'adversarial', '0', 'train')
+  d1 = runner.disc
+  d2 = copy.deepcopy(d1)
+  d1.train(); d2.train()
+  g = torch.Generator().manual_seed(11)
+  cdt = torch.float32 if dtype == 'fp32' else torch.bfloat16
+  n = 2
+  xs = []
+  for _ in range(3):
+    x = torch.zeros(n, size, size, 8, dtype=cdt).cuda()
+    x[..., 0] = torch.rand(n, size, size, generator=g).cuda().to(cdt)
+    xs.append(x)
+  chans = [f for _, bn, drop, f in d1._layers if bn is not None and drop]
+  masks = [(torch.rand(n, c, generator=g) < 0.5).float() * 2.0 for _ in range(3) for c in chans]
+  wc = torch.randn(n, generator=g).cuda()          # weights of the third call's logits in the second loss
+
+  def perturb(d):          # what an optimizer step does between the two backward passes
+    with torch.no_grad():
+      gen = torch.Generator().manual_seed(3)
+      for p in d.parameters():
+        p.mul_(1.0 + 0.05 * torch.randn(p.shape, generator=gen).to(p.device))
+    ops.bump_weight_epoch()
+
+  # reference order: three calls, D loss backward, weight change, G loss backward through the third call
+  d1.injected_dropout = [m.clone() for m in masks]
+  oa, ob = d1(nhwc=xs[0]), d1(nhwc=xs[1])
+  xc1 = xs[2].clone().requires_grad_(True)
+  d1.set_wgrad(False)
+  oc = d1(nhwc=xc1)
+  d1.set_wgrad(True)
+  (oa['logits'].sum() - 2.0 * ob['logits'].sum()).backward()
+  ops.join_wgrad_stream()
+  g1 = {k: p.grad.clone() for k, p in d1.named_parameters()}
+  perturb(d1)
+  ((oc['logits'].reshape(n, -1).sum(1) * wc).sum() + 0.5 * oc['features'][2].float().sum()).backward()
+  ops.join_wgrad_stream()
+
+  d2.injected_dropout = [m.clone() for m in masks]
+  x_all = torch.cat(xs, 0)
+  xc2 = torch.empty_like(xs[2])
+
+  class Link(torch.autograd.Function):      # group c's rows of x_all as a function of a leaf (the step: |pred|)
+    @staticmethod
+    def forward(ctx, leaf, holder):
+      return holder[0]
+
+    @staticmethod
+    def backward(ctx, gr):
+      return gr, None
+  leaf = xs[2].clone().requires_grad_(True)
+  o_ab, o_c = d2.forward_grouped(x_all, 3, [(0, 2, x_all[:2 * n], True, None),
+                                            (2, 3, Link.apply(leaf, [x_all[2 * n:]]), False, None)])
+  (o_ab['logits'][:n].sum() - 2.0 * o_ab['logits'][n:].sum()).backward()
+  ops.join_wgrad_stream()
+  assert leaf.grad is None
+  g2 = {k: p.grad.clone() for k, p in d2.named_parameters()}
+  perturb(d2)
+  ((o_c['logits'].reshape(n, -1).sum(1) * wc).sum() + 0.5 * o_c['features'][2].float().sum()).backward()
+  ops.join_wgrad_stream()
+  torch.cuda.synchronize()
+  tol = 2e-5 if dtype == 'fp32' else 2e-2
+
+  def close(a, b, what):
+    err = float((a.float() - b.float()).norm() / (b.float().norm() + 1e-20))
+    assert err < tol, (what, err)
+  close(o_ab['logits'][:n], oa['logits'], 'logits a')
+  close(o_ab['logits'][n:], ob['logits'], 'logits b')
+  close(o_c['logits'], oc['logits'], 'logits c')
+  close(o_c['prob'], oc['prob'], 'prob c')
+  for fa, fb, fc, fab, fcc in zip(oa['features'], ob['features'], oc['features'], o_ab['features'], o_c['features']):
+    close(fab[:n], fa, 'feature a')
+    close(fab[n:], fb, 'feature b')
+    close(fcc, fc, 'feature c')
+  for k in g1:
+    close(g2[k], g1[k], 'grad ' + k)
+  for k, p in d2.named_parameters():        # the second backward adds no parameter gradient
+    assert torch.equal(p.grad, g2[k]), k
+  close(leaf.grad, xc1.grad, 'input gradient of group c through the changed weights')
+  s1, s2 = d1.state_dict(), d2.state_dict()
+  for k in s1:
+    if 'running' in k:
+      close(s2[k], s1[k], k)
+    if 'num_batches_tracked' in k:
+      assert int(s1[k]) == int(s2[k]) == 3, k
+
+
 @pytest.mark.gpu
 def test_validation_path_eval_mode_psnr_ssim_fp32(env):
   """AdversarialRunner.validate (reference training/base_runner.py:86-108,
