@@ -77,6 +77,10 @@ def parse():
                  help='skip the second timed pass (batches resident in HBM) that fills `input_ab`')
   p.add_argument('--settle-s', type=float, default=0.6,
                  help='untimed graph-replay settling after the W warm-up steps, seconds (0 = none)')
+  p.add_argument('--lookahead-last', action='store_true',
+                 help='A/B: launch the look-ahead graph (frozen RecNet of batch t+1) AFTER the step graph instead of before')
+  p.add_argument('--finish-multi', default='auto', choices=['auto', '1', '0'],
+                 help='A/B: one slab-reduction launch per backward pass (csmri_wgrad_finish_multi) instead of per layer')
   p.add_argument('--no-other-configs', action='store_true',
                  help='skip the short C2 and C5 legs attached to the default (c3, bf16, N=1) line')
   a = p.parse_args()
@@ -437,19 +441,21 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
 
   gan = config in ('c3', 'c5')
   no_graphs = args.no_graphs
+  from csmri_hip import ops as _ops
+  _ops.WGRAD_FINISH_MULTI = args.finish_multi
   if gan:
+    runner.lookahead_first = not args.lookahead_last
     runner.overlap_streams = not args.no_overlap
     runner.prefetch_pretrained = not (args.no_prefetch or args.no_overlap)
-  if not no_graphs and (gan or ws == 1):
-    # capture the step once (eager warm-up steps inside); the timed region replays hipGraphs
+  if not no_graphs:
+    # capture the step once (eager warm-up steps inside); the timed region replays hipGraphs (with more than one rank
+    # the gradient collectives stay eager between the captured segments)
     try:
       runner.enable_graphs({k: v.to(dev) for k, v in host_batches[0].items()})
     except Exception as e:            # keep the measurement alive: eager launches, same kernels
       sys.stderr.write('bench: hipGraph capture failed (%r); running eager\n' % (e,))
       runner.disable_graphs()
       no_graphs = True
-  else:
-    no_graphs = True
   if warmup > 0:
     runner.train_epoch(loader_factory(warmup), 1, steps_per_train_summary=10 ** 9)
   torch.cuda.synchronize()
@@ -534,7 +540,8 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
     workload = ('C2 RecNet(5 blocks,3 convs,32 filters)+5 DC MSE training step incl. DC adjoints, Adam; '
                 '256x256, 4x Cartesian, %d slices/GPU' % batch)
     metric = 'train slices/sec, 256x256 RecNet (5-cascade DC-CNN) MSE step'
-    mode = 'eager' if no_graphs else 'hipGraph replay (one graph per step)'
+    mode = 'eager' if no_graphs else ('hipGraph replay (one graph per step)' if ws == 1 else
+                                      'hipGraph replay (backward | Adam, gradient collectives eager between them)')
   line = {
       'metric': metric, 'value': round(value, 2), 'unit': 'slices/s',
       'n_gpus': ws, 'steps': steps, 'warmup': warmup, 'warmup_total_steps': warmup + settle_steps,

@@ -38,6 +38,7 @@ struct BBParams {
   char* dx; int dxps;                        // bf16 [B,H,W,>=8] or NULL (first block of the cascade)
   float* slab1; float* slab2; float* slab3;  // [Z][Cout_p][NK] + [Z][Cout_p] bias partial rows behind them
   int want_db;
+  unsigned long long* dbg;                   // CSMRI_DBG_STAMPS builds: per-wave phase stamps (want_db == 2: dx is the buffer)
 };
 
 #define BB_T 16
@@ -205,6 +206,15 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
     load_g3(blockIdx.x);
     dma_image(blockIdx.x, p.a2, p.a2ps, A2, BB_PS2, 4, 2, 2, 20);
   }
+#ifdef CSMRI_DBG_STAMPS
+  unsigned long long ph[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_t;
+#define BB_STAMP(i) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    ph[i] += t_ - last_t; last_t = t_; } while (0)
+  { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_t) :: "memory"); }
+#else
+#define BB_STAMP(i) do {} while (0)
+#endif
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int t = tile;
     const int b = t / tpi;
@@ -222,11 +232,14 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
       if (g3_central) { bs3[0] += __uint_as_float(vg3 << 16); bs3[1] += __uint_as_float(vg3 & 0xffff0000u); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BB_STAMP(0);
     __syncthreads();
+    BB_STAMP(1);
     // a1 and x of this tile stream in under phase 1 (their images are free since the previous tile's phases 2 / 3; every
     // wait of the loop then finds only transfers that had a whole phase to land)
     dma_image(tile, p.a1, p.a1ps, A1, BB_PS1, 4, 1, 1, 18);
     dma_image(tile, p.x, p.xps, XI, 0, 1, 1, 1, 18);
+    BB_STAMP(2);
 
     // ---- phase 1: dA2 = conv(G3, W3 flipped) * lrelu'(a2) on 20 rows (origin y0 - 2, x0 - 2) ---------------------
     // K step s = filter row, lane group g = tap column (column 3 meets zero weights)
@@ -262,6 +275,7 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
       }
     };
     if (border) stage1(std::true_type{}); else stage1(std::false_type{});
+    BB_STAMP(3);
     // ---- ... and the weight gradient of layer 3: x = a2 (patch origin = image origin + (1, 1)), dY = G3 centre ------
     {
       const char* yb = G3 + (3 * BB_PW + 3 + trow) * 16 + tquad;            // one plane: both halves of the pair read it
@@ -282,12 +296,15 @@ BB_UNROLL_KC
         }
       }
     }
+    BB_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();               // dA2 complete, a1 / x landed; dY and a2 images are free
+    BB_STAMP(5);
     if (has_next) {
       load_g3(next);
       dma_image(next, p.a2, p.a2ps, A2, BB_PS2, 4, 2, 2, 20);
     }
+    BB_STAMP(6);
 
     // ---- phase 2: dA1 = conv(dA2, W2 flipped) * lrelu'(a1) on 18 rows (origin y0 - 1, x0 - 1) --------------------
     auto stage2 = [&](auto border_tag) {
@@ -322,6 +339,7 @@ BB_UNROLL_KC
       }
     };
     if (border) stage2(std::true_type{}); else stage2(std::false_type{});
+    BB_STAMP(7);
     // ---- ... and the weight gradient of layer 2: x = a1 (patch origin = image origin), dY = dA2 centre (2, 2).  The dY
     // fragments of a K chunk are read once and shared by this wave's units (3 transposed reads per MFMA otherwise:
     // past what the LDS delivers next to the matrix pipe)
@@ -350,8 +368,10 @@ BB_UNROLL_KC
         }
       }
     }
+    BB_STAMP(8);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();               // dA1 complete; the a1 image is free
+    BB_STAMP(9);
 
     // ---- phase 3: dX = conv(dA1, W1 flipped) on the 16 x 16 tile: fragment j = output row j --------------------------
     if (p.dx) {
@@ -369,6 +389,7 @@ BB_UNROLL_KC
           *(u32x2_t*)(p.dx + ((((size_t)b * p.H + y) * p.W + x) * (size_t)p.dxps + 4 * g) * 2) = pack4_bf16(acc);
       }
     }
+    BB_STAMP(10);
     // ---- ... and the weight gradient of layer 1: x = block input, 8 channels: a fragment is a PAIR of taps x 8
     // channels (lanes tp = 0, 1 address the first tap, tp = 2, 3 the second; the last pair repeats tap 8, its second
     // half is never written); dY = dA1 centre (1, 1)
@@ -385,9 +406,17 @@ BB_UNROLL_KC
         aw1[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf1, aw1[1], 0, 0, 0);
       }
     }
+    BB_STAMP(11);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();               // the x image is free (and dA2 / dA1 may be overwritten)
+    BB_STAMP(12);
   }
+#ifdef CSMRI_DBG_STAMPS
+  if (p.dbg && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) p.dbg[((size_t)blockIdx.x * 8 + wv) * 16 + i] = ph[i];
+  }
+#endif
 
   // ---- one slab per layer and workgroup: [Cout_p][NK], NK index = tap * Cin_p + ci; D row = 4g + reg, column = r16 ---
   const int z = blockIdx.x, Z = gridDim.x;
@@ -462,6 +491,10 @@ extern "C" int csmri_convblock_fused_bwd(const csmri_convblock_bwd_desc* d, void
   p.kp1 = d->Kp[0]; p.kp2 = d->Kp[1]; p.kp3 = d->Kp[2];
   p.slope = d->slope;
   p.dx = (char*)d->dx; p.dxps = d->dx_pix_stride;
+  p.dbg = nullptr;
+#ifdef CSMRI_DBG_STAMPS
+  if (d->want_db == 2) { p.dbg = (unsigned long long*)d->dx; p.dx = nullptr; }
+#endif
   p.slab1 = d->slab[0]; p.slab2 = d->slab[1]; p.slab3 = d->slab[2];
   p.want_db = d->want_db;
   const long long tiles = (long long)d->B * p.tiles_x * p.tiles_y;

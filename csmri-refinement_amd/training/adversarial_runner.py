@@ -196,6 +196,8 @@ class AdversarialRunner(BaseRunner):
     self._side_stream3 = None
     self._metric_stream = None
     self.vgg_early = None                 # None: decided at the first step (True on a single GPU)
+    # graph mode: launch the look-ahead graph before (True) or after (False) the step's own graph(s)
+    self.lookahead_first = True
     self.batch_disc_passes = True         # D(fake) and D(real) of the D phase as one grouped pass
     self.batch_three_disc_passes = True   # ... together with the generator phase's D(fake): one pass of three groups
 
@@ -657,19 +659,28 @@ class AdversarialRunner(BaseRunner):
       G['pool'].external_plan = False
       G['pool'].prepare(G['pool'].buffer[:G['static']['inp'].shape[0]])
       G['pool'].external_plan = True
+    ready = None
     if G.get('pf_graph') is not None:
+      ready = torch.cuda.Event()           # the copies of the look-ahead's inputs are complete here
+      ready.record()
+
+    def launch_lookahead():
       # the look-ahead graph on its own stream, behind the copies of its inputs; its result is read by the NEXT step's
       # copy into static_pre (which waits for pf_done)
-      ready = torch.cuda.Event()
-      ready.record()
+      if ready is None:
+        return
       self._pf_stream.wait_event(ready)
       with torch.cuda.stream(self._pf_stream):
         G['pf_graph'].replay()
         done = torch.cuda.Event()
         done.record(self._pf_stream)
       G['pf_done'] = done
+    if self.lookahead_first:
+      launch_lookahead()
     if len(G['graphs']) == 1:
       G['graphs'][0].replay()
+      if not self.lookahead_first:
+        launch_lookahead()
     else:
       g1, g2, g3, g4 = G['graphs']
       g1.replay()
@@ -680,6 +691,8 @@ class AdversarialRunner(BaseRunner):
       self.gen_optimizer.start_allreduce()
       self.gen_optimizer.wait_allreduce()
       g4.replay()
+      if not self.lookahead_first:
+        launch_lookahead()
     self.disc_optimizer.step_count += 1
     self.gen_optimizer.step_count += 1
     for m, d in G['bn_delta']:

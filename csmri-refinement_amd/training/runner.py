@@ -148,12 +148,13 @@ class Runner(BaseRunner):
     return names, [l.detach() for l in losses], total.detach(), out
 
   def enable_graphs(self, example_batch, warmup=2):
-    """Capture the whole step (reference training/runner.py:154-178) as ONE hipGraph for this batch shape and
-    replay it per step: the RecNet step is ~150 short launches and eager issue leaves the GPU idle between
-    them.  Single process only (with data parallelism the gradient exchange sits between backward and Adam).
+    """Capture the step (reference training/runner.py:154-178) as hipGraphs for this batch shape and replay them per
+    step: the RecNet step is ~150 short launches and eager issue leaves the GPU idle between them.  One rank: ONE graph
+    (zero_grad, forward, backward, Adam).  Data parallelism: TWO graphs -- [zero_grad, forward, backward] and [Adam] --
+    with the gradient exchange (RCCL collectives are not captured) issued eagerly between them; 1/world is a launch
+    argument of the captured Adam kernel.
     ``warmup`` eager steps run first (allocator / pack caches); they are REAL optimizer updates on the example
     batch -- pass warmup=0 (after at least one eager step elsewhere) when that matters."""
-    assert not dist_utils.exchange_active(), 'graph mode of the standard runner is single-GPU'
     static = {k: v.detach().clone() for k, v in example_batch.items()}
     self._set_train()
     from csmri_hip import ops as _ops
@@ -162,6 +163,7 @@ class Runner(BaseRunner):
     with torch.cuda.stream(side):
       for _ in range(warmup):
         self._step_body(static)
+        self.optimizer.start_allreduce()
         self.optimizer.step()
     torch.cuda.current_stream().wait_stream(side)
     from models.utils import prepare_packs_for_capture
@@ -169,13 +171,22 @@ class Runner(BaseRunner):
     torch.cuda.synchronize()
     import gc
     gc.collect()
-    g = torch.cuda.CUDAGraph()
     cap = _ops.named_stream('capture')
+    split = dist_utils.exchange_active()
+    g = torch.cuda.CUDAGraph()
+    g2 = None
     with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
       names, losses, total, out = self._step_body(static)
-      self.optimizer.step()
+      if not split:
+        self.optimizer.step()
+    if split:
+      self.optimizer._scale = 1.0 / dist_utils.world_size()       # (what wait_allreduce() returns on every step)
+      g2 = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g2, pool=g.pool(), stream=cap, capture_error_mode='thread_local'):
+        self.optimizer.apply()
     self.optimizer.step_count -= 1                   # the capture pass executed nothing
-    self._graph = {'graph': g, 'static': static, 'names': names, 'losses': losses, 'total': total, 'out': out}
+    self._graph = {'graph': g, 'graph_adam': g2, 'static': static, 'names': names, 'losses': losses, 'total': total,
+                   'out': out}
     return self
 
   def disable_graphs(self):
@@ -189,6 +200,10 @@ class Runner(BaseRunner):
     if G is not None:
       torch._foreach_copy_(list(G['static'].values()), [batch[k] for k in G['static']])
       G['graph'].replay()
+      if G['graph_adam'] is not None:
+        self.optimizer.start_allreduce()
+        self.optimizer.wait_allreduce()
+        G['graph_adam'].replay()
       self.optimizer.step_count += 1
       names, losses, total, out, batch = G['names'], [l.clone() for l in G['losses']], G['total'].clone(), G['out'], G['static']
     else:

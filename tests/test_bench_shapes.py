@@ -4,7 +4,8 @@ oracle (plain torch fp32 F.conv2d on the same bf16-rounded operands), one case p
 
   frozen RecNet (reference models/recnet.py:29-62), U-Net (models/unet.py:27-290 as configured in
   configs/2-refinement.json:31-47), CNNDiscriminator (models/discriminators.py:137-172; the D phase
-  runs [fake; real] as one 16-image pass, the generator phase an 8-image pass), VGG19
+  forward is one 24-image pass over [pool-fake; real; current-fake], the D-phase backward a 16-image and the
+  generator-phase data gradient an 8-image pass), VGG19
   (models/vgg.py:8-80; [pred; target] = 16 images forward, 8 images data gradient).
 
 Whatever kernel instance the dispatcher picks for a shape is the one checked here (its name is logged
@@ -60,6 +61,15 @@ CASES = [
     ('disc5_b8', 512, 1024, 4, 2, 'reflection', False, S // 16, S // 16, 8, None, 'fd'),
     ('disc6_b8', 1024, 1024, 4, 1, 'reflection', False, S // 32, S // 32, 8, None, 'fd'),
     ('disc_final_b8', 1024, 1, 4, 1, 'none', False, S // 32, S // 32, 8, None, 'fd'),
+    # discriminator, round 4: ONE forward over [pool-fake; real; current-fake] (24 images); the D-phase backward runs
+    # on its first 16 images (cases *_b16 above: 'dw'), the generator-phase data gradient on the last 8 (*_b8: 'd')
+    ('disc1_b24', 1, 64, 4, 2, 'reflection', False, S, S, 24, None, 'f'),
+    ('disc2_b24', 64, 128, 4, 2, 'reflection', False, S // 2, S // 2, 24, None, 'f'),
+    ('disc3_b24', 128, 256, 4, 2, 'reflection', False, S // 4, S // 4, 24, None, 'f'),
+    ('disc4_b24', 256, 512, 4, 2, 'reflection', False, S // 8, S // 8, 24, None, 'f'),
+    ('disc5_b24', 512, 1024, 4, 2, 'reflection', False, S // 16, S // 16, 24, None, 'f'),
+    ('disc6_b24', 1024, 1024, 4, 1, 'reflection', False, S // 32, S // 32, 24, None, 'f'),
+    ('disc_final_b24', 1024, 1, 4, 1, 'none', False, S // 32, S // 32, 24, None, 'f'),
     # VGG19: [pred; target] forward (16), data gradient on the prediction half (8)
     ('vgg1_1', 3, 64, 3, 1, 'zero', False, S, S, 16, None, 'f'),
     ('vgg1_2', 64, 64, 3, 1, 'zero', False, S, S, 16, None, 'f'),
@@ -167,7 +177,7 @@ def test_bench_layer_vs_oracle_bf16(hip, case):
 
 def test_dispatch_variants_are_all_exercised():
   """Every kernel instance the BENCHMARKED step launches (the `conv_kernels` table of the committed bench line,
-  profiles/r03_bench_n1.json: keys are the instance names rocprofv3 prints) has been reached by a bench shape above,
+  profiles/r04_bench_n1.json: keys are the instance names rocprofv3 prints) has been reached by a bench shape above,
   i.e. has been compared with the oracle; a dispatch change that strands an instance, or a bench line taken with a
   build whose instances these shapes no longer reach, fails here."""
   import json
@@ -183,8 +193,8 @@ def test_dispatch_variants_are_all_exercised():
   need = {'tconv_kernel', 'gconv_kernel', 'gconv_glds_kernel', 'pconv2_kernel',
           'thin_out1_kernel', 'wpatch_kernel', 'wgrad_glds_row_kernel', 'wthin_out_kernel'}
   assert need <= fam, (need - fam, fam)
-  path = os.path.join(ROOT, 'profiles', 'r03_bench_n1.json')
-  assert os.path.exists(path), 'commit the bench line of this build as profiles/r03_bench_n1.json'
+  path = os.path.join(ROOT, 'profiles', 'r04_bench_n1.json')
+  assert os.path.exists(path), 'commit the bench line of this build as profiles/r04_bench_n1.json'
   table = json.load(open(path))['conv_kernels']
   # second stages / fused blocks that are not csmri_gconv / csmri_wgrad main kernels (covered by tests/test_hip_ops.py)
   other = {'gconv_reduce_kernel', 'convblock_fwd_kernel'}

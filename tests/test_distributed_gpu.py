@@ -387,6 +387,34 @@ def _nccl_world1_worker(port, q):
   fg = rg.disc_optimizer.flat_g
   assert torch.equal(fg, fg.to(torch.bfloat16).float())
   res['graphs'] = 'ok'
+  # -- 3. the standard (RecNet MSE) runner with data parallelism in GRAPH mode: [zero_grad, forward, backward] and [Adam]
+  # as two hipGraphs with the eager gradient exchange between them (bench.py --config c2 with more than one rank) --
+  def make_recnet(payload):
+    os.environ['CSMRI_GRAD_PAYLOAD'] = payload
+    conf = Configuration.from_json(os.path.join(PKG, 'configs', '1-recnet.json'))
+    conf.model['num_blocks'], conf.model['num_convs'], conf.model['num_filters'] = 2, 3, 32
+    conf.model['compute_dtype'] = 'bf16'
+    conf.batch_size = 2
+    utils.set_random_seeds(conf.seed)
+    return build_runner(conf, 'standard', '0', 'train')
+
+  def run_recnet(runner, graphs):
+    if graphs:
+      runner.enable_graphs(batch, warmup=1)                  # (one real eager step on the batch, then the capture)
+    out = []
+    for _ in range(3 if graphs else 4):
+      losses, _ = runner.train_epoch(Loader([batch]), 1)
+      out.append(float(losses['loss_MSE'].value))
+    torch.cuda.synchronize()
+    return out, torch.cat([p.detach().float().reshape(-1) for p in runner.model.parameters()]).cpu()
+  D.FORCE_EXCHANGE = False
+  le, pe = run_recnet(make_recnet('fp32'), False)            # dp1 eager
+  D.FORCE_EXCHANGE = True
+  rr = make_recnet('fp32')
+  lgr, pgr = run_recnet(rr, True)
+  assert rr._graph['graph_adam'] is not None and rr.optimizer.bucket.exchanges >= 3
+  assert lgr == le[1:] and torch.equal(pgr, pe), 'two-graph data-parallel RecNet step differs from the dp1 eager run'
+  res['recnet_graphs'] = 'ok'
   dist.barrier()
   dist.destroy_process_group()
   q.put(res)
@@ -405,4 +433,97 @@ def test_nccl_backend_forced_exchange_world1():
   p.start()
   p.join(900)
   assert p.exitcode == 0, p.exitcode
-  assert q.get(timeout=10) == {'bucket': 'ok', 'eager': 'ok', 'graphs': 'ok'}
+  assert q.get(timeout=10) == {'bucket': 'ok', 'eager': 'ok', 'graphs': 'ok', 'recnet_graphs': 'ok'}
+
+
+# ---------------------------------------------------------------------------------------------
+# the first test a multi-GPU box runs: two ranks, two GPUs, the real 'nccl' (RCCL) backend
+# ---------------------------------------------------------------------------------------------
+
+
+def _nccl_world2_worker(rank, world, port, q):
+  sys.path.insert(0, PKG)
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+  os.environ.pop('CSMRI_DIST_BACKEND', None)
+  import torch.distributed as dist
+  from training import distributed as D
+  assert D.init_from_env() == world and dist.get_backend() == 'nccl'
+  dev = torch.device('cuda', rank)
+  torch.cuda.set_device(dev)
+  # bucket arithmetic across two GPUs: every element bf16(sum_r bf16(g_r)) / the exact fp32 sum
+  gen = torch.Generator().manual_seed(3)
+  base = torch.randn(300000 + 4, generator=gen) * 1e-2
+  mine = (base * (rank + 1)).to(dev)
+  for payload in ('bf16', 'fp32'):
+    flat = mine.clone()
+    b = D.GradBucket(flat, splits=[(200000, 300004), (0, 200000)], payload=payload)
+    b.start(0)
+    b.start()
+    scale = b.wait()
+    torch.cuda.synchronize()
+    if payload == 'bf16':
+      want = (base.to(torch.bfloat16).float() + (base * 2).to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    else:
+      want = base + base * 2
+    assert scale == 0.5 and torch.equal(flat.cpu(), want), (payload, float((flat.cpu() - want).abs().max()))
+  # the GAN step, graphed (four segments, collectives between them), per-rank shards: both ranks end bit-identical
+  import csmri_hip  # noqa: F401
+  from utils.config import Configuration
+  from models.utils import set_default_compute_dtype
+  from training import build_runner
+  import utils
+  from data.synthetic import synth_batch
+  set_default_compute_dtype('bf16')
+  conf = Configuration.from_json(os.path.join(PKG, 'configs', '2-refinement.json'))
+  conf.batch_size = 2
+  conf.vgg_loss = {'seed': 19}
+  g, d = conf.generator_model, conf.discriminator_model
+  g['pretrained_model']['num_filters'] = 8
+  g['learnable_model']['encode_filters'] = [8, 16, 32]
+  g['learnable_model']['decode_filters'] = [16, 8]
+  d['num_filters_per_layer'] = [8, 16, 32, 64, 64, 64]
+  utils.set_random_seeds(conf.seed)
+  runner = build_runner(conf, 'adversarial', str(rank), 'train')
+  full = synth_batch(4, 128, 128, acc=4, seed=11)
+  shard = {k: v.to(dev) for k, v in D.shard_batch(full).items()}
+  p0 = torch.cat([p.detach().float().reshape(-1) for p in runner.disc.parameters()]).clone()
+
+  class Loader(list):
+    batch_size = 2
+  runner.overlap_streams = True
+  runner.enable_graphs(shard)
+  runner.train_epoch(Loader([shard, shard]), 1)
+  torch.cuda.synchronize()
+  flat = torch.cat([p.detach().float().reshape(-1) for net in (runner.disc, runner.gen)
+                    for p in net.parameters() if p.requires_grad]).cpu()
+  moved = float((torch.cat([p.detach().float().reshape(-1) for p in runner.disc.parameters()]) - p0).abs().max())
+  dist.barrier()
+  dist.destroy_process_group()
+  q.put((rank, flat.numpy().tobytes(), moved))
+
+
+@pytest.mark.gpu
+def test_nccl_backend_two_gpus():
+  """Runs wherever two GPUs are visible (skipped on the one-GPU test boxes): the gradient buckets over RCCL between two
+  devices -- all_to_all_single / all_gather_into_tensor with real inter-rank traffic, which a world of one cannot
+  exercise -- and two graphed data-parallel GAN steps after which both ranks hold bit-identical parameters
+  (reference utils/custom_data_parallel.py:26-35 is what this replaces)."""
+  if torch.cuda.device_count() < 2:
+    pytest.skip('needs two GPUs (the first multi-GPU box that sees this repository runs it before any benchmark)')
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 29900 + os.getpid() % 90
+  procs = [ctx.Process(target=_nccl_world2_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  got = sorted((q.get(timeout=900) for _ in range(2)), key=lambda t: t[0])
+  for p in procs:
+    p.join(120)
+    assert p.exitcode == 0, p.exitcode
+  import numpy as np
+  (_, b0, m0), (_, b1, m1) = got
+  f0, f1 = torch.from_numpy(np.frombuffer(b0, dtype=np.float32).copy()), torch.from_numpy(np.frombuffer(b1, dtype=np.float32).copy())
+  assert torch.isfinite(f0).all() and m0 > 0 and m1 > 0
+  assert torch.equal(f0, f1), float((f0 - f1).abs().max())

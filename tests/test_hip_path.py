@@ -325,11 +325,19 @@ def test_disc_phase_grads_identical_inputs_fp32(env):
   seen, grads = [], {}
   disc_fwd = runner.disc.forward
 
+  grouped = runner.disc.forward_grouped
+
   def fwd(inp=None, nhwc=None, groups=1):
     x = nhwc.detach().float().cpu()[..., :1].permute(0, 3, 1, 2).contiguous()
-    seen.extend(x.chunk(groups, 0))       # the D phase runs [fake; real] as one grouped pass
+    seen.extend(x.chunk(groups, 0))
     return disc_fwd(inp, nhwc, groups)
+
+  def fwd_grouped(nhwc, groups, subs):      # the step runs [pool-fake; real; current-fake] as ONE grouped pass
+    x = nhwc.detach().float().cpu()[..., :1].permute(0, 3, 1, 2).contiguous()
+    seen.extend(x.chunk(groups, 0))
+    return grouped(nhwc, groups, subs)
   runner.disc.forward = fwd
+  runner.disc.forward_grouped = fwd_grouped
   apply_orig = runner.disc_optimizer.apply
   names = {id(p): n for n, p in runner.disc.named_parameters()}
 
@@ -530,7 +538,7 @@ def test_grouped_disc_pass_equals_two_passes(env, dtype, size, small):
       assert int(s1[k]) == int(s2[k]) == 2, k
 
 
-@pytest.mark.parametrize('dtype,size,small', [('fp32', 64, True), ('bf16', 64, True), ('bf16', 128, False)])
+@pytest.mark.parametrize('dtype,size,small', [('fp32', 128, True), ('bf16', 128, True), ('bf16', 256, False)])
 def test_three_group_disc_pass_equals_three_passes(env, dtype, size, small):
   """CNNDiscriminator.forward_grouped on [a; b; c] -- the training step's ONE discriminator pass over
   [pool-fake; real; current-fake] -- against the reference's three module calls (training/adversarial_runner.py
@@ -1062,10 +1070,19 @@ def test_c2_recnet5_bf16_train_step_vs_oracle(env):
         (losses['loss_MSE'].value, ref['loss_MSE'], rel, rel_e, metrics['psnr'].value, ref['psnr']))
   assert rel < 2e-3 and dpsnr < 0.01, (rel, dpsnr)
   bad, worst = [], (1.0, '')
+  gmax = max(float(v.norm()) for v in g_ref.values())
   for k, gr in g_ref.items():
     cos, err = _cos_err(grads[k].reshape(gr.shape), gr)
     cos_e, err_e = _cos_err(g_emu[k], gr)
-    print('C2 grad %-34s hip cos %.5f rel_l2 %.3e | floor cos %.5f rel_l2 %.3e' % (k, cos, err, cos_e, err_e))
+    print('C2 grad %-34s |g| %.3e hip cos %.5f rel_l2 %.3e | floor cos %.5f rel_l2 %.3e' %
+          (k, float(gr.norm()), cos, err, cos_e, err_e))
+    if float(gr.norm()) < 1e-4 * gmax:
+      # analytically zero: the bias of a block's last conv only moves the image's mean, which the following
+      # data-consistency layer overwrites with the measured k-space centre -- the oracle's own value is fp32 noise
+      # (1e-8 .. 1e-7), a relative error means nothing; the HIP value must be at that floor too
+      if float(grads[k].norm()) > 1e-3 * gmax:
+        bad.append((k, 'noise-floor tensor', float(grads[k].norm()), float(gr.norm())))
+      continue
     if err > max(2.0 * err_e, 2e-2) or (gr.numel() > 2 and cos < 0.99):
       bad.append((k, cos, err, err_e))
     if gr.numel() > 2 and cos < worst[0]:
@@ -1077,6 +1094,8 @@ def test_c2_recnet5_bf16_train_step_vs_oracle(env):
   lr = conf.optimizer['learning_rate']
   cur = runner.model.state_dict()
   for k, v in P_ref.items():
+    if float(g_ref[k].norm()) < 1e-4 * gmax:
+      continue
     well = g_ref[k].abs() > 5e-2 * g_ref[k].abs().max()
     d_h, d_o = (cur[k].cpu() - P0[k])[well], (v - P0[k])[well]
     agree = float(((d_h - d_o).abs() < 0.25 * lr).float().mean())
@@ -1287,7 +1306,7 @@ def test_config5_512_radial_fp8_forward_step(env):
     csmri_hip.ops.LAUNCH_LOG = None
   n8 = sum(1 for e in log if e[1].startswith('gconv_fp8_kernel'))
   print('config5 fp8: %d fp8 convolution launches in the step' % n8)
-  assert n8 >= 2 * 4 + 3          # D layers 3-6 in the grouped D-phase pass and the generator-phase pass, three U-Net layers
+  assert n8 >= 4 + 3          # D layers 3-6 in the ONE three-group discriminator pass, three U-Net layers
   ref8 = _oracle_step(PG, SG, PD, SD, PV, batch, masks, emulate={'mode': 'bf16', 'fp8': True})
   ref = _oracle_step(PG, SG, PD, SD, PV, batch, masks)
   for k in sorted(ref[0]):
@@ -1341,7 +1360,7 @@ def test_fp8_config_key_step_fp8_convs_and_bf16_dc(env, monkeypatch):
     print('%s: %d fp8 convolution launches, %d bf16-storage / %d fp32-storage DC launches' % (dtype, n8, dc16, dc32))
     if dtype == 'fp8':
       assert runner.gen.pretrained_model.dc_storage == 'bf16'
-      assert n8 >= 2 * 4 + 3 and dc16 >= 3 and dc32 == 0
+      assert n8 >= 4 + 3 and dc16 >= 3 and dc32 == 0
     else:
       assert n8 == 0 and dc16 == 0 and dc32 >= 3
     res[dtype] = hip
