@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CSMRI_HIP_LIB') or os.path.join(_HERE, 'libcsmri_hip.so')
 
 F32, BF16 = 0, 1
+BF16_SPLIT = 3      # CSMRI_BF16_SPLIT: 2-channel image as bf16 hi + lo in a padded pixel (include/csmri_hip.h)
 BORDER_ZERO, BORDER_REFLECT = 0, 1
 
 if not os.path.exists(LIB_PATH):
@@ -64,6 +65,7 @@ class ConvBlockDesc(C.Structure):
       ('slope', f32),
       ('act', vp * 2), ('act_pix_stride', i32 * 2),
       ('out', vp), ('out_dtype', i32), ('out_pix_stride', i32),
+      ('x_split', i32),
   ]
 
 
@@ -80,6 +82,7 @@ class ConvBlockBwdDesc(C.Structure):
       ('slope', f32),
       ('dx', vp), ('dx_pix_stride', i32),
       ('slab', vp * 3), ('splits', i32), ('want_db', i32),
+      ('x_split', i32), ('dx_split', i32),
   ]
 
 

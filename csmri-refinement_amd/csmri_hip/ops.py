@@ -76,14 +76,16 @@ def _need_gpu(t):
 # ----------------------------------------------------------------------------
 
 
-def nchw_to_nhwc(x, dtype, cpad=None):
-  """fp32 NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] of ``dtype`` (zero padded)."""
+def nchw_to_nhwc(x, dtype, cpad=None, split=False):
+  """fp32 NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] of ``dtype`` (zero padded).  ``split`` (2-channel images into 8 bf16
+  channels): CSMRI_BF16_SPLIT -- channels 2,3 hold what the bf16 rounding of channels 0,1 dropped."""
   _need_gpu(x)
   x = x.contiguous().float()
   b, c, h, w = x.shape
   cp = pad8(c) if cpad is None else cpad
   out = torch.empty(b, h, w, cp, dtype=dtype, device=x.device)
-  lib.call('csmri_nchw_to_nhwc', x.data_ptr(), b, c, h, w, out.data_ptr(), dt_of(out), cp, cp,
+  split = bool(split) and dtype == torch.bfloat16 and c == 2 and cp == 8 and (h * w) % 4 == 0
+  lib.call('csmri_nchw_to_nhwc', x.data_ptr(), b, c, h, w, out.data_ptr(), lib.BF16_SPLIT if split else dt_of(out), cp, cp,
            stream())
   return out
 
@@ -101,13 +103,13 @@ def nhwc_to_nchw(x, c_real):
 
 class ToNHWC(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, x, dtype, cpad):
+  def forward(ctx, x, dtype, cpad, split=False):
     ctx.c = x.shape[1]
-    return nchw_to_nhwc(x, dtype, cpad)
+    return nchw_to_nhwc(x, dtype, cpad, split)
 
   @staticmethod
   def backward(ctx, g):
-    return nhwc_to_nchw(g, ctx.c), None, None
+    return nhwc_to_nchw(g, ctx.c), None, None, None
 
 
 class ToNCHW(torch.autograd.Function):
@@ -820,7 +822,7 @@ class ConvActReplay(torch.autograd.Function):
 FUSED_CONVBLOCK = True
 
 
-def convblock_fused_forward(x, plan, out_dtype_last, need_acts, out_complex=False):
+def convblock_fused_forward(x, plan, out_dtype_last, need_acts, out_complex=False, x_split=False):
   """The whole conv block in one launch (csrc/convblock.hip) when its shape is the supported one, else None.
   Returns [x, a1, a2, y] (a1 / a2 = None when ``need_acts`` is false: nothing of them reaches HBM).
   ``out_complex``: y is the dense interleaved complex fp32 image [B,H,W,2] instead of the padded [B,H,W,8]."""
@@ -851,6 +853,7 @@ def convblock_fused_forward(x, plan, out_dtype_last, need_acts, out_complex=Fals
     keep += [wp, bp]
   d.x, d.x_pix_stride, d.B, d.H, d.W = x.data_ptr(), x.stride(2), b, h, w
   d.slope = float(slopes[0])
+  d.x_split = int(bool(x_split))              # x is CSMRI_BF16_SPLIT: layer 1 multiplies hi + lo
   a1 = a2 = None
   if need_acts:
     a1 = torch.empty(b, h, w, layers[0].cout_p, dtype=torch.bfloat16, device=x.device)
@@ -893,7 +896,7 @@ def _grad_targets(layer):
   return wgt.grad, (layer.bias.grad if layer.bias is not None else None), int(not fresh)
 
 
-def convblock_fused_backward(plan, saved, g, need_dx, out_complex):
+def convblock_fused_backward(plan, saved, g, need_dx, out_complex, x_split=False):
   """The whole backward of a fused conv block in one launch (csrc/convblock_bwd.hip) + the slab reduction of its three
   weight gradients; returns (ok, dx).  ``saved`` = [x, a1, a2, _]; ``g``: gradient of the block output."""
   if not FUSED_CONVBLOCK_BWD or len(plan) != 3:
@@ -939,6 +942,9 @@ def convblock_fused_backward(plan, saved, g, need_dx, out_complex):
     d.dx, d.dx_pix_stride = dx.data_ptr(), dx.stride(2)
   z = lib.raw('csmri_convblock_fused_bwd_splits')(b, h, w)
   d.splits, d.want_db = z, 1
+  # split images on both sides of the block: the weight gradient of layer 1 sees hi + lo of x, and dX leaves with the
+  # part its bf16 rounding drops in channels 2,3 (the DC adjoint adds the two)
+  d.x_split = d.dx_split = int(bool(x_split))
   descs = []
   for i, l in enumerate(layers):
     wd = lib.WGradDesc()
@@ -996,13 +1002,19 @@ class ConvActStack(torch.autograd.Function):
     # hands back -- instead of the channel-padded [B,H,W,8] (4x the bytes written, read, and returned as gradient)
     n = len(plan)
     out_complex = isinstance(out_dtype_last, tuple)
+    x_split = False
     if out_complex:
+      # ('complex', torch.float32[, 'split']): 'split' = x is a CSMRI_BF16_SPLIT image (the fused kernels multiply
+      # hi + lo and return dX split as well; the per-layer fallback reads plain bf16: its weights are zero on the lo
+      # channels)
+      x_split = len(out_dtype_last) > 2 and out_dtype_last[2] == 'split'
       out_dtype_last = out_dtype_last[1]
       assert out_dtype_last == torch.float32 and plan[-1][0].cout == 2 and plan[-1][1] == 1.0
+    ctx.x_split = x_split
     saved = None
     if FUSED_CONVBLOCK:
       need_acts = any(ctx.needs_input_grad[i] for i in (0,) + tuple(range(3, 3 + len(params))))
-      saved = convblock_fused_forward(x, plan, out_dtype_last, need_acts, out_complex)
+      saved = convblock_fused_forward(x, plan, out_dtype_last, need_acts, out_complex, x_split)
     if saved is None:
       saved, cur = [x], x
       for i, (layer, slope) in enumerate(plan):
@@ -1026,7 +1038,7 @@ class ConvActStack(torch.autograd.Function):
     g = as_nhwc(gy)
     last_layer, last_slope = plan[-1]
     if n == 3 and all(ctx.w_req) and saved[1] is not None:
-      ok, dx = convblock_fused_backward(plan, saved, g, ctx.needs_input_grad[0], ctx.out_complex)
+      ok, dx = convblock_fused_backward(plan, saved, g, ctx.needs_input_grad[0], ctx.out_complex, ctx.x_split)
       if ok:
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
     if ctx.out_complex:              # [B,H,W,2] fp32 -> the data-gradient kernels' padded layout, one pass
@@ -1465,18 +1477,21 @@ def dc_raw(x, k0, mask_u8, pad_dtype=None, out_fp32=False):
   b, h, w, _ = x.shape
   out = torch.empty(b, h, w, 2, dtype=x.dtype, device=x.device)
   out_pad = None
+  pad_code = 0
   if pad_dtype is not None:
-    out_pad = torch.empty(b, h, w, 8, dtype=pad_dtype, device=x.device)
+    split = isinstance(pad_dtype, tuple)               # (torch.bfloat16, 'split'): CSMRI_BF16_SPLIT padded copy
+    out_pad = torch.empty(b, h, w, 8, dtype=pad_dtype[0] if split else pad_dtype, device=x.device)
+    pad_code = lib.BF16_SPLIT if split else dt_of(out_pad)
   if x.dtype == torch.bfloat16 and out_fp32:      # bf16 input (a padded gradient), fp32 arithmetic and result
     out = torch.empty(b, h, w, 2, dtype=torch.float32, device=x.device)
     lib.call('csmri_dc_in_bf16', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
-             ptr(out_pad), dt_of(out_pad) if out_pad is not None else 0, b, h, w, stream())
+             ptr(out_pad), pad_code, b, h, w, stream())
   elif x.dtype == torch.bfloat16:     # bf16 image storage (k0 stays fp32): the "bf16 cFFT" of config 5
     lib.call('csmri_dc_bf16', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
-             ptr(out_pad), dt_of(out_pad) if out_pad is not None else 0, b, h, w, stream())
+             ptr(out_pad), pad_code, b, h, w, stream())
   else:
     lib.call('csmri_dc', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
-             ptr(out_pad), dt_of(out_pad) if out_pad is not None else 0, 0, b, h, w, stream())
+             ptr(out_pad), pad_code, 0, b, h, w, stream())
   return out, out_pad
 
 

@@ -31,6 +31,7 @@ struct CBParams {
   float slope;
   char* a1; int a1ps; char* a2; int a2ps;   // bf16 [B,H,W,32] (training) or NULL
   char* out; int out_dt, ops;               // [B,H,W,8]
+  int x_split;                              // x is CSMRI_BF16_SPLIT (hi in channels 0,1, lo in 2,3)
 };
 
 #define CB_T 16
@@ -97,6 +98,14 @@ __global__ __launch_bounds__(256, 2) void convblock_fwd_kernel(const CBParams p)
 #pragma unroll
   for (int s = 0; s < 9; ++s) w3f[s] = *(const u32x4_t*)(p.w3 + ((size_t)r16 * p.kp3 + s * 32 + g * 8) * 2);
 
+  if (p.x_split) {
+    // split input (channels 0,1 = hi, 2,3 = lo of the same two real channels): repeat the weights of channels 0,1 on
+    // channels 2,3 -- a lane's 16 bytes are the 8 channels of one tap -- so that layer 1 multiplies hi + lo
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) w1f[i][s][1] = w1f[i][s][0];
+  }
   const f32x4_t zero4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   f32x4_t bias10 = *(const f32x4_t*)(p.b1 + 4 * g), bias11 = *(const f32x4_t*)(p.b1 + 16 + 4 * g);
   f32x4_t bias20 = *(const f32x4_t*)(p.b2 + 4 * g), bias21 = *(const f32x4_t*)(p.b2 + 16 + 4 * g);
@@ -333,6 +342,7 @@ extern "C" int csmri_convblock_fused_fwd(const csmri_convblock_desc* d, void* st
   p.slope = d->slope;
   p.a1 = (char*)d->act[0]; p.a1ps = d->act_pix_stride[0]; p.a2 = (char*)d->act[1]; p.a2ps = d->act_pix_stride[1];
   p.out = (char*)d->out; p.out_dt = d->out_dtype; p.ops = d->out_pix_stride;
+  p.x_split = d->x_split;
   const long long blocks = (long long)d->B * p.tiles_x * p.tiles_y;
   if (blocks >= (1ll << 31)) return CSMRI_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;

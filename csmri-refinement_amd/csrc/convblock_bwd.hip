@@ -38,6 +38,7 @@ struct BBParams {
   char* dx; int dxps;                        // bf16 [B,H,W,>=8] or NULL (first block of the cascade)
   float* slab1; float* slab2; float* slab3;  // [Z][Cout_p][NK] + [Z][Cout_p] bias partial rows behind them
   int want_db;
+  int x_split, dx_split;                     // CSMRI_BF16_SPLIT block input / input gradient
   unsigned long long* dbg;                   // CSMRI_DBG_STAMPS builds: per-wave phase stamps (want_db == 2: dx is the buffer)
 };
 
@@ -161,50 +162,54 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
   // zero page.
   // piece i of an image = plane i / 7, pixels (i % 7) * 64 + lane; wave wv issues pieces wv, wv + 8, wv + 16, wv + 24.
   // The piece's pixel (py, px) inside the region is a per-lane constant: decoded once, not per tile.
-  int dpy[4], dpx[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int i = wv + 8 * a, c = i % 7, pp = c * 64 + lane;
-    dpy[a] = (pp * 2979) >> 16; dpx[a] = pp - dpy[a] * BB_PW;
-  }
-  auto dma_image = [&](int tl, const char* src, int sps, char* img, int pstride, int planes, int oy, int ox, int rows) {
+  // Wave c (0..6) issues chunk c (pixels 64 c + lane) of every plane of an image -- the four planes of a 32-channel
+  // image in iterations 0..3, the one plane of the block input with iteration 0 --, wave 7 none: the piece's pixel is
+  // ONE per-lane constant for all of a wave's pieces (two registers instead of nine).
+  const int dpp = (wv < 7 ? wv : 6) * 64 + lane;
+  const int dpy = (dpp * 2979) >> 16, dpx = dpp - dpy * BB_PW;
+  const int dpix = dpy * p.W + dpx;                   // pixel offset inside a region (regions are 22 wide)
+  // A DMA piece is issued from INSIDE the data-gradient loops, one per fragment iteration: the stamped kernel
+  // (tools/stamp_convblock_bwd.py) spent 4,400 of its 18,500 cycles per tile in two phases in which all eight waves did
+  // nothing but compute addresses and issue their pieces.  Per tile and image the plan (base pointer, border flag) is
+  // computed once; a piece's offset inside the region is a per-lane constant computed once per launch.
+  struct DmaPlan { const char* base; int yb, xb; bool inner; };
+  auto dma_plan = [&](int tl, const char* src, int sps, int oy, int ox, int rows) {
+    DmaPlan pl;
     const int b_ = tl / tpi, r_ = tl - b_ * tpi, ty_ = r_ / p.tiles_x, tx_ = r_ - ty_ * p.tiles_x;
-    const int yb = ty_ * BB_T - oy, xb = tx_ * BB_T - ox;
-    const bool inner = yb >= 0 && xb >= 0 && yb + rows <= p.H && xb + BB_PW <= p.W;     // workgroup-uniform
-    const char* base = src + (((size_t)b_ * p.H + yb) * p.W + xb) * (size_t)sps * 2;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int i = wv + 8 * a;
-      if (i >= planes * 7) break;
-      const int k = i / 7, c = i - k * 7;
-      bool ok = dpy[a] < rows;
-      if (!inner) ok = ok && (unsigned)(yb + dpy[a]) < (unsigned)p.H && (unsigned)(xb + dpx[a]) < (unsigned)p.W;
-      const char* g_ = ok ? base + ((size_t)(dpy[a] * p.W + dpx[a]) * sps + k * 8) * 2 : bb_zero_page;
-      __builtin_amdgcn_global_load_lds((bb_gptr_t)g_, (bb_lptr_t)(img + k * pstride + c * 1024), 16, 0, 0);
-    }
+    pl.yb = ty_ * BB_T - oy; pl.xb = tx_ * BB_T - ox;
+    pl.inner = pl.yb >= 0 && pl.xb >= 0 && pl.yb + rows <= p.H && pl.xb + BB_PW <= p.W;     // workgroup-uniform
+    pl.base = src + (((long long)b_ * p.H + pl.yb) * p.W + pl.xb) * (long long)sps * 2;
+    return pl;
   };
-  unsigned vg3 = 0u;                            // this thread's dY pixel of the NEXT tile (bf16 pair)
+  auto dma_piece = [&](const DmaPlan& pl, int plane, int sps, char* img, int pstride, int rows) {
+    if (wv >= 7) return;                               // wave-uniform
+    bool ok = dpy < rows;
+    if (!pl.inner) ok = ok && (unsigned)(pl.yb + dpy) < (unsigned)p.H && (unsigned)(pl.xb + dpx) < (unsigned)p.W;
+    const char* g_ = ok ? pl.base + (unsigned)((dpix * sps + plane * 8) * 2) : bb_zero_page;
+    __builtin_amdgcn_global_load_lds((bb_gptr_t)g_, (bb_lptr_t)(img + plane * pstride + wv * 1024), 16, 0, 0);
+  };
+  // this thread's dY pixel of the NEXT tile, loaded at the START of the current tile and kept as loaded (the conversion to
+  // bf16 -- i.e. the wait for the load -- happens where the value is stored into its image, a whole tile later)
+  u32x2_t vg3r = (u32x2_t){0u, 0u};                  // fp32 pair, or the bf16 pair in [0]
   auto load_g3 = [&](int tl) {
-    vg3 = 0u;
-    if (tid >= 484) return;
+    vg3r = (u32x2_t){0u, 0u};
+    if (tid >= 484 || tl >= ntiles) return;
     const int b_ = tl / tpi, r_ = tl - b_ * tpi, ty_ = r_ / p.tiles_x, tx_ = r_ - ty_ * p.tiles_x;
     const int py = tid / BB_PW, px = tid - py * BB_PW;
     const int y = ty_ * BB_T - 3 + py, x = tx_ * BB_T - 3 + px;
     if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
       const size_t pix = ((size_t)b_ * p.H + y) * p.W + x;
-      if (p.gy_dt == CSMRI_F32) {
-        const f32x2_t v = *(const f32x2_t*)(p.gy + pix * (size_t)p.gyps * 4);
-        vg3 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-      } else {
-        vg3 = *(const unsigned*)(p.gy + pix * (size_t)p.gyps * 2);
-      }
+      if (p.gy_dt == CSMRI_F32) vg3r = *(const u32x2_t*)(p.gy + pix * (size_t)p.gyps * 4);
+      else vg3r[0] = *(const unsigned*)(p.gy + pix * (size_t)p.gyps * 2);
     }
   };
   const int gpy = tid / BB_PW, gpx = tid - gpy * BB_PW;
   const bool g3_central = tid < 484 && gpy >= 3 && gpy < 3 + BB_T && gpx >= 3 && gpx < 3 + BB_T;
   if ((int)blockIdx.x < ntiles) {
     load_g3(blockIdx.x);
-    dma_image(blockIdx.x, p.a2, p.a2ps, A2, BB_PS2, 4, 2, 2, 20);
+    const DmaPlan pl0 = dma_plan(blockIdx.x, p.a2, p.a2ps, 2, 2, 20);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_piece(pl0, k, p.a2ps, A2, BB_PS2, 20);
   }
 #ifdef CSMRI_DBG_STAMPS
   unsigned long long ph[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_t;
@@ -228,6 +233,8 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
     // ---- this tile's dY pixel into its image (bias gradient of layer 3 on the bf16 values the products see); all of
     // this tile's DMA pieces were issued during the previous tile: wait for mine, the barrier publishes everybody's
     if (tid < 484) {
+      const unsigned vg3 = p.gy_dt == CSMRI_F32
+          ? __builtin_bit_cast(unsigned, __builtin_convertvector(__builtin_bit_cast(f32x2_t, vg3r), bf16x2_t)) : vg3r[0];
       *(u32x4_t*)(G3 + tid * 16) = (u32x4_t){vg3, 0u, 0u, 0u};
       if (g3_central) { bs3[0] += __uint_as_float(vg3 << 16); bs3[1] += __uint_as_float(vg3 & 0xffff0000u); }
     }
@@ -235,17 +242,22 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
     BB_STAMP(0);
     __syncthreads();
     BB_STAMP(1);
-    // a1 and x of this tile stream in under phase 1 (their images are free since the previous tile's phases 2 / 3; every
-    // wait of the loop then finds only transfers that had a whole phase to land)
-    dma_image(tile, p.a1, p.a1ps, A1, BB_PS1, 4, 1, 1, 18);
-    dma_image(tile, p.x, p.xps, XI, 0, 1, 1, 1, 18);
+    load_g3(next);                               // (a register prefetch: the dY image itself is not touched)
+    // a1 and x of this tile stream in under phase 1 (their images are free since the previous tile's phases 2 / 3), one
+    // piece per fragment iteration of stage 1
+    const DmaPlan plA1 = dma_plan(tile, p.a1, p.a1ps, 1, 1, 18);
+    const DmaPlan plX = dma_plan(tile, p.x, p.xps, 1, 1, 18);
     BB_STAMP(2);
 
     // ---- phase 1: dA2 = conv(G3, W3 flipped) * lrelu'(a2) on 20 rows (origin y0 - 2, x0 - 2) ---------------------
     // K step s = filter row, lane group g = tap column (column 3 meets zero weights)
     auto stage1 = [&](auto border_tag) {
       constexpr bool BORDER = decltype(border_tag)::value;
-      for (int j = wv; j < BB_A2F; j += 8) {
+      int it = 0;                                      // (a ROLLED loop: unrolled, its four bodies spill)
+      dma_piece(plX, 0, p.xps, XI, 0, 18);
+#pragma nounroll
+      for (int j = wv; j < BB_A2F; j += 8, ++it) {
+        dma_piece(plA1, it, p.a1ps, A1, BB_PS1, 18);
         bf16x8_t xf[3];
         const char* src = G3 + (j * 16 + r16 + g) * 16;
 #pragma unroll
@@ -273,6 +285,8 @@ __global__ __launch_bounds__(BB_THREADS, 1) void convblock_bwd_kernel(const BBPa
         *(u32x2_t*)(D2 + so0) = pack4_bf16(v0);
         *(u32x2_t*)(D2 + so1) = pack4_bf16(v1);
       }
+#pragma nounroll
+      for (; it < 4; ++it) dma_piece(plA1, it, p.a1ps, A1, BB_PS1, 18);     // waves with three fragments
     };
     if (border) stage1(std::true_type{}); else stage1(std::false_type{});
     BB_STAMP(3);
@@ -300,16 +314,17 @@ BB_UNROLL_KC
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();               // dA2 complete, a1 / x landed; dY and a2 images are free
     BB_STAMP(5);
-    if (has_next) {
-      load_g3(next);
-      dma_image(next, p.a2, p.a2ps, A2, BB_PS2, 4, 2, 2, 20);
-    }
+    // a2 of the next tile streams in under phase 2, one piece per fragment iteration (its image is free from here on)
+    const DmaPlan plA2 = dma_plan(has_next ? next : tile, p.a2, p.a2ps, 2, 2, 20);
     BB_STAMP(6);
 
     // ---- phase 2: dA1 = conv(dA2, W2 flipped) * lrelu'(a1) on 18 rows (origin y0 - 1, x0 - 1) --------------------
     auto stage2 = [&](auto border_tag) {
       constexpr bool BORDER = decltype(border_tag)::value;
-      for (int j = wv; j < BB_A1F; j += 8) {
+      int it = 0;
+#pragma nounroll
+      for (int j = wv; j < BB_A1F; j += 8, ++it) {
+        if (has_next) dma_piece(plA2, it, p.a2ps, A2, BB_PS2, 20);
         bf16x8_t xf[9];
         const char* src = D2 + g * BB_PS2 + (j * 16 + r16) * 16;
 #pragma unroll
@@ -336,6 +351,10 @@ BB_UNROLL_KC
         }
         *(u32x2_t*)(D1 + so0) = pack4_bf16(v0);
         *(u32x2_t*)(D1 + so1) = pack4_bf16(v1);
+      }
+      if (has_next) {
+#pragma nounroll
+        for (; it < 4; ++it) dma_piece(plA2, it, p.a2ps, A2, BB_PS2, 20);
       }
     };
     if (border) stage2(std::true_type{}); else stage2(std::false_type{});
@@ -385,6 +404,11 @@ BB_UNROLL_KC
         for (int s = 0; s < 9; ++s)
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(W3L + (s * 64 + lane) * 16), xf[s], acc, 0, 0, 0);
         const int y = y0 + j, x = x0 + r16;
+        if (p.dx_split && g == 0) {
+          // channels 2,3 (zero weight rows: exact zeros so far) carry what the bf16 rounding of channels 0,1 drops
+          acc[2] = acc[0] - bf16_bits_to_f32(f32_to_bf16_bits(acc[0]));
+          acc[3] = acc[1] - bf16_bits_to_f32(f32_to_bf16_bits(acc[1]));
+        }
         if (g < 2 && y < p.H && x < p.W)
           *(u32x2_t*)(p.dx + ((((size_t)b * p.H + y) * p.W + x) * (size_t)p.dxps + 4 * g) * 2) = pack4_bf16(acc);
       }
@@ -434,8 +458,13 @@ BB_UNROLL_KC
     const int tap = 2 * wv + (g >> 1);
     if (tap < 9) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-        *(f32x4_t*)(p.slab1 + ((size_t)z * 32 + n * 16 + r16) * 72 + tap * 8 + (g & 1) * 4) = aw1[n];
+      for (int n = 0; n < 2; ++n) {
+        f32x4_t v = aw1[n];
+        if (p.x_split && (g & 1) == 0) {          // input channels 0..3 = (hi, lo) of the two real ones: one gradient
+          v[0] += v[2]; v[1] += v[3]; v[2] = 0.f; v[3] = 0.f;
+        }
+        *(f32x4_t*)(p.slab1 + ((size_t)z * 32 + n * 16 + r16) * 72 + tap * 8 + (g & 1) * 4) = v;
+      }
     }
   }
   if (p.want_db) {
@@ -476,6 +505,7 @@ extern "C" int csmri_convblock_fused_bwd(const csmri_convblock_bwd_desc* d, void
   CSMRI_CHECK_ARG((d->gy_pix_stride == 2 && d->gy_dtype == CSMRI_F32) || (d->gy_pix_stride >= 8 && d->gy_pix_stride % 2 == 0));
   CSMRI_CHECK_ARG(d->gy_dtype == CSMRI_F32 || d->gy_dtype == CSMRI_BF16);
   CSMRI_CHECK_ARG(d->Kp[0] >= 288 && d->Kp[1] >= 288 && d->Kp[2] >= 96);
+  if ((long long)d->H * d->W * (d->act_pix_stride[0] > d->act_pix_stride[1] ? d->act_pix_stride[0] : d->act_pix_stride[1]) * 2 >= (1ll << 31)) return CSMRI_E_UNSUPPORTED;   // 32-bit offsets inside an image
   if (d->dx) CSMRI_CHECK_ARG(d->dx_pix_stride >= 8 && d->dx_pix_stride % 4 == 0);
   if (((uintptr_t)d->x | (uintptr_t)d->act[0] | (uintptr_t)d->act[1] | (uintptr_t)d->wd[0] | (uintptr_t)d->wd[1] |
        (uintptr_t)d->wd[2] | (uintptr_t)d->dx | (uintptr_t)d->slab[0] | (uintptr_t)d->slab[1] | (uintptr_t)d->slab[2]) & 15)
@@ -497,6 +527,7 @@ extern "C" int csmri_convblock_fused_bwd(const csmri_convblock_bwd_desc* d, void
 #endif
   p.slab1 = d->slab[0]; p.slab2 = d->slab[1]; p.slab3 = d->slab[2];
   p.want_db = d->want_db;
+  p.x_split = d->x_split; p.dx_split = d->dx_split;
   const long long tiles = (long long)d->B * p.tiles_x * p.tiles_y;
   if (tiles >= (1ll << 31)) return CSMRI_E_UNSUPPORTED;
   CSMRI_CHECK_ARG(d->splits <= tiles);

@@ -172,8 +172,14 @@ __device__ __forceinline__ void fft_dit_inv(float2 (&v)[FftCfg<LOGN>::R], const 
 // Complex element storage of the image-side buffers: interleaved fp32 (float2) or interleaved bf16 (4 bytes per
 // complex value -- the "bf16 cFFT" of BASELINE config 5: arithmetic stays fp32 in registers / LDS, only the HBM
 // images and the intermediate between the passes are rounded; k-space data k0 / kout stays fp32).
+#define DC_IO_BF16_PADDED 4           // bf16 pixels of >= 4 channels: value = channels (0,1) + channels (2,3)
 template <int IO> __device__ __forceinline__ float2 ldc(const void* p, size_t scalar_idx) {
   if (IO == CSMRI_F32) return *(const float2*)((const float*)p + scalar_idx);
+  if (IO == DC_IO_BF16_PADDED) {      // a CSMRI_BF16_SPLIT gradient in full; a plain padded one unchanged (zeros there)
+    const u32x2_t u = *(const u32x2_t*)((const unsigned short*)p + scalar_idx);
+    return make_float2(__uint_as_float(u[0] << 16) + __uint_as_float(u[1] << 16),
+                       __uint_as_float(u[0] & 0xffff0000u) + __uint_as_float(u[1] & 0xffff0000u));
+  }
   const unsigned u = *(const unsigned*)((const unsigned short*)p + scalar_idx);
   return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
 }
@@ -232,7 +238,12 @@ __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const void* __restr
           f32x4_t* pp = (f32x4_t*)out_pad + p * 2;
           pp[0] = (f32x4_t){o.x, o.y, 0.f, 0.f}; pp[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         } else {
-          ((u32x4_t*)out_pad)[p] = (u32x4_t){(unsigned)f32_to_bf16_bits(o.x) | ((unsigned)f32_to_bf16_bits(o.y) << 16), 0u, 0u, 0u};
+          const unsigned hx = f32_to_bf16_bits(o.x), hy = f32_to_bf16_bits(o.y);
+          unsigned lo = 0u;
+          if (out_pad_dt == CSMRI_BF16_SPLIT)        // channels 2,3: what the rounding of channels 0,1 dropped
+            lo = (unsigned)f32_to_bf16_bits(o.x - bf16_bits_to_f32((unsigned short)hx)) |
+                 ((unsigned)f32_to_bf16_bits(o.y - bf16_bits_to_f32((unsigned short)hy)) << 16);
+          ((u32x4_t*)out_pad)[p] = (u32x4_t){hx | (hy << 16), lo, 0u, 0u};
         }
       }
     }
@@ -404,6 +415,9 @@ extern "C" int csmri_dc_bf16(const void* x, int x_pix_stride, const float* k0, c
 // data-gradient kernel wrote, without a conversion pass in between
 extern "C" int csmri_dc_in_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, float* out,
                                 void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream) {
+  if (x_pix_stride >= 4 && x_pix_stride % 4 == 0)     // channel-padded pixels: channels (0,1) + (2,3), see CSMRI_BF16_SPLIT
+    return dc_passes<CSMRI_F32, DC_IO_BF16_PADDED>(x, x_pix_stride, k0, mask, out, out_pad, out_pad_dtype, B, H, W,
+                                                    (hipStream_t)stream);
   return dc_passes<CSMRI_F32, CSMRI_BF16>(x, x_pix_stride, k0, mask, out, out_pad, out_pad_dtype, B, H, W,
                                            (hipStream_t)stream);
 }

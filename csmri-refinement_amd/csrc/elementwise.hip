@@ -54,7 +54,7 @@ __global__ void mask_to_u8_kernel(const float* m, int B, long long HW, uint8_t* 
 template <int C, int CP, int DT>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_c12_kernel(const float* __restrict__ src, int B, long long HW,
                                                                char* __restrict__ dst, int ps) {
-  constexpr int ES = DT == CSMRI_BF16 ? 2 : 4;
+  constexpr int ES = DT == CSMRI_F32 ? 4 : 2;
   const long long quads = (HW >> 2) * B;
   GRID_STRIDE(i, quads) {
     const long long b = i / (HW >> 2), r = (i - b * (HW >> 2)) << 2;
@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_c12_kernel(const float* __re
 #pragma unroll
         for (int c = 0; c < C; ++c) e[c] = v[c][q];
         char* oq = o + (long long)q * ps * ES;
-        if constexpr (DT == CSMRI_BF16) {
+        if constexpr (DT == CSMRI_BF16_SPLIT) {          // C == 2: channels 2,3 = what the rounding of 0,1 dropped
+          const float h0 = bf16_bits_to_f32(f32_to_bf16_bits(e[0])), h1 = bf16_bits_to_f32(f32_to_bf16_bits(e[1]));
+          const u32x2_t lo = pack4_bf16((f32x4_t){e[0], e[1], e[0] - h0, e[1] - h1});
+          *(u32x4_t*)oq = (u32x4_t){lo[0], lo[1], 0u, 0u};
+        } else if constexpr (DT == CSMRI_BF16) {
           const u32x2_t lo = pack4_bf16((f32x4_t){e[0], e[1], e[2], e[3]});
           *(u32x4_t*)oq = (u32x4_t){lo[0], lo[1], 0u, 0u};
         } else {
@@ -87,6 +91,16 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_c12_kernel(const float* __re
 extern "C" int csmri_nchw_to_nhwc(const float* src, int B, int C, int H, int W, void* dst,
                                   int dst_dtype, int dst_pix_stride, int Cpad, void* stream) {
   CSMRI_CHECK_ARG(src && dst && Cpad >= C && dst_pix_stride >= Cpad);
+  if (dst_dtype == CSMRI_BF16_SPLIT) {
+    // a 2-channel image as bf16 hi + lo in a padded pixel of 8: the fast path below only
+    if (C != 2 || Cpad != 8 || dst_pix_stride != 8 || (((uintptr_t)src | (uintptr_t)dst) & 15) || ((long long)H * W) % 4)
+      return CSMRI_E_UNSUPPORTED;
+    const long long HW_ = (long long)H * W;
+    hipLaunchKernelGGL((nchw_to_nhwc_c12_kernel<2, 8, CSMRI_BF16_SPLIT>), dim3(grid_for(HW_ / 4 * B)), dim3(256), 0,
+                       (hipStream_t)stream, src, B, HW_, (char*)dst, dst_pix_stride);
+    CSMRI_LAUNCH_CHECK();
+    return CSMRI_OK;
+  }
   long long total = (long long)B * H * W * Cpad;
   const long long HW = (long long)H * W;
   const bool al = !(((uintptr_t)src | (uintptr_t)dst) & 15) && HW % 4 == 0;

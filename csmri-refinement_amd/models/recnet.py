@@ -18,7 +18,7 @@ from models.weight_inits import initialize_weights
 RECNET_REQUIRED_PARAMS = ['num_blocks', 'num_convs', 'num_filters']
 RECNET_OPTIONAL_PARAMS = ['num_final_outputs', 'dilations_per_conv', 'kernel_size',
                           'relu_leakiness', 'padding', 'use_refinement', 'skip_final_dc',
-                          'return_intermediate_recs', 'compute_dtype', 'dc_storage']
+                          'return_intermediate_recs', 'compute_dtype', 'dc_storage', 'image_precision']
 
 
 def construct_model(conf, model_name, **kwargs):
@@ -56,16 +56,16 @@ class ConvBlock(nn.Module):
     return {'conv_weight': ('he_normal', RecNet.DEFAULT_RELU_LEAKINESS),
             first: {'weight': ('xavier', 1.0)}}
 
-  def forward(self, x):
-    """x: NHWC [B,H,W,8] compute dtype.  Returns interleaved complex fp32
-    [B,H,W,2] when the block ends in 2 channels (feeds DC), else NHWC."""
+  def forward(self, x, split=False):
+    """x: NHWC [B,H,W,8] compute dtype (``split``: a CSMRI_BF16_SPLIT image, bf16 hi + lo of the two real channels).
+    Returns interleaved complex fp32 [B,H,W,2] when the block ends in 2 channels (feeds DC), else NHWC."""
     n = self.num_convs
     cps = [self.layers[str(3 * i + 1)] for i in range(n)]
     plan = [(cp.layer, 1.0 if i == n - 1 else self.slope) for i, cp in enumerate(cps)]
     params = [p for cp in cps for p in (cp.weight, cp.bias)]
     out = self.out_dtype
     if self.num_outputs == 2 and out == torch.float32 and x.is_cuda:
-      out = ('complex', torch.float32)          # dense [B,H,W,2] fp32: what DC consumes
+      out = ('complex', torch.float32, 'split') if split else ('complex', torch.float32)   # dense [B,H,W,2] fp32: what DC consumes
     return ops.ConvActStack.apply(x, plan, out, *params)
 
 
@@ -75,7 +75,7 @@ class RecNet(nn.Module):
   def __init__(self, num_blocks, num_convs, num_filters, num_final_outputs=2,
                dilations_per_conv=1, kernel_size=3, relu_leakiness=DEFAULT_RELU_LEAKINESS,
                padding='zero', use_refinement=False, skip_final_dc=False,
-               return_intermediate_recs=False, compute_dtype=None, dc_storage=None):
+               return_intermediate_recs=False, compute_dtype=None, dc_storage=None, image_precision=None):
     super(RecNet, self).__init__()
     if isinstance(num_filters, int):
       num_filters = [num_filters] * num_blocks
@@ -107,11 +107,22 @@ class RecNet(nn.Module):
       assert dtype == torch.bfloat16 and not use_refinement, 'bf16 DC storage needs bf16 compute without refinement'
       for block in self.conv_blocks:
         block.out_dtype = torch.bfloat16
+    # The image between two cascades (and its gradient on the way back) is the one 2-channel tensor of the block: in bf16
+    # compute it travels as a channel-padded bf16 pixel of 8, 6 channels of which are padding.  'split' (default with
+    # bf16 compute and the fp32 DC path) stores bf16 hi + lo of the two real channels in that same pixel
+    # (CSMRI_BF16_SPLIT): 16 significant bits for the block input and for dX at no extra byte; 'bf16' rounds both to 8
+    # bits as rounds 1-3 did.  Measured on the trained 5-cascade at 45 dB: the bf16 forward pass loses 0.10 dB to the fp32
+    # one, 0.045 dB of it through this rounding (tests/c2_forward_floor.py, profiles/r04_c2_forward_floor.json).
+    if image_precision is None:
+      image_precision = 'split' if (dtype == torch.bfloat16 and dc_storage == 'fp32' and num_convs == 3) else 'bf16'
+    assert image_precision in ('split', 'bf16')
+    self.split_images = image_precision == 'split' and dtype == torch.bfloat16 and dc_storage == 'fp32'
 
   def forward(self, inp, kspace, mask):
     """inp, kspace, mask: [B,2,H,W] fp32 (re, im planes).  Returns [B,2,H,W]."""
     ensure_pack_group(self)          # trainable: one multi-layer re-pack per mode after an optimizer step (15 x 2 launches otherwise)
-    x_pad = ops.ToNHWC.apply(inp, self.dtype, 8)             # conv input layout
+    split = self.split_images and inp.is_cuda
+    x_pad = ops.ToNHWC.apply(inp, self.dtype, 8, split)      # conv input layout
     # interleaved complex copy of the input: only the residual form (use_refinement) and a cascade without any
     # block read it
     x_c = ops.ToNHWC.apply(inp, torch.float32, 2) if (self.use_refinement or not len(self.conv_blocks)) else None
@@ -120,11 +131,11 @@ class RecNet(nn.Module):
     recs = []
     nb = len(self.conv_blocks)
     for idx, block in enumerate(self.conv_blocks):
-      y = block(x_pad)                                       # fp32 [B,H,W,2] (re, im), or [B,H,W,8] with ch 0,1 = re,im
+      y = block(x_pad, split)                                # fp32 [B,H,W,2] (re, im), or [B,H,W,8] with ch 0,1 = re,im
       if self.use_refinement:
         y = y + (x_c if y.shape[3] == 2 else _CastPad.apply(x_c, torch.float32))
       if idx < len(self.dc_layers):
-        want_pad = self.dtype if idx < nb - 1 else None
+        want_pad = ((self.dtype, 'split') if split else self.dtype) if idx < nb - 1 else None
         res = ops.DataConsistency.apply(y, k0, m8, want_pad)
         if want_pad is not None:
           x_c, x_pad = res                 # both differentiable (ops.DataConsistency)

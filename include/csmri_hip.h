@@ -36,6 +36,12 @@ extern "C" {
 #define CSMRI_F32 0
 #define CSMRI_BF16 1
 #define CSMRI_FP8 2   /* OCP e4m3fn, per-tensor power-of-two scale: operand type of the fp8 csmri_gconv variant only */
+/* A 2-channel image (re, im) in a channel-padded bf16 pixel [8] as a SPLIT pair: channels 0,1 = hi = bf16(v), channels
+ * 2,3 = lo = bf16(v - hi), channels 4..7 zero -- 16 significant bits in the 16 bytes a padded bf16 pixel occupies anyway.
+ * A convolution whose weights repeat input channels 0,1 on channels 2,3 (csmri_convblock_desc.x_split) multiplies
+ * hi + lo; one whose weights are zero there reads plain bf16.  Accepted as the padded-copy type of csmri_dc* and as
+ * dst_dtype of csmri_nchw_to_nhwc (C = 2, Cpad = 8); never a compute dtype. */
+#define CSMRI_BF16_SPLIT 3
 
 #define CSMRI_OK 0
 #define CSMRI_E_ARG (-1)
@@ -173,6 +179,7 @@ typedef struct csmri_convblock_desc {
   void* out; int out_dtype; int out_pix_stride;       /* [B,H,W,8] (out_pix_stride >= 8), or out_pix_stride == 2 with
                                                          fp32: the dense interleaved complex image [B,H,W,2] that
                                                          DataConsistencyInKspace.perform (myfft.py:145-163) consumes */
+  int x_split;                                        /* x is CSMRI_BF16_SPLIT: layer 1 multiplies hi + lo */
 } csmri_convblock_desc;
 int csmri_convblock_fused_supported(const csmri_convblock_desc* d);
 int csmri_convblock_fused_fwd(const csmri_convblock_desc* d, void* stream);
@@ -206,6 +213,9 @@ typedef struct csmri_convblock_bwd_desc {
   float slope;
   void* dx; int dx_pix_stride;
   float* slab[3]; int splits; int want_db;
+  int x_split;        /* x is CSMRI_BF16_SPLIT: the weight gradient of layer 1 sums the hi and the lo products */
+  int dx_split;       /* write dx as CSMRI_BF16_SPLIT (channels 2,3 = what the bf16 rounding of channels 0,1 dropped):
+                         csmri_dc_in_bf16, the adjoint that consumes it, adds the two */
 } csmri_convblock_bwd_desc;
 int csmri_convblock_fused_bwd(const csmri_convblock_bwd_desc* d, void* stream);
 int csmri_convblock_fused_bwd_splits(int B, int H, int W);
@@ -319,7 +329,9 @@ int csmri_dc_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_
                   void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream);
 /* csmri_dc (fp32 arithmetic, intermediate and output) with the input image read as bf16, x_pix_stride in bf16
  * elements: the adjoint of DataConsistencyInKspace.perform (myfft.py:145-163 under autograd, k0 = NULL) applied
- * straight to the channel-padded bf16 gradient of the next conv block's input. */
+ * straight to the channel-padded bf16 gradient of the next conv block's input.  With x_pix_stride >= 4 the value read
+ * is channels (0,1) + channels (2,3): a CSMRI_BF16_SPLIT gradient in full, a plain one unchanged (its channels 2,3
+ * are zero). */
 int csmri_dc_in_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, float* out,
                      void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream);
 

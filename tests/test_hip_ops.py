@@ -707,6 +707,107 @@ def test_convblock_fused_forward_backward_at_bench_shape(hip):
     assert e < {'dx': 4e-3, 'db1': 6e-3, 'db2': 6e-3, 'db3': 6e-3}.get(lab, 3e-3), (lab, e)
 
 
+def test_split_bf16_image_format(hip):
+  """CSMRI_BF16_SPLIT (include/csmri_hip.h): a 2-channel image in a channel-padded bf16 pixel as hi = bf16(v) in channels
+  0,1 and lo = bf16(v - hi) in channels 2,3.  Producers: csmri_nchw_to_nhwc and the padded copy of csmri_dc; consumer
+  of a split GRADIENT: csmri_dc_in_bf16 (the DC adjoint), which reads channels (0,1) + (2,3).  hi + lo reproduces the
+  fp32 value to 2^-16 relative (bf16 alone: 2^-9); a plain padded bf16 tensor (zeros in channels 2,3) reads unchanged."""
+  ops = hip.ops
+  g = torch.Generator().manual_seed(77)
+  b, h, w = 2, 64, 64
+  x = torch.randn(b, 2, h, w, generator=g)
+  t = ops.nchw_to_nhwc(x.cuda(), torch.bfloat16, 8, split=True)
+  assert t.shape == (b, h, w, 8) and t.dtype == torch.bfloat16
+  tf = t.float().cpu()
+  want = x.permute(0, 2, 3, 1)
+  assert torch.equal(tf[..., :2], want.bfloat16().float())                   # hi = the plain bf16 rounding
+  assert torch.equal(tf[..., 2:4], (want - tf[..., :2]).bfloat16().float())  # lo = bf16 of the remainder
+  assert float(tf[..., 4:].abs().max()) == 0.0
+  rec = tf[..., :2] + tf[..., 2:4]
+  e_split, e_plain = float((rec - want).abs().max() / want.abs().max()), float((tf[..., :2] - want).abs().max() / want.abs().max())
+  print('split bf16: max rel err hi+lo %.2e, hi alone %.2e' % (e_split, e_plain))
+  assert e_split < 2.0 ** -15 and e_plain > 2.0 ** -10
+  # DC: the padded copy in split form against the fp32 result of the same call
+  k0 = torch.randn(b, h, w, 2, generator=g).cuda()
+  mask = (torch.rand(b, h, w, generator=g) < 0.3).to(torch.uint8).cuda()
+  xc = ops.nchw_to_nhwc(x.cuda(), torch.float32, 2)
+  out, pad = ops.dc_raw(xc, k0, mask, (torch.bfloat16, 'split'))
+  out2, pad2 = ops.dc_raw(xc, k0, mask, torch.bfloat16)
+  assert torch.equal(out, out2)
+  pf, of = pad.float(), out
+  assert torch.equal(pf[..., :2], pad2.float()[..., :2]) and float(pad2.float()[..., 2:].abs().max()) == 0.0
+  assert torch.equal(pf[..., 2:4], (of - pf[..., :2]).bfloat16().float()) and float(pf[..., 4:].abs().max()) == 0.0
+  assert float((pf[..., :2] + pf[..., 2:4] - of).abs().max() / of.abs().max()) < 2.0 ** -15
+  # the adjoint on a split gradient == the fp32 adjoint of (hi + lo); on a plain padded gradient == of its channels 0,1
+  gsp = pad                                                   # any split tensor serves as a gradient
+  a_split, _ = ops.dc_raw(gsp, None, mask, None, out_fp32=True)
+  a_ref, _ = ops.dc_raw((pf[..., :2] + pf[..., 2:4]).contiguous(), None, mask, None)
+  a_plain, _ = ops.dc_raw(pad2, None, mask, None, out_fp32=True)
+  a_ref_plain, _ = ops.dc_raw(pad2.float()[..., :2].contiguous(), None, mask, None)
+  assert rel_l2(a_split.cpu(), a_ref.cpu()) < 1e-6 and rel_l2(a_plain.cpu(), a_ref_plain.cpu()) < 1e-6
+
+
+def test_convblock_fused_split_images(hip):
+  """RecNet's fused conv block (reference models/recnet.py:29-62) fed a CSMRI_BF16_SPLIT input, 2 x 128 x 128: against
+  torch autograd on the CPU with the UNROUNDED fp32 input (weights and saved activations bf16-rounded as on the device),
+    forward: closer to that oracle than the same block on the plain bf16 input;
+    dW1 (x^T dA1): likewise -- the hi and the lo products are summed into one gradient;
+    dX: returned split, hi + lo closer to the oracle than the plain bf16 dX (whose output rounding alone is 1.7e-3);
+    the other gradients (they read a1, a2 and dY, which move with layer 1's input) stay within 5e-3 of the plain mode's."""
+  ops = hip.ops
+  b, h, w = 2, 128, 128
+  g = torch.Generator().manual_seed(4128)
+  ws = [torch.randn(32, 2, 3, 3, generator=g) * 0.4, torch.randn(32, 32, 3, 3, generator=g) * 0.08,
+        torch.randn(2, 32, 3, 3, generator=g) * 0.08]
+  bs = [torch.randn(32, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1, torch.randn(2, generator=g) * 0.1]
+  x = torch.randn(b, 2, h, w, generator=g)
+  gy = torch.randn(b, 2, h, w, generator=g)
+
+  def run(split):
+    params = [(torch.nn.Parameter(wt.clone().cuda()), torch.nn.Parameter(bi.clone().cuda())) for wt, bi in zip(ws, bs)]
+    plan = [(ops.ConvLayer(wp, bp, 1, (1, 1, 1, 1), 'zero', torch.bfloat16), 0.01 if i < 2 else 1.0)
+            for i, (wp, bp) in enumerate(params)]
+    xd = ops.nchw_to_nhwc(x.cuda(), torch.bfloat16, 8, split=split).requires_grad_(True)
+    out = ('complex', torch.float32, 'split') if split else ('complex', torch.float32)
+    log = ops.LAUNCH_LOG = []
+    try:
+      y = ops.ConvActStack.apply(xd, plan, out, *[t for pr in params for t in pr])
+      y.backward(to_dev_nhwc(gy, torch.float32)[..., :2].contiguous())
+      ops.join_wgrad_stream()
+      torch.cuda.synchronize()
+    finally:
+      ops.LAUNCH_LOG = None
+    assert [e[1] for e in log] == ['convblock_fwd_kernel<true>', 'convblock_bwd_kernel'], log
+    dx = xd.grad.float().cpu()
+    dx = (dx[..., :2] + dx[..., 2:4]) if split else dx[..., :2]
+    if not split:
+      assert float(xd.grad[..., 2:].float().abs().max()) == 0.0
+    return (y.detach().permute(0, 3, 1, 2).float().cpu(), dx.permute(0, 3, 1, 2).contiguous(),
+            [t.grad.cpu().clone() for pr in params for t in pr])
+  ys, dxs, gs = run(True)
+  yp, dxp, gp = run(False)
+  xr = x.clone().requires_grad_(True)                       # the UNROUNDED input
+  wr = [wt.bfloat16().float().requires_grad_(True) for wt in ws]
+  br = [bi.clone().requires_grad_(True) for bi in bs]
+  r = xr
+  for i in range(3):
+    r = F.conv2d(F.pad(r, (1, 1, 1, 1)), wr[i], br[i])
+    if i < 2:
+      r = F.leaky_relu(r, 0.01)
+      r = r + (r.detach().bfloat16().float() - r.detach())
+  r.backward(gy.bfloat16().float())
+  e = {'fwd': (rel_l2(ys, r.detach()), rel_l2(yp, r.detach())), 'dx': (rel_l2(dxs, xr.grad), rel_l2(dxp, xr.grad)),
+       'dw1': (rel_l2(gs[0], wr[0].grad), rel_l2(gp[0], wr[0].grad))}
+  for k, (a, c) in e.items():
+    print('convblock split images %-4s vs fp32-input oracle: split %.3e  plain bf16 %.3e' % (k, a, c))
+  assert e['fwd'][0] < 0.7 * e['fwd'][1] and e['fwd'][0] < 1.5e-3
+  assert e['dx'][0] < 0.7 * e['dx'][1] and e['dx'][0] < 1.5e-3
+  assert e['dw1'][0] < 0.7 * e['dw1'][1]
+  # the other gradients read a1, a2, dY only: the forward differs through x, so they are close, not identical
+  for i, lab in ((1, 'db1'), (2, 'dw2'), (3, 'db2'), (4, 'dw3'), (5, 'db3')):
+    assert rel_l2(gs[i], gp[i]) < 5e-3, (lab, rel_l2(gs[i], gp[i]))
+
+
 def test_layout_roundtrip(hip):
   ops = hip.ops
   x = torch.randn(2, 3, 8, 12)

@@ -142,6 +142,20 @@ def run(config, dtype, args, train, held, pretrained, dev):
          'final_psnr_heldout_train_bn': psnr_of(runner, held, True),
          'final_psnr_heldout_eval': psnr_of(runner, held, False),
          'final_psnr_train_batches': psnr_of(runner, train[:len(held)], True)}
+  if config == 'c2' and dtype != 'fp32':
+    # the SAME trained fp32 master weights evaluated through the fp32 compute path: separates what the storage format did
+    # to the TRAINING (the weights it arrived at) from what it does to the FORWARD pass that evaluates them
+    r32, _ = build(config, 'fp32', args.batch, args.width, args.seed, pretrained)
+    r32.model.load_state_dict(runner.model.state_dict())
+    from csmri_hip import ops
+    ops.bump_weight_epoch()
+    res['final_psnr_heldout_eval_fp32_compute_of_these_weights'] = psnr_of(r32, held, False)
+    del r32
+  if getattr(args, 'save_weights', None):
+    model = runner.gen if hasattr(runner, 'gen') else runner.model
+    os.makedirs(args.save_weights, exist_ok=True)
+    torch.save({k: v.detach().float().cpu() for k, v in model.state_dict().items()},
+               os.path.join(args.save_weights, '%s_%s.pth' % (config, dtype + ('p%d' % pseed if perturbed else ''))))
   return res, runner, conf
 
 
@@ -169,6 +183,7 @@ def main(argv=None):
   p.add_argument('--seed', type=int, default=1)
   p.add_argument('--ensemble', type=int, default=0,
                  help='append this many perturbed members (fp32p1.., bf16p1..) per base dtype in --dtypes')
+  p.add_argument('--save-weights', default=None, help='directory for the trained state dicts (one small file per run)')
   p.add_argument('--variant', default='', help='free-text tag of the product variant under test (recorded)')
   p.add_argument('--out', default=None)
   args = p.parse_args(argv)
