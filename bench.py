@@ -73,6 +73,7 @@ def parse():
   p.add_argument('--device-resident', action='store_true',
                  help='A/B: batches resident in HBM when the timed region starts (default: pinned host batches, '
                       'H2D on a copy stream INSIDE the timed region, as SURVEY 8d defines the metric)')
+  p.add_argument('--copy-streams', type=int, default=2, help='HIP streams the H2D copies of a batch are spread over')
   p.add_argument('--no-input-ab', action='store_true',
                  help='skip the second timed pass (batches resident in HBM) that fills `input_ab`')
   p.add_argument('--settle-s', type=float, default=0.6,
@@ -159,6 +160,7 @@ class PinnedHostLoader(object):
 
   _pinned = {}          # host batches are pinned ONCE (page-locking ~1 GB takes most of a second)
   _resident = {}        # device copies of the resident A/B leg, made once
+  COPY_STREAMS = 2      # (--copy-streams)
 
   def __init__(self, host_batches, n, device, resident=False):
     import torch
@@ -174,9 +176,11 @@ class PinnedHostLoader(object):
       with _near_gpu(device):        # page-lock on the GPU's own NUMA node (2-socket hosts: H2D from the far node is slower)
         PinnedHostLoader._pinned[key] = [{k: v.pin_memory() for k, v in b.items()} for b in host_batches]
     self.host = PinnedHostLoader._pinned[key]
-    self.copy_stream = torch.cuda.Stream()
+    # the tensors of a batch are copied on COPY_STREAMS streams in turn: one hipMemcpyAsync stream is served by one
+    # SDMA engine (17-28 GB/s on the boxes measured), two move a 134 MB C2 batch in parallel
+    self.copy_streams = [torch.cuda.Stream() for _ in range(max(1, PinnedHostLoader.COPY_STREAMS))]
     self.dev = [{k: torch.empty_like(v, device=device) for k, v in host_batches[0].items()} for _ in range(4)]
-    self.ready = [torch.cuda.Event() for _ in self.dev]
+    self.ready = [[torch.cuda.Event() for _ in self.copy_streams] for _ in self.dev]
 
   def __len__(self):
     return self.n
@@ -188,12 +192,14 @@ class PinnedHostLoader(object):
     # (steps <= i-2) must be done before it is overwritten
     guard = torch.cuda.Event()
     guard.record()
-    self.copy_stream.wait_event(guard)
-    with torch.cuda.stream(self.copy_stream):
-      src = self.host[i % len(self.host)]
-      for k, d in self.dev[j].items():
-        d.copy_(src[k], non_blocking=True)
-      self.ready[j].record(self.copy_stream)
+    src = self.host[i % len(self.host)]
+    items = list(self.dev[j].items())
+    for c, st in enumerate(self.copy_streams):
+      st.wait_event(guard)
+      with torch.cuda.stream(st):
+        for k, d in items[c::len(self.copy_streams)]:
+          d.copy_(src[k], non_blocking=True)
+        self.ready[j][c].record(st)
 
   def __iter__(self):
     import torch
@@ -205,7 +211,8 @@ class PinnedHostLoader(object):
     for i in range(self.n):
       if i + 1 < self.n:
         self._issue(i + 1)
-      torch.cuda.current_stream().wait_event(self.ready[i % len(self.dev)])
+      for ev in self.ready[i % len(self.dev)]:
+        torch.cuda.current_stream().wait_event(ev)
       yield self.dev[i % len(self.dev)]
 
 
@@ -427,6 +434,7 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
                     for i in range(N_HOST_BATCHES)]
   dev = torch.device('cuda', torch.cuda.current_device())
   resident = bool(args.device_resident)
+  PinnedHostLoader.COPY_STREAMS = args.copy_streams
 
   def loader_factory(n, resident=resident):
     return PinnedHostLoader(host_batches, n, dev, resident=resident)
