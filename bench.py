@@ -29,9 +29,9 @@ Extra legs (rank 0, outside the timed region):
                 same workload; the dominant kernel's algorithmic FLOP/s vs the dense MFMA peak of the dtype
   roofline_hbm  the same brackets around the HBM-bound entry points (data consistency, BatchNorm passes,
                 Adam) with their algorithmic bytes vs 8 TB/s
-  cpu_baseline  the CPU oracle's (plain torch fp32) step on the SAME batch (N=1 only): one timed step at 32 and at
-                64 threads picks the thread count, then >= 5 timed steps at that count; plus the PSNR of both
-                paths on the same batch/weights.
+  cpu_baseline  the CPU oracle's (plain torch fp32) step on the SAME batch (N=1 only): >= 5 timed steps after a
+                warm-up at 32 threads (--cpu-all-threads probes 64 and os.cpu_count() as well and keeps the best);
+                plus the PSNR of both paths on the same batch/weights.
 """
 import argparse
 import json
@@ -69,7 +69,7 @@ def parse():
   p.add_argument('--no-graphs', action='store_true', help='eager launches instead of hipGraph replay')
   p.add_argument('--no-overlap', action='store_true', help='keep the VGG branch on the main stream')
   p.add_argument('--cpu-all-threads', action='store_true',
-                 help='also time the CPU baseline at os.cpu_count() threads (256 on the GPU box: ~3 min per step)')
+                 help='also probe the CPU baseline at 64 and at os.cpu_count() threads (256 on the GPU box: ~3 min per step)')
   p.add_argument('--device-resident', action='store_true',
                  help='A/B: batches resident in HBM when the timed region starts (default: pinned host batches, '
                       'H2D on a copy stream INSIDE the timed region, as SURVEY 8d defines the metric)')
@@ -234,14 +234,14 @@ def _split_sd(sd):
 
 
 def _thread_counts(all_threads):
-  """Thread counts the CPU baseline is timed at.  Small-batch conv2d stops scaling well before the box's
-  hardware threads and then collapses: measured on the GPU box (2 x EPYC 9575F, 256 threads;
-  profiles/r02_bench_n1_a.json) 1.79 slices/s at 32 threads against 0.046 at 256 (174 s per step), so
-  the os.cpu_count() run is opt-in (--cpu-all-threads) and the default adds 64 threads beside 32."""
+  """Thread counts the CPU baseline is probed at.  Small-batch conv2d stops scaling well before the box's hardware
+  threads and then collapses: measured on the GPU boxes (2 x EPYC 9575F, 256 threads) 1.5-1.8 slices/s at 32 threads,
+  1.0 at 64 (profiles/r04_bench_n1.json: every round's probe picked 32) and 0.046 at 256 (174 s per step,
+  profiles/r02_bench_n1_a.json): the default is 32 alone, --cpu-all-threads adds 64 and os.cpu_count()."""
   n = os.cpu_count() or 1
-  counts = {min(32, n), min(64, n)}
+  counts = {min(32, n)}
   if all_threads:
-    counts.add(n)
+    counts.update((min(64, n), n))
   return sorted(counts)
 
 
@@ -267,15 +267,15 @@ def cpu_baseline_c3(runner, host_batch, steps=5, all_threads=False):
     pool = O.ImagePool(80)
     return lambda: O.gan_train_step(PG, SG, PD, SD, PV, gopt, dopt, batch, pool=pool)
 
-  probe = {}
-  for threads in _thread_counts(all_threads):
+  probe, counts = {}, _thread_counts(all_threads)
+  for threads in (counts if len(counts) > 1 else ()):     # (one candidate: nothing to probe)
     torch.set_num_threads(threads)
     step = fresh()
     step()                                       # warm-up
     t0 = time.time()
     step()
     probe[threads] = b / (time.time() - t0)
-  best = max(probe, key=probe.get)
+  best = max(probe, key=probe.get) if probe else counts[0]
   torch.set_num_threads(best)
   step = fresh()
   step()
@@ -286,9 +286,8 @@ def cpu_baseline_c3(runner, host_batch, steps=5, all_threads=False):
   return {'value': round(value, 4), 'unit': 'slices/s', 'cores': best, 'kind': 'port', 'cpu': _cpu_model(),
           'probe_by_threads': {str(k): round(v, 4) for k, v in probe.items()}, 'host_threads': os.cpu_count(),
           'timed_steps': steps,
-          'sample': 'oracle (plain torch fp32) GAN step on the same %d slices of 256x256 as the GPU run: one timed '
-                    'step per thread count picks the count, then %d timed steps after 1 warm-up at that count'
-                    % (b, steps)}
+          'sample': 'oracle (plain torch fp32) GAN step on the same %d slices of 256x256 as the GPU run: %d timed steps '
+                    'after 1 warm-up at %d threads%s' % (b, steps, best, ' (the best of the probed counts)' if probe else '')}
 
 
 def psnr_probe_c3(runner, host_batch, scale):
@@ -321,14 +320,14 @@ def cpu_baseline_c2(runner, host_batch, sample_b=16, steps=5, all_threads=False,
 
   probe = {}
   counts = [min(32, os.cpu_count() or 1)] if fast else _thread_counts(all_threads)
-  for threads in counts:
+  for threads in (counts if len(counts) > 1 else ()):
     torch.set_num_threads(threads)
     _, step = fresh()
     step()
     t0 = time.time()
     step()
     probe[threads] = sample_b / (time.time() - t0)
-  best = max(probe, key=probe.get)
+  best = max(probe, key=probe.get) if probe else counts[0]
   torch.set_num_threads(best)
   P, step = fresh()
   with torch.no_grad():
@@ -341,9 +340,8 @@ def cpu_baseline_c2(runner, host_batch, sample_b=16, steps=5, all_threads=False,
   return {'value': round(value, 4), 'unit': 'slices/s', 'cores': best, 'kind': 'port', 'cpu': _cpu_model(),
           'probe_by_threads': {str(k): round(v, 4) for k, v in probe.items()}, 'host_threads': os.cpu_count(),
           'timed_steps': steps,
-          'sample': 'oracle (plain torch fp32) RecNet(5,3,32) MSE step, first %d slices of the batch: one timed step '
-                    'per thread count picks the count, then %d timed steps after 1 warm-up at that count'
-                    % (sample_b, steps)}, psnr
+          'sample': 'oracle (plain torch fp32) RecNet(5,3,32) MSE step, first %d slices of the batch: %d timed steps '
+                    'after 1 warm-up at %d threads%s' % (sample_b, steps, best, ' (the best of the probed counts)' if probe else '')}, psnr
 
 
 def roofline(runner, loader_factory, dtype, steps=2, config='c3'):

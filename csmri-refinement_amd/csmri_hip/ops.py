@@ -363,8 +363,13 @@ def quantize_fp8(x, amax=None):
   return q, scales
 
 
+SPLITK_OVERRIDE = None   # tools/sk_sweep.py only: force the split-K factor of csmri_gconv launches
+
+
 def _gconv_run(d, want_stats, flops=0.0):
   splitk = lib.raw('csmri_gconv_suggest_splitk')(C.byref(d))
+  if SPLITK_OVERRIDE is not None and splitk >= 1 and not want_stats:
+    splitk = SPLITK_OVERRIDE
   if want_stats:
     splitk = 1
   d.splitk = splitk
