@@ -191,7 +191,7 @@ def test_dispatch_variants_are_all_exercised():
   splitk = any(e[2] > 1 and e[0] == 'gconv' for v in SEEN.values() for e in v)
   assert splitk, 'no split-K convolution among the bench shapes'
   need = {'tconv_kernel', 'gconv_kernel', 'gconv_glds_kernel', 'pconv2_kernel',
-          'thin_out1_kernel', 'wpatch_kernel', 'wgrad_glds_row_kernel', 'wthin_out_kernel'}
+          'thin_out1_tile_kernel', 'wpatch_kernel', 'wgrad_glds_row_kernel', 'wthin_out_kernel'}
   assert need <= fam, (need - fam, fam)
   path = os.path.join(ROOT, 'profiles', 'r04_bench_n1.json')
   assert os.path.exists(path), 'commit the bench line of this build as profiles/r04_bench_n1.json'
