@@ -699,28 +699,39 @@ __device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned (&k)[2])
   c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
   k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
 }
-__global__ __launch_bounds__(1024) void dropout2d_mask_kernel(float* __restrict__ out, long long n, float p,
-                                                              unsigned long long* state) {
+// state = {seed, call, arrivals}: every workgroup reads `call` when it starts and takes a ticket when it is done; the
+// one that draws the last ticket advances `call` and clears the tickets -- after every workgroup has read the old value,
+// so the launch may span the chip (one workgroup of 1024 threads took 33 us for the 43,008 values of the 24-image
+// discriminator pass; it sits at the head of the discriminator chain).
+__global__ __launch_bounds__(256) void dropout2d_mask_kernel(float* __restrict__ out, long long n, float p,
+                                                             unsigned long long* state) {
   const unsigned long long seed = state[0], call = state[1];
-  __syncthreads();
-  if (threadIdx.x == 0) state[1] = call + 1;
   const float keep_p = 1.f - p, scale = 1.f / (1.f - p);
-  for (long long g = threadIdx.x; g * 4 < n; g += blockDim.x) {
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g * 4 < n; g += (long long)gridDim.x * 256) {
     unsigned c[4] = {(unsigned)g, (unsigned)(g >> 32), (unsigned)call, (unsigned)(call >> 32)};
     unsigned k[2] = {(unsigned)seed, (unsigned)(seed >> 32)};
 #pragma unroll
     for (int r = 0; r < 10; ++r) philox_round(c, k);
+    float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const long long i = g * 4 + e;
-      if (i < n) out[i] = (float)(c[e] >> 8) * (1.f / 16777216.f) < keep_p ? scale : 0.f;
-    }
+    for (int e = 0; e < 4; ++e) v[e] = (float)(c[e] >> 8) * (1.f / 16777216.f) < keep_p ? scale : 0.f;
+    if (g * 4 + 3 < n) *(f32x4_t*)(out + g * 4) = (f32x4_t){v[0], v[1], v[2], v[3]};
+    else
+      for (int e = 0; e < 4; ++e) if (g * 4 + e < n) out[g * 4 + e] = v[e];
+  }
+  __syncthreads();                                  // every thread of the workgroup has read `call`
+  if (threadIdx.x == 0) {
+    const unsigned long long t = atomicAdd(&state[2], 1ull);
+    if (t == (unsigned long long)gridDim.x - 1) { state[2] = 0ull; state[1] = call + 1; }
   }
 }
 extern "C" int csmri_dropout2d_mask(float* mask, long long n, float p, unsigned long long* state, void* stream) {
   CSMRI_CHECK_ARG(mask && state && n > 0 && n <= (1ll << 24) && p >= 0.f && p < 1.f);
-  if ((uintptr_t)state & 7) return CSMRI_E_ALIGN;
-  hipLaunchKernelGGL(dropout2d_mask_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, n, p, state);
+  if (((uintptr_t)state & 7) || ((uintptr_t)mask & 15)) return CSMRI_E_ALIGN;
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(dropout2d_mask_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, mask, n, p, state);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -127,7 +127,7 @@ class CNNDiscriminator(nn.Module):
     st = getattr(self, '_rng_state', None)
     if st is None or st.device != device:
       seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-      st = self._rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+      st = self._rng_state = torch.tensor([seed, 0, 0], dtype=torch.int64, device=device)   # {seed, call, tickets}
     n = b * sum(cs)
     flat = torch.empty(n, dtype=torch.float32, device=device)
     lib.call('csmri_dropout2d_mask', flat.data_ptr(), n, float(self.dropout_prob), st.data_ptr(), ops.stream())

@@ -544,8 +544,9 @@ int csmri_disc_accuracy(const float* prob_fake, const float* prob_real, int B, i
  * Bernoulli(1 - p) draw per (image, channel), survivors scaled by 1 / (1 - p)), all dropout layers in ONE launch:
  *   mask[i] = keep_i / (1 - p),  keep_i = [u_i < 1 - p],
  *   u_i = (Philox4x32-10(counter = (i / 4, 0, call_lo, call_hi), key = (seed_lo, seed_hi))[i % 4] >> 8) * 2^-24
- * state: DEVICE uint64[2] = {seed, call}; the launch increments `call` (hipGraph-replay safe: every replay draws
- * new masks, and an eager run draws the same sequence).  The masks are APPLIED by csmri_bn_act / the BatchNorm
+ * state: DEVICE uint64[3] = {seed, call, 0}; the launch increments `call` (hipGraph-replay safe: every replay draws
+ * new masks, and an eager run draws the same sequence); the third word counts the launch's workgroups as they finish
+ * (the last one advances `call`) and is zero between launches.  mask: 16-byte aligned.  The masks are APPLIED by csmri_bn_act / the BatchNorm
  * backward (`dropmask`); tests inject masks there directly.  n <= 2^24. */
 int csmri_dropout2d_mask(float* mask, long long n, float p, unsigned long long* state, void* stream);
 

@@ -1146,12 +1146,12 @@ def test_dropout2d_mask_matches_the_philox_oracle_bit_for_bit(hip, n, p):
   numpy Philox4x32-10 (pinned to the generator's published known-answer vectors on the CPU side): every mask value
   equal, the call counter advances by one per launch, untouched memory behind the mask stays untouched."""
   seed = 0x0123456789abcdef ^ n
-  st = torch.tensor([seed, 5], dtype=torch.int64, device='cuda')
+  st = torch.tensor([seed, 5, 0], dtype=torch.int64, device='cuda')      # {seed, call, finished workgroups}
   out = torch.full((n + 5,), -3.0, device='cuda')
   for call in (5, 6):
     hip.lib.call('csmri_dropout2d_mask', out.data_ptr(), n, p, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert st.tolist() == [seed, call + 1]
+    assert st.tolist() == [seed, call + 1, 0]
     want = O.dropout2d_mask(seed, call, n, p)
     assert torch.equal(out[:n].cpu(), want), (n, p, call)
     assert bool((out[n:] == -3.0).all())

@@ -5,7 +5,7 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcb_$c -o r01 -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-other-configs --settle-s 0 --steps 6 --warmup 2 "$@" > $R/gpurun_out/pmcb_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcb_$c -o r01 -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-other-configs --no-input-ab --settle-s 0 --steps 6 --warmup 2 "$@" > $R/gpurun_out/pmcb_$c.log 2>&1
 done
 python3 - $R <<'PY'
 import csv, glob, sys, json, collections

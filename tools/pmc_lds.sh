@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   rm -rf $R/gpurun_out/pmcl_$((++i))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcl_$i -o l -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-other-configs --settle-s 0 --no-overlap --steps 4 --warmup 2 > /dev/null 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcl_$i -o l -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-other-configs --no-input-ab --settle-s 0 --no-overlap --steps 4 --warmup 2 > /dev/null 2>&1
 done
 python3 - $R <<'PY'
 import csv, glob, sys, collections

@@ -6,7 +6,7 @@
 #   utilisation = MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 * 1024)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/pmcm -o r01 -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-other-configs --settle-s 0 --no-overlap --steps 6 --warmup 2 "$@" > $R/gpurun_out/pmcm.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/pmcm -o r01 -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-other-configs --no-input-ab --settle-s 0 --no-overlap --steps 6 --warmup 2 "$@" > $R/gpurun_out/pmcm.log 2>&1
 python3 - $R <<'PY'
 import csv, glob, sys, json, collections
 R = sys.argv[1]

@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/tl
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl -o t -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 12 --warmup 4 --no-other-configs --settle-s 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl -o t -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 12 --warmup 4 --no-other-configs --no-input-ab --settle-s 0 > /dev/null 2>&1
 f=$(find $R/gpurun_out/tl -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/trace_timeline.py "$f" > $R/gpurun_out/timeline.txt
 NAMELEN=150 python3 $R/tools/trace_timeline.py "$f" | head -40 > $R/gpurun_out/timeline_head.txt
