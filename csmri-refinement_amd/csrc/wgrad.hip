@@ -260,6 +260,49 @@ __global__ __launch_bounds__(256) void wgrad_scatter_t_kernel(const float* slab,
   __shared__ float tile[16][65];
   wgrad_scatter_t_body(tile, blockIdx.x, blockIdx.y * 64, slab, splitk, Cout, NK, Cin, taps, Cin_real, dw, accumulate);
 }
+// The same for ROWS output channels per workgroup, taps <= 16 (every layer of the step): all ROWS * 4 slab loads of a thread
+// are in flight before the one barrier -- the single-row form moves 4 KiB in and 4 KiB out per workgroup behind two
+// barriers and ran the discriminator's 67 MB layers at 2 TB/s (67 us on the tail of D's backward).
+template <int ROWS>
+__global__ __launch_bounds__(256) void wgrad_scatter_t_rows_kernel(const float* __restrict__ slab, int splitk, int Cout, int NK,
+                                                                   int Cin, int taps, int Cin_real, int Cout_real,
+                                                                   float* __restrict__ dw, int accumulate) {
+  __shared__ float tile[ROWS][16][65];
+  const int co0 = blockIdx.x * ROWS, ci0 = blockIdx.y * 64;
+  const size_t zs = (size_t)Cout * NK;
+  float v[ROWS][4];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = threadIdx.x + 256 * j, t = e >> 6, c = e & 63;
+      v[r][j] = 0.f;
+      if (co0 + r < Cout_real && t < taps && ci0 + c < Cin) {
+        const float* q = slab + (size_t)(co0 + r) * NK + (size_t)t * Cin + ci0 + c;
+        float s = 0.f;
+        for (int z = 0; z < splitk; ++z) s += q[(size_t)z * zs];
+        v[r][j] = s;
+      }
+    }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      tile[r][e >> 6][e & 63] = v[r][j];
+    }
+  __syncthreads();
+  const int nc = min(64, Cin_real - ci0);
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    if (co0 + r >= Cout_real) break;
+    for (int idx = threadIdx.x; idx < nc * taps; idx += 256) {
+      const int cc = idx / taps, t = idx - cc * taps;
+      const size_t o = ((size_t)(co0 + r) * Cin_real + ci0 + cc) * taps + t;
+      dw[o] = accumulate ? dw[o] + tile[r][t][cc] : tile[r][t][cc];
+    }
+  }
+}
 
 // bias gradient: column sums of dY, two deterministic stages
 #define DB_ROWS 2048     // partial rows of the bias-gradient column sums (one workgroup each)
@@ -1145,9 +1188,14 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
     return CSMRI_OK;
   }
   if (p.splitk <= 8) {        // big layers: bandwidth-bound transposing copy
-    hipLaunchKernelGGL(wgrad_scatter_t_kernel, dim3(d->Cout_real, (d->Cin_real + 63) / 64), dim3(256), 0, st,
-                       d->slab, p.splitk, d->Cout, p.NK, d->Cin, d->KH * d->KW, d->Cin_real, d->dw,
-                       d->accumulate);
+    if (d->KH * d->KW <= 16 && (long long)d->Cout_real * ((d->Cin_real + 63) / 64) >= 4096)
+      hipLaunchKernelGGL((wgrad_scatter_t_rows_kernel<4>), dim3((d->Cout_real + 3) / 4, (d->Cin_real + 63) / 64), dim3(256), 0, st,
+                         d->slab, p.splitk, d->Cout, p.NK, d->Cin, d->KH * d->KW, d->Cin_real, d->Cout_real, d->dw,
+                         d->accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_scatter_t_kernel, dim3(d->Cout_real, (d->Cin_real + 63) / 64), dim3(256), 0, st,
+                         d->slab, p.splitk, d->Cout, p.NK, d->Cin, d->KH * d->KW, d->Cin_real, d->dw,
+                         d->accumulate);
   } else {                    // few outputs, many splits: one thread per output element
     const long long total = (long long)d->Cout_real * p.NK;
     int blocks = (int)((total + 31) / 32); if (blocks > 4096) blocks = 4096;
