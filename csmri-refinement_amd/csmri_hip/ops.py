@@ -1610,12 +1610,13 @@ class RefineCombine(torch.autograd.Function):
     u, scale, mm = ctx.saved_tensors
     b, h, w, cp = u.shape
     gpred = gpred.contiguous()
-    du = torch.zeros(b, h, w, cp, dtype=u.dtype, device=u.device)        # (pad channels must be exact zeros)
+    # (pad channels must be exact zeros: the kernel writes a pixel of 8 channels whole, wider ones are cleared here)
+    du = (torch.empty if cp == 8 else torch.zeros)(b, h, w, cp, dtype=u.dtype, device=u.device)
     part = torch.empty(1026, dtype=torch.float32, device=u.device)
     lib.call('csmri_refine_combine_bwd', gpred.data_ptr(), u.data_ptr(), dt_of(u), u.stride(2),
              scale.data_ptr(), mm.data_ptr(), b, h * w, du.data_ptr(), dt_of(du), du.stride(2),
              part.data_ptr(), stream())
-    return None, du, part[:1].clone()
+    return None, du, part[:1]
 
 
 class MeanLoss(torch.autograd.Function):

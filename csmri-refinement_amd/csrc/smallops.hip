@@ -176,7 +176,11 @@ __global__ __launch_bounds__(256) void refine_combine_bwd_kernel(
     const float half_mx = mm[2 * b + 1] * 0.5f;
     const float g = gpred[i].x;
     const float uv = load_elem(u, i * ups, udt);
-    store_elem(du, i * dups, dudt, g * s * half_mx);
+    // a pixel of exactly 8 channels is written whole (the value + 7 zero pad channels): the caller need not clear du
+    const float dv = g * s * half_mx;
+    if (dups == 8 && dudt == CSMRI_BF16) ((u32x4_t*)du)[i] = (u32x4_t){(unsigned)f32_to_bf16_bits(dv), 0u, 0u, 0u};
+    else if (dups == 8) { ((f32x4_t*)du)[2 * i] = (f32x4_t){dv, 0.f, 0.f, 0.f}; ((f32x4_t*)du)[2 * i + 1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    else store_elem(du, i * dups, dudt, dv);
     acc += (double)(g * uv * half_mx);
   }
   double tot = block_sum(acc);
@@ -197,6 +201,7 @@ extern "C" int csmri_refine_combine_bwd(const float* gpred, const void* u, int u
                                         long long HW, void* du, int du_dtype, int du_pix_stride,
                                         float* dscale_partial, void* stream) {
   CSMRI_CHECK_ARG(gpred && u && scale_param && minmax && du && dscale_partial);
+  if (du_pix_stride == 8 && ((uintptr_t)du & 15)) return CSMRI_E_ALIGN;
   const int blocks = grid_for((long long)B * HW);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(refine_combine_bwd_kernel, dim3(blocks), dim3(256), 0, st, (const float2*)gpred, u,

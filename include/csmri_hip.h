@@ -436,7 +436,8 @@ int csmri_minmax_real(const float* x, int B, long long HW, float* minmax, void* 
 int csmri_refine_combine(const float* pre, const void* u, int u_dtype, int u_pix_stride,
                          const float* scale_param, const float* minmax, int B, long long HW,
                          float* pred, float* scaled, void* stream);
-/* backward: du = gpred_real * s*max/2 (+ gu_extra), dscale += sum gpred_real*u*max/2 */
+/* backward: du = gpred_real * s*max/2, dscale += sum gpred_real*u*max/2.  du_pix_stride == 8 (16-byte aligned du): the
+ * pixel is written whole -- the value and seven zero pad channels --, wider pixels must be cleared by the caller. */
 int csmri_refine_combine_bwd(const float* gpred, const void* u, int u_dtype, int u_pix_stride,
                              const float* scale_param, const float* minmax, int B,
                              long long HW, void* du, int du_dtype, int du_pix_stride,
