@@ -92,7 +92,7 @@ class ScalarList(C.Structure):
 
 class PackItem(C.Structure):
   _fields_ = [('w', vp), ('out', vp), ('mode', i32), ('dtype', i32), ('Cout', i32), ('Cin', i32),
-              ('KH', i32), ('KW', i32)]
+              ('KH', i32), ('KW', i32), ('bias', vp), ('bias_out', vp)]
 
 
 class LossItem(C.Structure):
@@ -155,6 +155,7 @@ _SIGS = {
     'csmri_dc_in_bf16': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     'csmri_nchw_to_nhwc': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),
     'csmri_nhwc_to_nchw': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    'csmri_nchw_to_nhwc_add': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, vp]),
     'csmri_mask_to_u8': (i32, [vp, i32, i32, i32, vp, vp]),
     'csmri_bn_stats_rows': (i32, [i32, i32]),
     'csmri_bn_stats': (i32, [i32, vp, i32, i32, i32, vp, i32, vp]),
@@ -162,10 +163,10 @@ _SIGS = {
     'csmri_bn_act': (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, f32,
                            vp, vp, i32, vp]),
     'csmri_bn_bwd_reduce': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, f32,
-                                  vp, vp, vp, i32, vp]),
+                                  vp, vp, vp, i32, vp, i32, vp]),
     'csmri_bn_bwd_apply': (i32, [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32,
-                                 vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, vp, i32, vp]),
-    'csmri_act_bwd': (i32, [i32, vp, i32, vp, i32, vp, i32, i64, i32, f32, vp]),
+                                 vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp]),
+    'csmri_act_bwd': (i32, [i32, vp, i32, vp, i32, vp, i32, i64, i32, f32, vp, i32, vp]),
     'csmri_maxpool2': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     'csmri_maxpool2_bwd': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     'csmri_maxpool2_bwd_act': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i32, f32, vp, i32, vp]),
@@ -175,7 +176,7 @@ _SIGS = {
     'csmri_minmax_real': (i32, [vp, i32, i64, vp, vp]),
     'csmri_refine_combine': (i32, [vp, vp, i32, i32, vp, vp, i32, i64, vp, vp, vp]),
     'csmri_refine_combine_bwd': (i32, [vp, vp, i32, i32, vp, vp, i32, i64, vp, i32, i32, vp,
-                                       vp]),
+                                       vp, vp, i32, vp, i32, vp]),
     'csmri_loss': (i32, [i32, i32, vp, i32, vp, i32, i64, i32, vp, vp, vp]),
     'csmri_loss_work_bytes': (sz, []),
     'csmri_loss_multi_work_bytes': (sz, [i32]),

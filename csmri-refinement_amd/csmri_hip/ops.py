@@ -269,9 +269,10 @@ class PackGroup(object):
       self.refresh_biases()
 
   def refresh_biases(self):
-    """One multi-tensor copy of every member's bias into its zero-padded fp32 buffer."""
+    """One multi-tensor copy of every stale member bias into its zero-padded fp32 buffer (the fallback: a re-pack
+    launch carries the biases along, see ensure_table)."""
     members = [l for l in self.layers if l.bias is not None and l._bias_pad is not None and
-               l._bias_pad[1].device == l.bias.device]
+               l._bias_pad[1].device == l.bias.device and l._bias_pad[0] != _weight_epoch(l)]
     if not members:
       return False
     torch._foreach_copy_([l._bias_pad[1][:l.cout] for l in members],
@@ -280,22 +281,38 @@ class PackGroup(object):
       l._bias_pad = (_weight_epoch(l), l._bias_pad[1])
     return True
 
+  @staticmethod
+  def _has_bias_pad(l):
+    return l.bias is not None and l._bias_pad is not None and l._bias_pad[1].device == l.bias.device
+
   def ensure_table(self, mode):
     """The device-side item table of ``mode``'s multi-layer re-pack (built by a host-to-device copy: must exist
-    before a stream capture that re-packs).  Returns (table, n) or None when no member owns a pack of that mode."""
+    before a stream capture that re-packs).  Returns ((sig, table, n, bias_layers), members) or None when no member
+    owns a pack of that mode.  The item of a layer whose LOWEST pack mode this is also carries its bias refresh, and
+    the table of the group's lowest mode gets one bias-only item per layer that has a bias buffer but no pack at all:
+    after an optimizer step the re-pack launches are the only ones the weights need (the biases used to cost a
+    multi-tensor copy launch of their own, 25 us for the U-Net's)."""
     members = [l for l in self.layers if mode in l._packs]
     if not members:
       return None
-    sig = tuple((id(l), l.weight.data_ptr(), l._packs[mode][1].data_ptr()) for l in members)
+    carried = [l for l in members if self._has_bias_pad(l) and min(l._packs) == mode]
+    bias_only = []
+    if mode == min(self.modes()):
+      bias_only = [l for l in self.layers if not l._packs and self._has_bias_pad(l)]
+    sig = tuple((id(l), l.weight.data_ptr(), l._packs[mode][1].data_ptr()) for l in members) + \
+        tuple((id(l), l.bias.data_ptr(), l._bias_pad[1].data_ptr()) for l in carried + bias_only)
     tab = self._tables.get(mode)
     if tab is None or tab[0] != sig:
-      arr = (lib.PackItem * len(members))()
-      for it, l in zip(arr, members):
-        it.w, it.out = l.weight.data_ptr(), l._packs[mode][1].data_ptr()
-        it.mode, it.dtype = mode, (BF16 if l.dtype == torch.bfloat16 else F32)
+      arr = (lib.PackItem * (len(members) + len(bias_only)))()
+      for it, l in zip(arr, members + bias_only):
+        it.mode, it.dtype = -1, (BF16 if l.dtype == torch.bfloat16 else F32)
+        if l in members:
+          it.w, it.out, it.mode = l.weight.data_ptr(), l._packs[mode][1].data_ptr(), mode
         it.Cout, it.Cin, it.KH, it.KW = l.cout, l.cin, l.kh, l.kw
+        if l in carried or l in bias_only:
+          it.bias, it.bias_out = l.bias.data_ptr(), l._bias_pad[1].data_ptr()
       host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-      tab = (sig, host.to(members[0].weight.device), len(members))
+      tab = (sig, host.to(members[0].weight.device), len(arr), carried + bias_only)
       self._tables[mode] = tab
     return tab, members
 
@@ -310,6 +327,8 @@ class PackGroup(object):
     for l in members:
       e = l._packs[mode]
       l._packs[mode] = (_weight_epoch(l),) + tuple(e[1:])
+    for l in tab[3]:
+      l._bias_pad = (_weight_epoch(l), l._bias_pad[1])
     return True
 
 
@@ -338,6 +357,21 @@ class _Timed(object):
       self.rec[3].record()
       PROFILE.append(self.rec)
     return False
+
+
+_SEEDS = {}
+
+
+def backward_scalar(total):
+  """``total.backward()`` with the seed gradient taken from a per-device constant instead of autograd's ones_like
+  (one fill launch per backward pass, 5-12 us on the step's critical chain)."""
+  if not total.is_cuda or total.dim() != 0:
+    return total.backward()
+  key = (total.device, total.dtype)
+  one = _SEEDS.get(key)
+  if one is None:
+    one = _SEEDS[key] = torch.ones((), dtype=total.dtype, device=total.device)
+  total.backward(gradient=one)
 
 
 def absmax(x):
@@ -757,13 +791,32 @@ def join_wgrad_stream():
   _WGRAD['pending'] = []
 
 
-def act_bwd(gz, z, slope):
+def act_bwd(gz, z, slope, gz2=None):
+  """dy = (gz + gz2) * lrelu'(z); ``gz2``: a second gradient of z (see _two_grads)."""
   gz, z = as_nhwc(gz), as_nhwc(z)
   b, h, w, c = z.shape
   out = torch.empty(b, h, w, c, dtype=z.dtype, device=z.device)
   lib.call('csmri_act_bwd', dt_of(z), gz.data_ptr(), gz.stride(2), z.data_ptr(), z.stride(2),
-           out.data_ptr(), out.stride(2), b * h * w, c, float(slope), stream())
+           out.data_ptr(), out.stride(2), b * h * w, c, float(slope), ptr(gz2),
+           gz2.stride(2) if gz2 is not None else 0, stream())
   return out
+
+
+def _two_grads(ctx, g_a, g_b, dtype):
+  """The gradients of the two aliases a ``tap`` replay node returned (either may be missing) as (g, g2) in the layer's
+  dtype: g2 is summed with g inside the first backward kernel (csmri_bn_bwd_* / csmri_act_bwd ``dz2``), not by an add
+  launch of its own -- on the generator step every discriminator feature has two consumers, the next layer and the
+  feature-matching loss, and that add sat on the critical chain of the backward six times."""
+  if g_a is None:
+    g_a, g_b = g_b, None
+  g_a = as_nhwc(g_a)
+  if g_a.dtype != dtype:
+    g_a = g_a.to(dtype)
+  if g_b is not None:
+    g_b = as_nhwc(g_b)
+    if g_b.dtype != dtype:
+      g_b = g_b.to(dtype)
+  return g_a, g_b
 
 
 class ConvAct(torch.autograd.Function):
@@ -782,13 +835,14 @@ class ConvAct(torch.autograd.Function):
     return y
 
   @staticmethod
-  def backward(ctx, gy):
+  def backward(ctx, gy, gy2=None):
     layer = ctx.layer
     x0, x1, y = ctx.saved_tensors
-    gy = as_nhwc(gy)
-    if gy.dtype != layer.dtype:
-      gy = gy.to(layer.dtype)
-    g = act_bwd(gy, y, ctx.act_slope) if ctx.act_slope != 1.0 else gy
+    gy, gy2 = _two_grads(ctx, gy, gy2, layer.dtype)
+    if ctx.act_slope != 1.0:
+      g = act_bwd(gy, y, ctx.act_slope, gy2)
+    else:
+      g = gy if gy2 is None else gy + gy2
     gx0 = gx1 = None                  # data gradient first, weight gradient second (see ConvBnAct._finish_backward)
     if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
       gx = conv_dgrad(layer, g, ctx.in_hw)
@@ -809,18 +863,42 @@ class ConvActReplay(torch.autograd.Function):
   rows.  ``w_req``: whether this sub-batch contributes weight gradients."""
 
   @staticmethod
-  def forward(ctx, x0, x1, weight, bias, layer, act_slope, y_holder, w_req):
+  def forward(ctx, x0, x1, weight, bias, layer, act_slope, y_holder, w_req, tap=False, nchw_out=0):
     y_rows = y_holder[0]               # (in a list: a tensor argument returned as it is would be aliased to the input)
     ctx.layer, ctx.act_slope = layer, act_slope
     ctx.c0 = x0.shape[3]
     ctx.in_hw = (x0.shape[1], x0.shape[2])
     ctx.save_for_backward(x0, x1, y_rows)
     ctx.w_req = bool(w_req) and weight.requires_grad
-    return y_rows
+    ctx.nchw_out = nchw_out
+    if nchw_out:
+      # the output in both of the forms it leaves the library in -- the device-layout rows and the fp32 NCHW API
+      # tensor of ``nchw_out`` channels (ToNCHW's result) --: the backward converts, sums and rounds the two
+      # gradients in one launch (csmri_nchw_to_nhwc_add) where ToNCHW's backward, autograd's add and a dtype cast
+      # were three
+      assert not tap and act_slope == 1.0
+      ctx.set_materialize_grads(False)
+      return y_rows[:], nhwc_to_nchw(y_rows, nchw_out)
+    if not tap:
+      return y_rows
+    # ``tap``: two aliases of the output, one per consumer, so that the backward receives their gradients
+    # separately (_two_grads) instead of autograd's sum
+    ctx.set_materialize_grads(False)
+    return y_rows[:], y_rows[:]
 
   @staticmethod
-  def backward(ctx, gy):
-    return ConvAct.backward(ctx, gy)[:4] + (None, None, None, None)
+  def backward(ctx, gy, gy2=None):
+    if ctx.nchw_out and gy2 is not None:
+      layer = ctx.layer
+      g_nchw = gy2.contiguous().float()
+      b, c, h, w = g_nchw.shape
+      cp = ctx.saved_tensors[2].shape[3]
+      add = as_nhwc(gy) if gy is not None else None
+      g = torch.empty(b, h, w, cp, dtype=layer.dtype, device=g_nchw.device)
+      lib.call('csmri_nchw_to_nhwc_add', g_nchw.data_ptr(), b, c, h, w, g.data_ptr(), dt_of(g), cp, cp, ptr(add),
+               dt_of(add) if add is not None else 0, add.stride(2) if add is not None else 0, stream())
+      gy, gy2 = g, None
+    return ConvAct.backward(ctx, gy, gy2)[:4] + (None,) * 6
 
 
 # RecNet conv blocks of the supported shape run as one launch (csmri_convblock_fused_fwd); tests turn it off for A/B
@@ -1150,14 +1228,13 @@ class ConvBnAct(torch.autograd.Function):
     return z
 
   @staticmethod
-  def backward(ctx, gz):
+  def backward(ctx, gz, gz2=None):
     layer, bn = ctx.layer, ctx.bn
     x0, x1, y, snap, mean, invstd, dropmask = ctx.saved_tensors
     if not ctx.training:
       raise RuntimeError('backward through eval-mode BatchNorm is not on the training path')
-    gz = as_nhwc(gz)
-    if gz.dtype != layer.dtype:
-      gz = gz.to(layer.dtype)
+    gz, gz2 = _two_grads(ctx, gz, gz2, layer.dtype)
+    gz2_ptr, gz2_ps = (gz2.data_ptr(), gz2.stride(2)) if gz2 is not None else (0, 0)
     b, h, w, cp = y.shape
     dev = y.device
     groups = ctx.groups
@@ -1179,13 +1256,15 @@ class ConvBnAct(torch.autograd.Function):
     partial = torch.empty(rows + groups, 2, cp, dtype=torch.float32, device=dev)
     lib.call('csmri_bn_bwd_reduce', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
              0, 0, b, h * w, cp, mean.data_ptr(), invstd.data_ptr(),
-             float(ctx.slope), ptr(dropmask), partial.data_ptr(), snap.data_ptr(), groups, stream())
+             float(ctx.slope), ptr(dropmask), partial.data_ptr(), snap.data_ptr(), groups, gz2_ptr, gz2_ps,
+             stream())
     lib.call('csmri_bn_bwd_apply', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),
              0, 0, gy.data_ptr(), gy.stride(2), b, h * w, cp, layer.cout,
              mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), float(ctx.slope), ptr(dropmask),
              partial.data_ptr(), rows,
              bn.weight.grad.data_ptr() if want_affine else 0,
-             bn.bias.grad.data_ptr() if want_affine else 0, acc_affine, snap.data_ptr(), groups, stream())
+             bn.bias.grad.data_ptr() if want_affine else 0, acc_affine, snap.data_ptr(), groups, gz2_ptr, gz2_ps,
+             stream())
     return ConvBnAct._finish_backward(ctx, gy, x0, x1, want_affine)
 
   @staticmethod
@@ -1219,18 +1298,21 @@ class ConvBnActReplay(torch.autograd.Function):
   training/adversarial_runner.py:332,338,354 are three module calls whose results do not depend on each other."""
 
   @staticmethod
-  def forward(ctx, x0, x1, weight, gamma, beta, layer, bn, slope, dropmask_rows, rec, n, lo, hi, w_req):
+  def forward(ctx, x0, x1, weight, gamma, beta, layer, bn, slope, dropmask_rows, rec, n, lo, hi, w_req, tap=False):
     y, z, mean, invstd, snap = rec
     ctx.layer, ctx.bn, ctx.slope, ctx.training, ctx.groups = layer, bn, slope, True, hi - lo
     ctx.c0 = x0.shape[3]
     ctx.in_hw = (x0.shape[1], x0.shape[2])
     ctx.save_for_backward(x0, x1, y[lo * n:hi * n], snap, mean[lo:hi], invstd[lo:hi], dropmask_rows)
     ctx.w_req = bool(w_req) and weight.requires_grad
-    return z[lo * n:hi * n]
+    if not tap:
+      return z[lo * n:hi * n]
+    ctx.set_materialize_grads(False)           # two aliases, one per consumer (see ConvActReplay)
+    return z[lo * n:hi * n], z[lo * n:hi * n]
 
   @staticmethod
-  def backward(ctx, gz):
-    return ConvBnAct.backward(ctx, gz)[:5] + (None,) * 9
+  def backward(ctx, gz, gz2=None):
+    return ConvBnAct.backward(ctx, gz, gz2)[:5] + (None,) * 10
 
 
 def maxpool2_fwd(x):
@@ -1589,7 +1671,11 @@ class RefineCombine(torch.autograd.Function):
   """RefinementWrapper 'real-penalty-add' tail (refinement_wrapper.py:169-194):
   pred = cat(unscale(scale(pre_real) + s*u), pre_imag).  pre: fp32 [B,H,W,2]
   (no grad), u: NHWC [B,H,W,8] channel 0, scale: fp32 [1].
-  Returns (pred [B,H,W,2] fp32, scaled [B,H,W] fp32)."""
+  Returns (pred [B,H,W,2] fp32, scaled [B,H,W] fp32, pred_b, u_b): pred_b is a second alias of pred and u_b an alias
+  of u, one per consumer (pred: the discriminator input and the VGG loss; u: this node and the feature penalty), so
+  that the backward receives those gradients separately and sums them inside its one kernel; the scale parameter's
+  gradient is written by that launch as well (lazy-zero protocol of FlatAdam, like the weight-gradient kernels).
+  Four torch launches of the generator backward's head -- two adds, a zero fill, an accumulate -- are gone."""
 
   @staticmethod
   def forward(ctx, pre, u, scale):
@@ -1602,21 +1688,43 @@ class RefineCombine(torch.autograd.Function):
     lib.call('csmri_refine_combine', pre.data_ptr(), u.data_ptr(), dt_of(u), u.stride(2),
              scale.data_ptr(), mm.data_ptr(), b, h * w, pred.data_ptr(), scaled.data_ptr(), stream())
     ctx.save_for_backward(u, scale, mm)
+    ctx.scale_param = scale
     ctx.mark_non_differentiable(scaled)
-    return pred, scaled
+    ctx.set_materialize_grads(False)
+    return pred, scaled, pred[:], u[:]
 
   @staticmethod
-  def backward(ctx, gpred, gscaled):
+  def backward(ctx, gpred, gscaled, gpred_b, gu_b):
     u, scale, mm = ctx.saved_tensors
     b, h, w, cp = u.shape
+    if gpred is None:
+      gpred, gpred_b = gpred_b, None
+    if gpred is None:                       # only the alias of u was used: its gradient passes through
+      return None, gu_b, None
     gpred = gpred.contiguous()
+    if gpred_b is not None:
+      gpred_b = gpred_b.contiguous()
+    if gu_b is not None:
+      gu_b = as_nhwc(gu_b)
+      if gu_b.dtype != u.dtype:
+        gu_b = gu_b.to(u.dtype)
     # (pad channels must be exact zeros: the kernel writes a pixel of 8 channels whole, wider ones are cleared here)
     du = (torch.empty if cp == 8 else torch.zeros)(b, h, w, cp, dtype=u.dtype, device=u.device)
     part = torch.empty(1026, dtype=torch.float32, device=u.device)
+    p = ctx.scale_param
+    direct = isinstance(p, torch.nn.Parameter) and p.requires_grad and ctx.needs_input_grad[2]
+    acc = 1
+    if direct:
+      if p.grad is None:
+        p.grad = torch.zeros_like(p)
+      p._kernel_grad = True
+      if getattr(p, '_grad_fresh', False):
+        acc, p._grad_fresh = 0, False
     lib.call('csmri_refine_combine_bwd', gpred.data_ptr(), u.data_ptr(), dt_of(u), u.stride(2),
              scale.data_ptr(), mm.data_ptr(), b, h * w, du.data_ptr(), dt_of(du), du.stride(2),
-             part.data_ptr(), stream())
-    return None, du, part[:1]
+             part.data_ptr(), ptr(gpred_b), ptr(gu_b), gu_b.stride(2) if gu_b is not None else 0,
+             p.grad.data_ptr() if direct else 0, acc, stream())
+    return None, du, (None if direct else part[:1])
 
 
 class MeanLoss(torch.autograd.Function):

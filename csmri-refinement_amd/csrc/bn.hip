@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dz, int 
                                                             const void* z, int zps, int npix, int HW, int C,
                                                             const float* mean, const float* invstd, float slope,
                                                             const float* drop, int rows, float* partial,
-                                                            const float* snap) {
+                                                            const float* snap, const void* dz2, int dz2ps) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
   // npix, rows: per group; blockIdx.y = group
   const int grp = blockIdx.y, pbase = grp * npix;
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dz, int 
   for (int pp = p0 + pl; pp < p1; pp += lanes) {
     const int p = pbase + pp;
     f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c), zz;
+    if (dz2) g += ld4<DT>(dz2, (long long)p * dz2ps + c);       // gradient fan-in of z: summed here in fp32
     if (RECOMP) zz = (yy - mu) * fsc + fbe; else zz = ld4<DT>(z, (long long)p * zps + c);
     f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
     if (drop) dm = *(const f32x4_t*)(drop + (size_t)(p / HW) * C + c);
@@ -233,12 +234,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dz, int 
 extern "C" int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride, const void* y, int y_pix_stride,
                                    const void* z, int z_pix_stride, int B, int HW, int C, const float* mean,
                                    const float* invstd, float slope, const float* dropmask, float* partial,
-                                   const float* affine_snap, int groups, void* stream) {
+                                   const float* affine_snap, int groups, const void* dz2, int dz2_pix_stride,
+                                   void* stream) {
   CSMRI_CHECK_ARG(dz && y && partial && (z || affine_snap) && groups >= 1 && B % groups == 0);
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
   const int npix = B / groups * HW, rows = csmri_bn_stats_rows(npix, C);
   hipStream_t st = (hipStream_t)stream;
-#define BN_RED(DT_, RC_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT_, RC_>), dim3(rows, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, npix, HW, C, mean, invstd, slope, dropmask, rows, partial, affine_snap)
+#define BN_RED(DT_, RC_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<DT_, RC_>), dim3(rows, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, npix, HW, C, mean, invstd, slope, dropmask, rows, partial, affine_snap, dz2, dz2_pix_stride)
   if (dtype == CSMRI_BF16) { if (z) BN_RED(CSMRI_BF16, false); else BN_RED(CSMRI_BF16, true); }
   else { if (z) BN_RED(CSMRI_F32, false); else BN_RED(CSMRI_F32, true); }
 #undef BN_RED
@@ -282,7 +284,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
                                                            const float* __restrict__ gamma, float slope,
                                                            const float* __restrict__ drop,
                                                            const float* __restrict__ totals, float inv_count,
-                                                           const float* __restrict__ snap, int totals_R) {
+                                                           const float* __restrict__ snap, int totals_R,
+                                                           const void* __restrict__ dz2, int dz2ps) {
   const int nv = C >> 2, lanes = 256 / nv, cv = threadIdx.x % nv, pl = threadIdx.x / nv, c = cv * 4;
   // npix: per group; blockIdx.y = group
   const int grp = blockIdx.y, pbase = grp * npix;
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
   for (int pp = q0 + pl; pp < q1; pp += lanes) {
     const int p = pbase + pp;
     f32x4_t g = ld4<DT>(dz, (long long)p * dzps + c), yy = ld4<DT>(y, (long long)p * yps + c), zz, o;
+    if (dz2) g += ld4<DT>(dz2, (long long)p * dz2ps + c);
     if (RECOMP) zz = (yy - mu) * fsc + fbe; else zz = ld4<DT>(z, (long long)p * zps + c);
     f32x4_t dm = (f32x4_t){1.f, 1.f, 1.f, 1.f};
     if (drop) dm = *(const f32x4_t*)(drop + (size_t)(p / HW) * C + c);
@@ -319,7 +323,7 @@ extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, 
                                   int C, int C_real, const float* mean, const float* invstd, const float* gamma,
                                   float slope, const float* dropmask, const float* partial, int rows,
                                   float* dgamma, float* dbeta, int accumulate, const float* affine_snap,
-                                  int groups, void* stream) {
+                                  int groups, const void* dz2, int dz2_pix_stride, void* stream) {
   CSMRI_CHECK_ARG(dz && y && (z || affine_snap) && dy && partial && rows > 0 && groups >= 1 &&
                   rows % groups == 0 && B % groups == 0);
   if (!bn_channels_ok(C)) return CSMRI_E_UNSUPPORTED;
@@ -334,7 +338,7 @@ extern "C" int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, 
   const float* totals = partial + rows;                // [2][C][rows + groups]: totals follow each channel's rows
   const int totals_R = rows + groups;
   const float inv = 1.0f / ((float)B * (float)HW);
-#define BN_APP(DT_, RC_) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT_, RC_>), dim3(blocks, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv, affine_snap, totals_R)
+#define BN_APP(DT_, RC_) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT_, RC_>), dim3(blocks, groups), dim3(256), 0, st, dz, dz_pix_stride, y, y_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, HW, C, C_real, mean, invstd, gamma, slope, dropmask, totals, inv, affine_snap, totals_R, dz2, dz2_pix_stride)
   if (dtype == CSMRI_BF16) { if (z) BN_APP(CSMRI_BF16, false); else BN_APP(CSMRI_BF16, true); }
   else { if (z) BN_APP(CSMRI_F32, false); else BN_APP(CSMRI_F32, true); }
 #undef BN_APP

@@ -29,6 +29,19 @@ __global__ void nchw_to_nhwc_kernel(const float* src, int B, int C, long long HW
     store_elem(dst, pix * ps + c, dt, v);
   }
 }
+// dst = pad(src) + add: the gradient of a tensor handed out both as NCHW fp32 (API layout) and as NHWC (device layout)
+__global__ void nchw_to_nhwc_add_kernel(const float* src, int B, int C, long long HW, void* dst, int dt, int ps,
+                                        int Cpad, const void* add, int adt, int aps) {
+  const long long total = (long long)B * HW * Cpad;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % Cpad);
+    const long long pix = i / Cpad;
+    const long long b = pix / HW, r = pix - b * HW;
+    float v = c < C ? src[(b * C + c) * HW + r] : 0.f;
+    if (add) v += load_elem(add, pix * aps + c, adt);
+    store_elem(dst, pix * ps + c, dt, v);
+  }
+}
 __global__ void nhwc_to_nchw_kernel(const void* src, int dt, int ps, int B, int C, long long HW,
                                     float* dst) {
   const long long total = (long long)B * C * HW;
@@ -118,6 +131,16 @@ extern "C" int csmri_nchw_to_nhwc(const float* src, int B, int C, int H, int W, 
   }
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                      src, B, C, (long long)H * W, dst, dst_dtype, dst_pix_stride, Cpad);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+extern "C" int csmri_nchw_to_nhwc_add(const float* src, int B, int C, int H, int W, void* dst, int dst_dtype,
+                                      int dst_pix_stride, int Cpad, const void* add, int add_dtype,
+                                      int add_pix_stride, void* stream) {
+  CSMRI_CHECK_ARG(src && dst && Cpad >= C && dst_pix_stride >= Cpad && (!add || add_pix_stride >= Cpad));
+  const long long total = (long long)B * H * W * Cpad;
+  hipLaunchKernelGGL(nchw_to_nhwc_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, B, C,
+                     (long long)H * W, dst, dst_dtype, dst_pix_stride, Cpad, add, add_dtype, add_pix_stride);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
@@ -214,6 +237,9 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const csmri_pack
   __shared__ float tile[16][65];
   const csmri_pack_item it = items[blockIdx.y];
   const float* __restrict__ it_w = it.w;
+  if (blockIdx.x == 0 && it.bias)        // the layer's bias into its zero-padded fp32 buffer, same launch
+    for (int c = threadIdx.x; c < it.Cout; c += 256) it.bias_out[c] = it.bias[c];
+  if (it.mode < 0) return;               // bias-only item
   const PackGeom g = pack_geom(it.mode, it.Cout, it.Cin, it.KH, it.KW);
   const int T = it.KH * it.KW, KW = it.KW, KH = it.KH;
   const bool swapped = it.mode != 0;
@@ -308,23 +334,25 @@ extern "C" int csmri_pack_weight(int mode, int dtype, const float* w_ref, int Co
 }
 
 __global__ void act_bwd_kernel(int dt, const void* dz, int dzps, const void* z, int zps, void* dy,
-                               int dyps, long long npix, int C, float slope) {
+                               int dyps, long long npix, int C, float slope, const void* dz2, int dz2ps) {
   const int nv = C >> 2;
   GRID_STRIDE32(i, npix * nv) {
     const int c = (int)(i % nv) * 4;
     const unsigned p = i / nv;
     f32x4_t g = load4(dz, (long long)p * dzps + c, dt), zz = load4(z, (long long)p * zps + c, dt);
+    if (dz2) g += load4(dz2, (long long)p * dz2ps + c, dt);    // gradient fan-in of z: summed here in fp32
     for (int q = 0; q < 4; ++q) g[q] = zz[q] > 0.f ? g[q] : g[q] * slope;
     store4(dy, (long long)p * dyps + c, dt, g);
   }
 }
 extern "C" int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const void* z,
                              int z_pix_stride, void* dy, int dy_pix_stride, long long npix, int C,
-                             float slope, void* stream) {
+                             float slope, const void* dz2, int dz2_pix_stride, void* stream) {
   CSMRI_CHECK_ARG(dz && z && dy && C % 4 == 0);
   CSMRI_CHECK_I32(npix * C);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                     dtype, dz, dz_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, C, slope);
+                     dtype, dz, dz_pix_stride, z, z_pix_stride, dy, dy_pix_stride, npix, C, slope, dz2,
+                     dz2_pix_stride);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

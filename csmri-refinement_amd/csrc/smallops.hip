@@ -168,16 +168,18 @@ extern "C" int csmri_refine_combine(const float* pre, const void* u, int u_dtype
 // element 0 receives the total (second stage in the same launch via last-block-free 2 kernels).
 __global__ __launch_bounds__(256) void refine_combine_bwd_kernel(
     const float2* gpred, const void* u, int udt, int ups, const float* sp, const float* mm, int B,
-    long long HW, void* du, int dudt, int dups, float* partial) {
+    long long HW, void* du, int dudt, int dups, float* partial, const float2* gpred2, const void* du2, int du2ps) {
   const float s = sp[0];
   double acc = 0.0;
   GRID_STRIDE(i, (long long)B * HW) {
     const int b = (int)(i / HW);
     const float half_mx = mm[2 * b + 1] * 0.5f;
-    const float g = gpred[i].x;
+    float g = gpred[i].x;
+    if (gpred2) g += gpred2[i].x;              // pred has two consumers (discriminator input, VGG loss)
     const float uv = load_elem(u, i * ups, udt);
     // a pixel of exactly 8 channels is written whole (the value + 7 zero pad channels): the caller need not clear du
-    const float dv = g * s * half_mx;
+    float dv = g * s * half_mx;
+    if (du2) dv += load_elem(du2, i * du2ps, dudt);   // u's second consumer (the feature penalty on the raw refinement)
     if (dups == 8 && dudt == CSMRI_BF16) ((u32x4_t*)du)[i] = (u32x4_t){(unsigned)f32_to_bf16_bits(dv), 0u, 0u, 0u};
     else if (dups == 8) { ((f32x4_t*)du)[2 * i] = (f32x4_t){dv, 0.f, 0.f, 0.f}; ((f32x4_t*)du)[2 * i + 1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     else store_elem(du, i * dups, dudt, dv);
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void refine_combine_bwd_kernel(
   double tot = block_sum(acc);
   if (threadIdx.x == 0) partial[1 + blockIdx.x] = (float)tot;
 }
-__global__ __launch_bounds__(256) void sum_partials_kernel(float* partial, int n) {
+__global__ __launch_bounds__(256) void sum_partials_kernel(float* partial, int n, float* total, int accumulate) {
   // one workgroup, fixed-order strided sums + tree: deterministic
   __shared__ double sh[256];
   double t = 0;
@@ -194,21 +196,25 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(float* partial, int n
   sh[threadIdx.x] = t;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0) partial[0] = (float)sh[0];
+  if (threadIdx.x == 0) {
+    partial[0] = (float)sh[0];
+    if (total) total[0] = (accumulate ? total[0] : 0.f) + (float)sh[0];
+  }
 }
 extern "C" int csmri_refine_combine_bwd(const float* gpred, const void* u, int u_dtype, int u_pix_stride,
                                         const float* scale_param, const float* minmax, int B,
                                         long long HW, void* du, int du_dtype, int du_pix_stride,
-                                        float* dscale_partial, void* stream) {
+                                        float* dscale_partial, const float* gpred2, const void* du2,
+                                        int du2_pix_stride, float* dscale, int accumulate, void* stream) {
   CSMRI_CHECK_ARG(gpred && u && scale_param && minmax && du && dscale_partial);
   if (du_pix_stride == 8 && ((uintptr_t)du & 15)) return CSMRI_E_ALIGN;
   const int blocks = grid_for((long long)B * HW);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(refine_combine_bwd_kernel, dim3(blocks), dim3(256), 0, st, (const float2*)gpred, u,
                      u_dtype, u_pix_stride, scale_param, minmax, B, HW, du, du_dtype, du_pix_stride,
-                     dscale_partial);
+                     dscale_partial, (const float2*)gpred2, du2, du2_pix_stride);
   CSMRI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, dscale_partial, blocks);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, dscale_partial, blocks, dscale, accumulate);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

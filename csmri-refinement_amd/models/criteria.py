@@ -61,7 +61,7 @@ def _get_vgg_criterion(conf, loss_name, cuda, target_key):
   vgg_loss = VGGLoss(loss_name, cuda, vconf.get('blocks', -1), vconf.get('criterion', 'MSE'),
                      vconf.get('weights'), seed=vconf.get('seed', 0),
                      weights_path=vconf.get('weights_path'), allow_random=vconf.get('allow_random'))
-  return CriterionWrapper(vgg_loss, target_key)
+  return CriterionWrapper(vgg_loss, target_key, tap='vgg')
 
 
 def _get_feature_penalty_criterion(conf, loss_name, cuda, target_key):
@@ -86,12 +86,13 @@ _CRITERIA = {
 _DIRECT = ('MSE', 'L1', 'SmoothL1Loss', 'CrossEntropy', 'NLLLoss')
 
 
-def _select(out_gen, key):
-  """(tensor, is_internal_nhwc): prefer the device-layout tensor the model provides."""
+def _select(out_gen, key, tap=None):
+  """(tensor, is_internal_nhwc): prefer the device-layout tensor the model provides -- and among those the alias
+  reserved for this consumer (``key@tap``) when the model hands one out."""
   if isinstance(out_gen, dict):
     fast = out_gen.get('_nhwc')
     if fast is not None and key in fast:
-      return fast[key], True
+      return fast.get('%s@%s' % (key, tap), fast[key]), True
     return out_gen[key], False
   return out_gen, False
 
@@ -100,12 +101,12 @@ _NHWC_REAL_CHANNELS = {'pred': 2, 'prescaled_refinement': 1}
 
 
 class CriterionWrapper(nn.Module):
-  def __init__(self, criterion, target_key='target', input_key='pred'):
+  def __init__(self, criterion, target_key='target', input_key='pred', tap=None):
     super(CriterionWrapper, self).__init__()
-    self.criterion, self.target_key, self.input_key = criterion, target_key, input_key
+    self.criterion, self.target_key, self.input_key, self.tap = criterion, target_key, input_key, tap
 
   def forward(self, out_gen, batch):
-    pred, nhwc = _select(out_gen, self.input_key)
+    pred, nhwc = _select(out_gen, self.input_key, self.tap)
     target = batch[self.target_key]
     if isinstance(self.criterion, _MeanCriterion):
       return self.criterion(pred, target, nhwc, _NHWC_REAL_CHANNELS.get(self.input_key))

@@ -222,20 +222,24 @@ class CNNDiscriminator(nn.Module):
           x_rows = x_rows()
         assert x_rows.shape[0] == (hi - lo) * n
         feats, chans, x = [], [], x_rows
+        # with features handed out every layer output has two consumers (the next layer, the feature-matching loss):
+        # the replay nodes return one alias for each and sum the two gradients inside their first backward kernel
+        tap = bool(self.compute_features)
         for (conv, bn, drop, f), (rec, mask) in zip(self._layers, recs):
           if bn is None:
             x = ops.ConvActReplay.apply(x, None, conv.weight, conv.bias, conv.layer, self.slope,
-                                        [rec[lo * n:hi * n]], wgrad)
+                                        [rec[lo * n:hi * n]], wgrad, tap)
           else:
             x = ops.ConvBnActReplay.apply(x, None, conv.weight, bn.weight, bn.bias, conv.layer,
                                           ops.BNState(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                                       bn.momentum),
                                           self.slope, mask[lo * n:hi * n] if mask is not None else None, rec, n, lo, hi,
-                                          wgrad)
-          feats.append(x)
+                                          wgrad, tap)
+          x, feat = x if tap else (x, x)
+          feats.append(feat)
           chans.append(f)
-        lg = ops.ConvActReplay.apply(x, None, fin.weight, fin.bias, fin.layer, 1.0, [lg_all[lo * n:hi * n]], wgrad)
-        logits = ops.ToNCHW.apply(lg, 1)
+        lg, logits = ops.ConvActReplay.apply(x, None, fin.weight, fin.bias, fin.layer, 1.0, [lg_all[lo * n:hi * n]],
+                                             wgrad, False, 1)
         out = {'prob': _Sigmoid.apply(logits), 'logits': logits}
         if self.compute_features:
           out['features'] = feats + [lg]

@@ -83,12 +83,15 @@ class RefinementWrapper(nn.Module):
     x = ops.ToNHWC.apply(pre, unet.dtype, 8)
     u = unet.forward_nhwc(x)                                      # [B,H,W,8], channel 0
     pre_c = ops.nchw_to_nhwc(pre.detach(), torch.float32, 2)      # interleaved complex
-    pred_c, scaled = ops.RefineCombine.apply(pre_c, u, self.scale)
+    pred_c, scaled, pred_c2, u2 = ops.RefineCombine.apply(pre_c, u, self.scale)
     return {
         'pred': ops.ToNCHW.apply(pred_c, 2),
         'pretrained': pre,
         'prescaled_refinement': ops.ToNCHW.apply(u, 1),
         'scaled_refinement': scaled.unsqueeze(1),
-        # internal device-layout views for the fused criteria (not part of the API)
-        '_nhwc': {'pred': pred_c, 'prescaled_refinement': u},
+        # internal device-layout views for the fused criteria (not part of the API).  'pred@vgg' and
+        # 'prescaled_refinement' are aliases with their own autograd edge into RefineCombine (models/criteria._select):
+        # the gradients of the prediction's two consumers and of the refinement's two are summed inside its backward
+        # kernel, not by add launches in front of it
+        '_nhwc': {'pred': pred_c, 'pred@vgg': pred_c2, 'prescaled_refinement': u2},
     }

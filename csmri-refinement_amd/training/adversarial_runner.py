@@ -258,7 +258,7 @@ class AdversarialRunner(BaseRunner):
     optimizer.zero_grad()
     ops.GRAD_READY_HOOK = self._grad_hook
     try:
-      total.backward()
+      ops.backward_scalar(total)
       ops.join_wgrad_stream()
     finally:
       ops.GRAD_READY_HOOK = None
@@ -365,7 +365,7 @@ class AdversarialRunner(BaseRunner):
     total_disc = self._weighted_total(disc_losses, self.disc_loss_weights)
     self.disc_optimizer.zero_grad()
     ops.enable_wgrad_stream(self.overlap_streams)
-    total_disc.backward()
+    ops.backward_scalar(total_disc)
     # (Joining D's weight-gradient stream only at D's Adam -- so that the look-ahead fork and the generator's losses
     # run next to the weight-gradient tail of D's backward -- measured 9 % slower on the bench and crashed the graph
     # replay of a small configuration inside the runtime: removed)
@@ -496,7 +496,7 @@ class AdversarialRunner(BaseRunner):
       self.disc_optimizer.apply()
     self.gen_optimizer.zero_grad()
     ops.enable_wgrad_stream(self.overlap_streams)
-    st['total_gen'].backward()
+    ops.backward_scalar(st['total_gen'])
     if ev_m is not None:
       self._fork_train_metrics(st, ev_m)
     ops.join_wgrad_stream()

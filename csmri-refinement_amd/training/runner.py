@@ -141,7 +141,7 @@ class Runner(BaseRunner):
     ops.enable_wgrad_stream(False)
     ops.GRAD_READY_HOOK = self._grad_hook
     try:
-      total.backward()
+      ops.backward_scalar(total)
       ops.join_wgrad_stream()
     finally:
       ops.GRAD_READY_HOOK = None

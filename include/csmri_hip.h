@@ -153,6 +153,8 @@ int csmri_pack_weight(int mode, int dtype, const float* w_ref, int Cout, int Cin
 typedef struct csmri_pack_item {
   const float* w; void* out;
   int mode, dtype, Cout, Cin, KH, KW;
+  const float* bias; float* bias_out;   /* optional: bias[0..Cout) copied to bias_out (the layer's zero-padded fp32
+                                           bias buffer) by the same launch; mode < 0 = bias only, w/out unused */
 } csmri_pack_item;
 int csmri_pack_weight_multi(const csmri_pack_item* items_dev, int n, void* stream);
 
@@ -341,6 +343,13 @@ int csmri_nchw_to_nhwc(const float* src, int B, int C, int H, int W, void* dst,
                        int dst_dtype, int dst_pix_stride, int Cpad, void* stream);
 int csmri_nhwc_to_nchw(const void* src, int src_dtype, int src_pix_stride, int B,
                        int C, int H, int W, float* dst, void* stream);
+/* dst[B,H,W,Cpad] (dst_dtype) = zero-padded NHWC form of src [B,C,H,W] fp32 + add (NULL, or NHWC of add_dtype with
+ * >= Cpad channels per pixel): the gradient of a tensor that left the library twice -- as the NCHW fp32 API tensor
+ * (the discriminator's `logits`, reference models/discriminators.py:236-247) and as its device-layout feature map --
+ * converted, summed and rounded to the conv's dtype in one launch. */
+int csmri_nchw_to_nhwc_add(const float* src, int B, int C, int H, int W, void* dst, int dst_dtype,
+                           int dst_pix_stride, int Cpad, const void* add, int add_dtype, int add_pix_stride,
+                           void* stream);
 /* mask [B,2,H,W] fp32 {0,1} -> uint8 [B,H,W] (bit-exact; returns E_ARG semantics
  * are checked on the host side of the binding) */
 int csmri_mask_to_u8(const float* mask_nchw, int B, int H, int W, uint8_t* dst, void* stream);
@@ -377,12 +386,16 @@ int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_
                  const float* dropmask, float* affine_snap, int groups, void* stream);
 /* backward, pass 1: partial sums of dyh = dz*mask*lrelu'(z) and dyh*xhat.
  * z may be NULL when affine_snap (from csmri_bn_act) is given: the activation sign is then
- * recomputed from y with the forward's own arithmetic, saving one tensor read. */
+ * recomputed from y with the forward's own arithmetic, saving one tensor read.
+ * dz2 (NULL or a second gradient of z, same dtype; both passes must get the same one): where z has
+ * two consumers (the next layer and a feature-matching loss, models/criteria.py of the reference via
+ * discriminators.py:118-126) the two gradients are summed in fp32 inside these passes instead of by a
+ * separate add launch. */
 int csmri_bn_bwd_reduce(int dtype, const void* dz, int dz_pix_stride, const void* y,
                         int y_pix_stride, const void* z, int z_pix_stride, int B, int HW,
                         int C, const float* mean, const float* invstd, float slope,
                         const float* dropmask, float* partial, const float* affine_snap,
-                        int groups, void* stream);
+                        int groups, const void* dz2, int dz2_pix_stride, void* stream);
 /* pass 2: finalize dgamma/dbeta (accumulated into fp32 grads if not NULL) and
  * write dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)).
  * partial: the rows of pass 1 plus `groups` extra rows that receive the totals. */
@@ -392,11 +405,12 @@ int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, const void*
                        const float* mean, const float* invstd, const float* gamma,
                        float slope, const float* dropmask, const float* partial, int rows,
                        float* dgamma, float* dbeta, int accumulate, const float* affine_snap,
-                       int groups, void* stream);
+                       int groups, const void* dz2, int dz2_pix_stride, void* stream);
 
-/* elementwise activation fwd/bwd with optional bias (used where no BN) */
+/* dy = (dz + dz2) * lrelu'(z)  (where no BN follows the conv); dz2: NULL or a second gradient of z */
 int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const void* z, int z_pix_stride,
-                  void* dy, int dy_pix_stride, long long npix, int C, float slope, void* stream);
+                  void* dy, int dy_pix_stride, long long npix, int C, float slope, const void* dz2,
+                  int dz2_pix_stride, void* stream);
 
 /* MaxPool2d(2,2) NHWC (models/unet.py:58, torchvision VGG19) */
 int csmri_maxpool2(int dtype, const void* x, int x_pix_stride, void* y, int y_pix_stride,
@@ -436,12 +450,18 @@ int csmri_minmax_real(const float* x, int B, long long HW, float* minmax, void* 
 int csmri_refine_combine(const float* pre, const void* u, int u_dtype, int u_pix_stride,
                          const float* scale_param, const float* minmax, int B, long long HW,
                          float* pred, float* scaled, void* stream);
-/* backward: du = gpred_real * s*max/2, dscale += sum gpred_real*u*max/2.  du_pix_stride == 8 (16-byte aligned du): the
- * pixel is written whole -- the value and seven zero pad channels --, wider pixels must be cleared by the caller. */
+/* backward: du = gpred_real * s*max/2, dscale_partial[0] = sum gpred_real*u*max/2.  du_pix_stride == 8 (16-byte aligned
+ * du): the pixel is written whole -- the value and seven zero pad channels --, wider pixels must be cleared by the caller.
+ * The gradient fan-ins around this node are summed here instead of by add launches (each NULL = absent):
+ *   gpred2  a second gradient of pred (its two consumers: the discriminator input and the VGG loss), added to gpred;
+ *   du2     a second gradient of u, du_dtype with pixel stride du2_pix_stride, channel 0 (the feature penalty on the
+ *           raw refinement, reference models/criteria.py feature_penalty), added to du;
+ *   dscale  the scale parameter's fp32 gradient: receives the sum (accumulate != 0: is added to). */
 int csmri_refine_combine_bwd(const float* gpred, const void* u, int u_dtype, int u_pix_stride,
                              const float* scale_param, const float* minmax, int B,
                              long long HW, void* du, int du_dtype, int du_pix_stride,
-                             float* dscale_partial, void* stream);
+                             float* dscale_partial, const float* gpred2, const void* du2,
+                             int du2_pix_stride, float* dscale, int accumulate, void* stream);
 
 /* deterministic two-stage reductions; result[0] = mean over n_real elements.
  * kind: 0 = L1 |a-b|, 1 = MSE (a-b)^2.  b == NULL means b = 0.

@@ -208,6 +208,65 @@ def test_conv_bn_act(hip, dtype, shape):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_replay_nodes_sum_two_gradients_in_kernel(hip, dtype):
+  """The ``tap`` form of ConvBnActReplay / ConvActReplay returns two aliases of the layer output (next layer,
+  feature-matching loss: reference models/discriminators.py:118-126 hands the same tensor to both) and sums their
+  gradients inside csmri_bn_bwd_* / csmri_act_bwd (``dz2``).  Against the untapped node fed autograd's own sum:
+  identical in fp32, within one bf16 rounding of the sum in bf16 (the fused form adds in fp32, autograd's add kernel
+  rounds the sum to bf16 first)."""
+  ops = hip.ops
+  g = torch.Generator().manual_seed(5)
+  b, cin, cout, h, w = 4, 16, 32, 24, 24
+  x = torch.randn(b, cin, h, w, generator=g)
+  wt = torch.randn(cout, cin, 4, 4, generator=g) / math.sqrt(cin * 16)
+  pads = O.same_padding(4, 2)
+  res = {}
+  for kind in ('bn', 'act'):
+    for tap in (False, True):
+      layer = ops.ConvLayer(torch.nn.Parameter(wt.clone().cuda()), torch.nn.Parameter(torch.zeros(cout).cuda())
+                            if kind == 'act' else None, 2, pads, 'reflection', dtype)
+      xd = to_dev_nhwc(x, dtype).requires_grad_(True)
+      if kind == 'bn':
+        bn = ops.BNState(torch.nn.Parameter(torch.ones(cout).cuda()), torch.nn.Parameter(torch.zeros(cout).cuda()),
+                         torch.zeros(cout).cuda(), torch.ones(cout).cuda())
+        with torch.no_grad():
+          rec = ops.ConvBnAct.run_forward(xd.detach(), None, layer, bn, 0.2, True, None, 1)
+        out = ops.ConvBnActReplay.apply(xd, None, layer.weight, bn.weight, bn.bias, layer, bn, 0.2, None, rec, b, 0, 1,
+                                        True, tap)
+      else:
+        with torch.no_grad():
+          y, _ = ops.conv_forward(layer, xd.detach(), None, True, 0.2, False, None)
+        out = ops.ConvActReplay.apply(xd, None, layer.weight, layer.bias, layer, 0.2, [y], True, tap)
+      za, zb = out if tap else (out, out)
+      assert za.data_ptr() == zb.data_ptr()
+      ga = torch.randn(za.shape, generator=torch.Generator().manual_seed(8)).to(dtype).cuda()
+      gb = torch.randn(za.shape, generator=torch.Generator().manual_seed(9)).to(dtype).cuda()
+      ((za.float() * ga.float()).sum() + (zb.float() * gb.float()).sum()).backward()
+      ops.join_wgrad_stream()
+      torch.cuda.synchronize()
+      res[kind, tap] = (xd.grad.float().cpu(), layer.weight.grad.float().cpu())
+    for i, name in enumerate(('dx', 'dw')):
+      a, r = res[kind, True][i], res[kind, False][i]
+      err = (a - r).abs().max().item() / r.abs().max().item()
+      print(kind, name, 'tap vs autograd sum: rel err', err)
+      assert err <= (1e-6 if dtype == torch.float32 else 1.2e-2), (kind, name, err)
+  # a tapped node whose second alias has no consumer
+  layer = ops.ConvLayer(torch.nn.Parameter(wt.clone().cuda()), torch.nn.Parameter(torch.zeros(cout).cuda()), 2, pads,
+                        'reflection', dtype)
+  xd = to_dev_nhwc(x, dtype).requires_grad_(True)
+  with torch.no_grad():
+    y, _ = ops.conv_forward(layer, xd.detach(), None, True, 0.2, False, None)
+  za, zb = ops.ConvActReplay.apply(xd, None, layer.weight, layer.bias, layer, 0.2, [y], True, True)
+  gb = torch.randn(za.shape, generator=torch.Generator().manual_seed(9)).to(dtype).cuda()
+  (zb.float() * gb.float()).sum().backward()
+  xd2 = to_dev_nhwc(x, dtype).requires_grad_(True)
+  z1 = ops.ConvActReplay.apply(xd2, None, layer.weight, layer.bias, layer, 0.2, [y], False)
+  (z1.float() * gb.float()).sum().backward()
+  torch.cuda.synchronize()
+  assert torch.equal(xd.grad, xd2.grad)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 def test_maxpool(hip, dtype):
   ops = hip.ops
   x = torch.randn(2, 16, 12, 20, generator=torch.Generator().manual_seed(2))
@@ -845,7 +904,8 @@ def test_small_ops(hip):
   pre_d = pre.permute(0, 2, 3, 1).contiguous().cuda()
   ud = to_dev_nhwc(u, torch.float32).requires_grad_(True)
   sd = scale.clone().cuda().requires_grad_(True)
-  pred, scaled = ops.RefineCombine.apply(pre_d, ud, sd)
+  pred, scaled, pred_b, u_b = ops.RefineCombine.apply(pre_d, ud, sd)
+  assert pred_b.data_ptr() == pred.data_ptr() and u_b.data_ptr() == ud.data_ptr()
   ur, sr = u.clone().requires_grad_(True), scale.clone().requires_grad_(True)
   rs, mn, mx = O.scale_minmax(pre[:, 0:1].contiguous())
   outr = O.unscale_minmax(rs + sr * ur, mn, mx)
@@ -856,6 +916,31 @@ def test_small_ops(hip):
   pred.backward(gp.permute(0, 2, 3, 1).contiguous().cuda())
   assert torch.allclose(from_dev_nhwc(ud.grad, 1), ur.grad, atol=1e-6, rtol=1e-5)
   assert torch.allclose(sd.grad.cpu(), sr.grad, atol=1e-4, rtol=1e-4)
+  # ... with every fan-in the node sums in its own kernel: two consumers of pred, a second consumer of u (the feature
+  # penalty), the scale parameter's gradient written by the launch (on top of what .grad holds)
+  sp = torch.nn.Parameter(scale.clone().cuda())
+  sp.grad = torch.full_like(sp, 0.25)
+  ud2 = to_dev_nhwc(u, torch.float32).requires_grad_(True)
+  pred, scaled, pred_b, u_b = ops.RefineCombine.apply(pre_d, ud2, sp)
+  gp2, gu2 = torch.randn(predr.shape, generator=g), torch.randn(u.shape, generator=g)
+  ur, sr = u.clone().requires_grad_(True), scale.clone().requires_grad_(True)
+  outr = O.unscale_minmax(rs + sr * ur, mn, mx)
+  predr = torch.cat((outr, pre[:, 1:2]), 1)
+  ((predr * (gp + gp2)).sum() + (ur * gu2).sum()).backward()
+  ((pred * gp.permute(0, 2, 3, 1).cuda()).sum() + (pred_b * gp2.permute(0, 2, 3, 1).cuda()).sum()
+   + (u_b * to_dev_nhwc(gu2, torch.float32)).sum()).backward()
+  assert torch.allclose(from_dev_nhwc(ud2.grad, 1), ur.grad, atol=1e-5, rtol=1e-5)
+  assert float(ud2.grad[..., 1:].abs().max()) == 0
+  assert torch.allclose(sp.grad.cpu() - 0.25, sr.grad, atol=1e-4, rtol=1e-4)
+  sp._grad_fresh = True            # FlatAdam's lazy zero: the first write overwrites
+  pred, scaled, pred_b, u_b = ops.RefineCombine.apply(pre_d, ud2, sp)
+  (pred_b * (gp + gp2).permute(0, 2, 3, 1).cuda()).sum().backward()
+  assert torch.allclose(sp.grad.cpu(), sr.grad, atol=1e-4, rtol=1e-4) and not sp._grad_fresh
+  # only the alias of u consumed
+  ud3 = to_dev_nhwc(u, torch.float32).requires_grad_(True)
+  u_b = ops.RefineCombine.apply(pre_d, ud3, sp)[3]
+  (u_b * 2.0).sum().backward()
+  assert float((ud3.grad - 2.0).abs().max()) == 0
   # complex abs (+ VGG normalisation) fwd/bwd
   xc = torch.randn(b, 2, h, w, generator=g)
   xd = xc.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)

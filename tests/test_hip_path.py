@@ -588,7 +588,8 @@ def test_three_group_disc_pass_equals_three_passes(env, dtype, size, small):
   ops.join_wgrad_stream()
   g1 = {k: p.grad.clone() for k, p in d1.named_parameters()}
   perturb(d1)
-  ((oc['logits'].reshape(n, -1).sum(1) * wc).sum() + 0.5 * oc['features'][2].float().sum()).backward()
+  ((oc['logits'].reshape(n, -1).sum(1) * wc).sum() + 0.5 * oc['features'][2].float().sum()
+   + 0.25 * oc['features'][0].float().sum() + 0.125 * oc['features'][-1].float().sum()).backward()
   ops.join_wgrad_stream()
 
   d2.injected_dropout = [m.clone() for m in masks]
@@ -611,7 +612,8 @@ def test_three_group_disc_pass_equals_three_passes(env, dtype, size, small):
   assert leaf.grad is None
   g2 = {k: p.grad.clone() for k, p in d2.named_parameters()}
   perturb(d2)
-  ((o_c['logits'].reshape(n, -1).sum(1) * wc).sum() + 0.5 * o_c['features'][2].float().sum()).backward()
+  ((o_c['logits'].reshape(n, -1).sum(1) * wc).sum() + 0.5 * o_c['features'][2].float().sum()
+   + 0.25 * o_c['features'][0].float().sum() + 0.125 * o_c['features'][-1].float().sum()).backward()
   ops.join_wgrad_stream()
   torch.cuda.synchronize()
   tol = 2e-5 if dtype == 'fp32' else 2e-2

@@ -17,10 +17,10 @@ for b, h, w, c in SHAPES:
     partial = torch.empty(rows + 1, 2, c, dtype=torch.float32, device='cuda')
     ops.lib.call('csmri_bn_bwd_reduce', ops.dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2), 0, 0,
                  b, h * w, c, mean.data_ptr(), invstd.data_ptr(), 0.2, 0, partial.data_ptr(), snap.data_ptr(), 1,
-                 ops.stream())
+                 0, 0, ops.stream())
     gy = torch.empty_like(y)
     ops.lib.call('csmri_bn_bwd_apply', ops.dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2), 0, 0,
                  gy.data_ptr(), gy.stride(2), b, h * w, c, c, mean.data_ptr(), invstd.data_ptr(),
-                 bn.weight.data_ptr(), 0.2, 0, partial.data_ptr(), rows, 0, 0, 1, snap.data_ptr(), 1, ops.stream())
+                 bn.weight.data_ptr(), 0.2, 0, partial.data_ptr(), rows, 0, 0, 1, snap.data_ptr(), 1, 0, 0, ops.stream())
   torch.cuda.synchronize()
   print('done', b, h, w, c, 'MB per tensor', b * h * w * c * 2 / 1e6)
