@@ -166,6 +166,11 @@ _SIGS = {
                                   vp, vp, vp, i32, vp, i32, vp]),
     'csmri_bn_bwd_apply': (i32, [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32,
                                  vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp]),
+    'csmri_bn_small_ok': (i32, [i32, i32, i32]),
+    'csmri_bn_small_fwd': (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, f32, f32, vp, vp, vp, vp,
+                                 vp, vp]),
+    'csmri_bn_small_bwd': (i32, [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, vp,
+                                 vp, vp, i32, vp]),
     'csmri_act_bwd': (i32, [i32, vp, i32, vp, i32, vp, i32, i64, i32, f32, vp, i32, vp]),
     'csmri_maxpool2': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     'csmri_maxpool2_bwd': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -295,9 +295,9 @@ class PackGroup(object):
     members = [l for l in self.layers if mode in l._packs]
     if not members:
       return None
-    carried = [l for l in members if self._has_bias_pad(l) and min(l._packs) == mode]
+    carried = [l for l in members if PACK_BIAS and self._has_bias_pad(l) and min(l._packs) == mode]
     bias_only = []
-    if mode == min(self.modes()):
+    if PACK_BIAS and mode == min(self.modes()):
       bias_only = [l for l in self.layers if not l._packs and self._has_bias_pad(l)]
     sig = tuple((id(l), l.weight.data_ptr(), l._packs[mode][1].data_ptr()) for l in members) + \
         tuple((id(l), l.bias.data_ptr(), l._bias_pad[1].data_ptr()) for l in carried + bias_only)
@@ -365,7 +365,7 @@ _SEEDS = {}
 def backward_scalar(total):
   """``total.backward()`` with the seed gradient taken from a per-device constant instead of autograd's ones_like
   (one fill launch per backward pass, 5-12 us on the step's critical chain)."""
-  if not total.is_cuda or total.dim() != 0:
+  if not SEED_CONST or not total.is_cuda or total.dim() != 0:
     return total.backward()
   key = (total.device, total.dtype)
   one = _SEEDS.get(key)
@@ -1163,9 +1163,29 @@ class BNState(object):
     self.eps, self.momentum = eps, momentum
 
 
+BN_SMALL = True       # small feature maps: one-launch BatchNorm forward / backward (tests turn it off for A/B)
+# A/B switches of the gradient fan-in fusions (tools/bench_toggle.py); all on in the product
+FANIN_TAPS = True     # grouped discriminator pass: replay nodes hand one alias per consumer, gradients summed in-kernel
+FANIN_REFINE = True   # RefineCombine: aliases for the prediction's / the refinement's second consumer
+FANIN_LOGITS = True   # final discriminator conv: NCHW + NHWC gradients converted and summed in one launch
+SEED_CONST = True     # backward seed gradient from a constant
+PACK_BIAS = True      # bias refresh inside the re-pack launch
+
+
 def _bn_forward(y, stats, bn, c_real, slope, training, dropmask, groups=1):
   b, h, w, cp = y.shape
   dev = y.device
+  if training and stats is None and BN_SMALL and lib.raw('csmri_bn_small_ok')(b * h * w, cp, groups):
+    # small map: statistics, finalize and normalise/activate in one launch
+    mean = torch.empty(1, cp, dtype=torch.float32, device=dev)
+    invstd = torch.empty(1, cp, dtype=torch.float32, device=dev)
+    snap = torch.empty(2, cp, dtype=torch.float32, device=dev)
+    z = torch.empty(b, h, w, cp, dtype=y.dtype, device=dev)
+    lib.call('csmri_bn_small_fwd', dt_of(y), y.data_ptr(), y.stride(2), z.data_ptr(), z.stride(2), b, h * w, cp,
+             c_real, bn.weight.data_ptr(), bn.bias.data_ptr(), float(slope), ptr(dropmask), bn.eps, bn.momentum,
+             mean.data_ptr(), invstd.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+             snap.data_ptr(), stream())
+    return z, mean, invstd, snap
   if training:
     if stats is None:
       rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups, cp)
@@ -1252,6 +1272,13 @@ class ConvBnAct(torch.autograd.Function):
       acc_affine = 0
       bn.weight._grad_fresh = False
       bn.bias._grad_fresh = False
+    if BN_SMALL and lib.raw('csmri_bn_small_ok')(b * h * w, cp, groups):
+      lib.call('csmri_bn_small_bwd', dt_of(y), gz.data_ptr(), gz.stride(2), gz2_ptr, gz2_ps, y.data_ptr(), y.stride(2),
+               gy.data_ptr(), gy.stride(2), b, h * w, cp, layer.cout, mean.data_ptr(), invstd.data_ptr(),
+               bn.weight.data_ptr(), float(ctx.slope), ptr(dropmask), snap.data_ptr(),
+               bn.weight.grad.data_ptr() if want_affine else 0, bn.bias.grad.data_ptr() if want_affine else 0,
+               acc_affine, stream())
+      return ConvBnAct._finish_backward(ctx, gy, x0, x1, want_affine)
     rows = groups * lib.raw('csmri_bn_stats_rows')(b * h * w // groups, cp)
     partial = torch.empty(rows + groups, 2, cp, dtype=torch.float32, device=dev)
     lib.call('csmri_bn_bwd_reduce', dt_of(y), gz.data_ptr(), gz.stride(2), y.data_ptr(), y.stride(2),

@@ -224,7 +224,7 @@ class CNNDiscriminator(nn.Module):
         feats, chans, x = [], [], x_rows
         # with features handed out every layer output has two consumers (the next layer, the feature-matching loss):
         # the replay nodes return one alias for each and sum the two gradients inside their first backward kernel
-        tap = bool(self.compute_features)
+        tap = bool(self.compute_features) and ops.FANIN_TAPS
         for (conv, bn, drop, f), (rec, mask) in zip(self._layers, recs):
           if bn is None:
             x = ops.ConvActReplay.apply(x, None, conv.weight, conv.bias, conv.layer, self.slope,
@@ -238,8 +238,12 @@ class CNNDiscriminator(nn.Module):
           x, feat = x if tap else (x, x)
           feats.append(feat)
           chans.append(f)
-        lg, logits = ops.ConvActReplay.apply(x, None, fin.weight, fin.bias, fin.layer, 1.0, [lg_all[lo * n:hi * n]],
-                                             wgrad, False, 1)
+        if ops.FANIN_LOGITS:
+          lg, logits = ops.ConvActReplay.apply(x, None, fin.weight, fin.bias, fin.layer, 1.0, [lg_all[lo * n:hi * n]],
+                                               wgrad, False, 1)
+        else:
+          lg = ops.ConvActReplay.apply(x, None, fin.weight, fin.bias, fin.layer, 1.0, [lg_all[lo * n:hi * n]], wgrad)
+          logits = ops.ToNCHW.apply(lg, 1)
         out = {'prob': _Sigmoid.apply(logits), 'logits': logits}
         if self.compute_features:
           out['features'] = feats + [lg]

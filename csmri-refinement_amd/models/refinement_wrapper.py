@@ -84,6 +84,8 @@ class RefinementWrapper(nn.Module):
     u = unet.forward_nhwc(x)                                      # [B,H,W,8], channel 0
     pre_c = ops.nchw_to_nhwc(pre.detach(), torch.float32, 2)      # interleaved complex
     pred_c, scaled, pred_c2, u2 = ops.RefineCombine.apply(pre_c, u, self.scale)
+    if not ops.FANIN_REFINE:
+      pred_c2, u2 = pred_c, u
     return {
         'pred': ops.ToNCHW.apply(pred_c, 2),
         'pretrained': pre,

@@ -379,7 +379,8 @@ int csmri_bn_finalize(const float* partial, int rows, int C, int C_real, long lo
                       float* running_mean, float* running_var, int groups, void* stream);
 /* z = dropmask[b,c] * lrelu( (y-mean)*invstd*gamma + beta ) ; dropmask NULL = 1.
  * eval mode: pass running stats as mean and 1/sqrt(var+eps) as invstd.
- * affine_snap (NULL or [2][C] fp32) receives gamma and beta as this forward used them. */
+ * affine_snap (NULL or [2][C] fp32) receives gamma and beta as this forward used them.
+ * z must not alias y (nor dy an input of the backward passes): E_ARG. */
 int csmri_bn_act(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride,
                  int B, int HW, int C, int C_real, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, float slope,
@@ -406,6 +407,22 @@ int csmri_bn_bwd_apply(int dtype, const void* dz, int dz_pix_stride, const void*
                        float slope, const float* dropmask, const float* partial, int rows,
                        float* dgamma, float* dbeta, int accumulate, const float* affine_snap,
                        int groups, const void* dz2, int dz2_pix_stride, void* stream);
+
+/* Small feature maps (one group, C a power of two >= 16, B*HW <= 512: csmri_bn_small_ok != 0 -- the discriminator's
+ * 8 x 8 x 1024 layers, reference models/discriminators.py:118-126, on an 8-image pass): the whole training-mode forward
+ * (csmri_bn_stats + csmri_bn_finalize + csmri_bn_act) resp. backward (csmri_bn_bwd_reduce + csmri_bn_bwd_apply with
+ * affine_snap) as ONE launch each; a workgroup owns 8 or 16 channels and all pixels, so the channel sums need no second
+ * stage.  Same arguments and results as the calls they replace (sums in a different, still fixed, order). */
+int csmri_bn_small_ok(int npix, int C, int groups);
+int csmri_bn_small_fwd(int dtype, const void* y, int y_pix_stride, void* z, int z_pix_stride, int B, int HW,
+                       int C, int C_real, const float* gamma, const float* beta, float slope,
+                       const float* dropmask, float eps, float momentum, float* mean, float* invstd,
+                       float* running_mean, float* running_var, float* affine_snap, void* stream);
+int csmri_bn_small_bwd(int dtype, const void* dz, int dz_pix_stride, const void* dz2, int dz2_pix_stride,
+                       const void* y, int y_pix_stride, void* dy, int dy_pix_stride, int B, int HW, int C,
+                       int C_real, const float* mean, const float* invstd, const float* gamma, float slope,
+                       const float* dropmask, const float* affine_snap, float* dgamma, float* dbeta,
+                       int accumulate, void* stream);
 
 /* dy = (dz + dz2) * lrelu'(z)  (where no BN follows the conv); dz2: NULL or a second gradient of z */
 int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const void* z, int z_pix_stride,

@@ -208,6 +208,50 @@ def test_conv_bn_act(hip, dtype, shape):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(8, 64, 1024, 16, 16), (8, 512, 512, 4, 4), (8, 32, 16, 16, 16), (2, 128, 256, 8, 8),
+                                   (3, 32, 64, 24, 24)],
+                         ids=['8x8x1024', '2x2x512', '8x8x16', '4x4x256', '12x12x64_b3'])
+def test_small_map_batchnorm_one_launch(hip, dtype, shape):
+  """csmri_bn_small_fwd / csmri_bn_small_bwd (one launch each for the inner U-Net layers, reference models/unet.py
+  :60-108) against the three-launch sequences they replace: output, saved statistics, running statistics, input /
+  weight / affine gradients.  fp32: agreement to summation-order rounding; bf16: within two roundings of the stored
+  tensors."""
+  ops = hip.ops
+  b, cin, cout, h, w = shape
+  g = torch.Generator().manual_seed(21)
+  x = torch.randn(b, cin, h, w, generator=g)
+  wt = torch.randn(cout, cin, 4, 4, generator=g) / math.sqrt(cin * 16)
+  gamma, beta = 1 + 0.1 * torch.randn(cout, generator=g), 0.1 * torch.randn(cout, generator=g)
+  keep = (torch.bernoulli(torch.full((b, ops.pad8(cout)), 0.5), generator=g) * 2.0).cuda()
+  gz = torch.randn(b, cout, h // 2, w // 2, generator=g)
+  assert ops.lib.raw('csmri_bn_small_ok')(b * (h // 2) * (w // 2), ops.pad8(cout), 1)
+  res = {}
+  for small in (True, False):
+    ops.BN_SMALL = small
+    log = ops.LAUNCH_LOG = []
+    try:
+      layer = ops.ConvLayer(torch.nn.Parameter(wt.clone().cuda()), None, 2, O.same_padding(4, 2), 'reflection', dtype)
+      bn = ops.BNState(torch.nn.Parameter(gamma.clone().cuda()), torch.nn.Parameter(beta.clone().cuda()),
+                       torch.zeros(cout).cuda(), torch.ones(cout).cuda())
+      xd = to_dev_nhwc(x, dtype).requires_grad_(True)
+      z = ops.ConvBnAct.apply(xd, None, layer.weight, bn.weight, bn.bias, layer, bn, 0.2, True, keep)
+      z.backward(to_dev_nhwc(gz, dtype))
+      ops.join_wgrad_stream()
+      torch.cuda.synchronize()
+    finally:
+      ops.BN_SMALL, ops.LAUNCH_LOG = True, None
+    res[small] = dict(z=from_dev_nhwc(z.detach(), cout), rm=bn.running_mean.cpu(), rv=bn.running_var.cpu(),
+                      dx=from_dev_nhwc(xd.grad, cin), dw=layer.weight.grad.cpu(), dg=bn.weight.grad.cpu(),
+                      db=bn.bias.grad.cpu())
+  tol = 2e-5 if dtype == torch.float32 else 2e-2
+  for k in res[True]:
+    a, r = res[True][k], res[False][k]
+    err = (a - r).abs().max().item() / max(r.abs().max().item(), 1e-6)
+    print(k, 'one launch vs three: rel err', err)
+    assert err <= tol, (k, err)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 def test_replay_nodes_sum_two_gradients_in_kernel(hip, dtype):
   """The ``tap`` form of ConvBnActReplay / ConvActReplay returns two aliases of the layer output (next layer,
   feature-matching loss: reference models/discriminators.py:118-126 hands the same tensor to both) and sums their

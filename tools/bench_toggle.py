@@ -1,0 +1,13 @@
+"""bench.py with A/B switches of csmri_hip.ops turned off: CSMRI_OFF=FANIN_TAPS,BN_SMALL python tools/bench_toggle.py [bench args]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from csmri_hip import ops  # noqa: E402
+
+for name in filter(None, os.environ.get('CSMRI_OFF', '').split(',')):
+  assert hasattr(ops, name), name
+  setattr(ops, name, False)
+bench.main()
