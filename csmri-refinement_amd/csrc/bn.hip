@@ -57,19 +57,6 @@ __device__ __forceinline__ f32x4_t ld4_real(const float* __restrict__ p, int c, 
   for (int q = 0; q < 4; ++q) r[q] = c + q < C_real ? p[c + q] : 0.f;
   return r;
 }
-// raw 4-channel load (no conversion: the conversions of a batch come after ALL its loads were issued)
-template <int DT> struct raw4 { typedef f32x4_t t; };
-template <> struct raw4<CSMRI_BF16> { typedef u32x2_t t; };
-template <int DT> __device__ __forceinline__ typename raw4<DT>::t ldraw(const void* p, long long idx) {
-  if constexpr (DT == CSMRI_F32) return *(const f32x4_t*)((const float*)p + idx);
-  else return *(const u32x2_t*)((const unsigned short*)p + idx);
-}
-template <int DT> __device__ __forceinline__ f32x4_t cvt4(typename raw4<DT>::t u) {
-  if constexpr (DT == CSMRI_F32) return u;
-  else return (f32x4_t){__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u),
-                        __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
-}
-
 // block-wide sum of two doubles (blockDim.x == 256); result valid in thread 0
 __device__ __forceinline__ void block_sum2(double& a, double& b) {
   __shared__ double sa[4], sb[4];

@@ -98,6 +98,19 @@ __device__ __forceinline__ void store4(void* p, long long idx, int dt, f32x4_t v
   }
 }
 
+// raw 4-channel load (no conversion: the conversions of a batch come after ALL its loads were issued)
+template <int DT> struct raw4 { typedef f32x4_t t; };
+template <> struct raw4<CSMRI_BF16> { typedef u32x2_t t; };
+template <int DT> __device__ __forceinline__ typename raw4<DT>::t ldraw(const void* p, long long idx) {
+  if constexpr (DT == CSMRI_F32) return *(const f32x4_t*)((const float*)p + idx);
+  else return *(const u32x2_t*)((const unsigned short*)p + idx);
+}
+template <int DT> __device__ __forceinline__ f32x4_t cvt4(typename raw4<DT>::t u) {
+  if constexpr (DT == CSMRI_F32) return u;
+  else return (f32x4_t){__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u),
+                        __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
+}
+
 __device__ __forceinline__ int reflect_idx(int u, int n) {
   // mirror without repeating the edge (nn.ReflectionPad2d); valid for |pad| < n
   u = u < 0 ? -u : u;

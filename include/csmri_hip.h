@@ -487,7 +487,8 @@ int csmri_loss(int kind, int dtype, const void* a, int a_pix_stride, const void*
                int b_pix_stride, long long npix, int C_real, float* result,
                float* work, void* stream);
 size_t csmri_loss_work_bytes(void);
-/* grad wrt a: g = coeff[0]*w * d/da ; written (or accumulated) into ga */
+/* grad wrt a: g = coeff[0]*w * d/da ; written (or accumulated) into ga.  ga must not alias a or b (E_ARG);
+ * npix * C / 4 < 2^31 (E_UNSUPPORTED). */
 int csmri_loss_bwd(int kind, int dtype, const void* a, int a_pix_stride, const void* b,
                    int b_pix_stride, long long npix, int C, int C_real, const float* coeff,
                    float weight, void* ga, int ga_pix_stride, int accumulate, void* stream);
