@@ -30,7 +30,7 @@ def _check_headline(d, steps, warmup):
   assert abs(d['value'] - 8 * steps / (d['ms_per_step'] * steps * 1e-3)) < 0.02 * d['value']
   # the metric includes the H2D of every batch (reference training/base_runner.py:29-41); the resident
   # A/B leg is reported beside it, never as `value`
-  assert 'H2D on a copy stream inside the timed region' in d['input']
+  assert 'H2D on copy streams inside the timed region' in d['input']
   ab = d['input_ab']
   assert abs(ab['host'] - d['value']) < 1e-6 * d['value'] + 0.02 and ab['resident'] > 0
   assert d['warmup_total_steps'] == d['warmup'] + d['settle_steps']
@@ -58,7 +58,7 @@ def test_bench_json_line_schema_with_other_configs():
   for o in others:
     for k in ('config', 'value', 'ms_per_step', 'dtype', 'roofline', 'roofline_hbm', 'input', 'input_ab'):
       assert k in o, k
-    assert 'H2D on a copy stream inside the timed region' in o['input']
+    assert 'H2D on copy streams inside the timed region' in o['input']
     assert o['dtype'] == 'bf16' and o['value'] > 0 and o['steps'] * o['ms_per_step'] >= 400.0    # ~0.5 s timed (the step count comes from the settle phase's rate)
     b = o['config']['per_gpu_batch']
     assert abs(o['value'] - b / (o['ms_per_step'] * 1e-3)) < 0.02 * o['value']
