@@ -39,6 +39,20 @@ template <int N> __device__ __forceinline__ void p2_vmwait() { asm volatile("s_w
 template <int... I, class F>
 __device__ __forceinline__ void p2_unroll(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
+#ifdef CSMRI_DBG_STAMPS
+#define P2_STAMP(i) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    ph[i] += t_ - last_t; last_t = t_; } while (0)
+#define P2_STAMP_DECL unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_t; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_t) :: "memory")
+#define P2_STAMP_DUMP do { if (lane == 0 && p.slab) { unsigned long long* dbg_ = (unsigned long long*)p.slab + ((size_t)blockIdx.x * 12 + wv) * 8; \
+    for (int i_ = 0; i_ < 8; ++i_) dbg_[i_] = ph[i_]; } } while (0)
+#else
+#define P2_STAMP(i) do {} while (0)
+#define P2_STAMP_DECL do {} while (0)
+#define P2_STAMP_DUMP do {} while (0)
+#endif
+
 template <int TH, int TW, int BN>
 __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
   constexpr int NT = TH * TW, TPW = 16 + TW - 1, TPH = 16 + TH - 1, NPIX = TPH * TPW;
@@ -144,6 +158,7 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
     p2_vmwait<2 * WP>();                               // patch 0 and stage 0 (older than stages 1, 2)
     __builtin_amdgcn_s_barrier();
     int s = 0;
+    P2_STAMP_DECL;
     for (int q = 0; q < n_chunks; ++q) {
       const bool patch_here = q + 1 < n_chunks;
       p2_unroll(std::make_integer_sequence<int, NT>{}, [&](auto tc) {
@@ -156,18 +171,24 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
             if constexpr (t == PTAPS - 1) patch_done();
           }
         }
+        P2_STAMP(0);
         __builtin_amdgcn_s_barrier();
+        P2_STAMP(1);
         // ---- second half: retire stage s+1 (read from the next first half on).  Younger in issue order: the patch
         // pieces of step s-2, all of steps s-1 and s (WP weight pieces each + that tap's patch pieces)
         constexpr int pp = (t - 2 >= 0 && t - 2 < PTAPS ? PPT : 0) + (t - 1 >= 0 && t - 1 < PTAPS ? PPT : 0) + (t < PTAPS ? PPT : 0);
         if (s + 3 >= S) p2_vmwait<0>();
         else if (patch_here) p2_vmwait<2 * WP + pp>();
         else p2_vmwait<2 * WP>();
+        P2_STAMP(2);
         __builtin_amdgcn_s_barrier();
+        P2_STAMP(3);
+        P2_STAMP(4);
         ++s;
       });
     }
     __builtin_amdgcn_s_barrier();
+    P2_STAMP_DUMP;
     return;
   }
 
@@ -217,6 +238,7 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
   if (wn) __builtin_amdgcn_s_barrier();               // channel half 1: half a step behind
   int c_cc = 0, c_tile = worker;
   unsigned r_ring = 0;
+  P2_STAMP_DECL;
   for (int q = 0; q < n_chunks; ++q) {
     const unsigned pa = abase + (q & 1) * PBUF;
     p2_unroll(std::make_integer_sequence<int, NT>{}, [&](auto tc) {
@@ -243,7 +265,9 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]),
                        "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]));
+      P2_STAMP(0);
       __builtin_amdgcn_s_barrier();
+      P2_STAMP(1);
       // ======== multiply half ========
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -255,13 +279,18 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[kc][i]),
                                                                 __builtin_bit_cast(bf16x8_t, a[kc][f]), acc[i][f], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      P2_STAMP(2);
       if constexpr (t == NT - 1) {
         if (++c_cc == ncc) { c_cc = 0; epilogue(c_tile); c_tile += workers; }
       }
+      P2_STAMP(3);
       __builtin_amdgcn_s_barrier();
+      P2_STAMP(4);
+      P2_STAMP(5);                                     // (nothing in between: the cost of a stamp)
     });
   }
   if (!wn) __builtin_amdgcn_s_barrier();
+  P2_STAMP_DUMP;
 }
 
 // ---------------------------------------------------------------------------------------------

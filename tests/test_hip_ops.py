@@ -913,6 +913,29 @@ def test_convblock_fused_split_images(hip):
     assert rel_l2(gs[i], gp[i]) < 1e-1, (lab, rel_l2(gs[i], gp[i]))
 
 
+def test_nchw_gradient_to_nhwc_with_addend(hip):
+  """csmri_nchw_to_nhwc_add: pad(NCHW fp32) + NHWC addend, rounded once to the output dtype -- the gradient of a tensor
+  handed out as an NCHW API tensor AND as a device-layout feature map (the discriminator's logits, reference
+  models/discriminators.py:236-247).  Bit-exact against torch on the same operands."""
+  ops = hip.ops
+  lib = ops.lib
+  g = torch.Generator().manual_seed(3)
+  for b, c, h, w, cp in ((8, 1, 5, 5, 8), (3, 2, 7, 9, 8), (2, 5, 4, 4, 16)):
+    src = torch.randn(b, c, h, w, generator=g).cuda()
+    for odt in (torch.float32, torch.bfloat16):
+      for adt in (None, torch.float32, torch.bfloat16):
+        add = None if adt is None else torch.randn(b, h, w, cp, generator=g).to(adt).cuda()
+        out = torch.full((b, h, w, cp), 7.0, dtype=odt).cuda()
+        lib.call('csmri_nchw_to_nhwc_add', src.data_ptr(), b, c, h, w, out.data_ptr(), ops.dt_of(out), cp, cp,
+                 ops.ptr(add), ops.dt_of(add) if add is not None else 0, cp if add is not None else 0, ops.stream())
+        ref = torch.zeros(b, h, w, cp, device='cuda')
+        ref[..., :c] = src.permute(0, 2, 3, 1)
+        if add is not None:
+          ref = ref + add.float()
+        assert torch.equal(out, ref.to(odt)), (b, c, odt, adt)
+  assert lib.raw('csmri_nchw_to_nhwc_add')(src.data_ptr(), 1, 5, 2, 2, out.data_ptr(), 0, 4, 4, 0, 0, 0, 0) < 0   # Cpad < C
+
+
 def test_layout_roundtrip(hip):
   ops = hip.ops
   x = torch.randn(2, 3, 8, 12)
