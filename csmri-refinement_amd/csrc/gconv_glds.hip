@@ -346,12 +346,19 @@ static int launch_glds(const GParams& p, hipStream_t st) {
   return CSMRI_OK;
 }
 
-// LDS stages by grid size: one buffer when >= 3 workgroups per CU overlap each other, two when at
-// most two are resident, a 4-deep ring for grids of at most half a workgroup per CU (re-measured after
+// LDS stages by grid size: one buffer when 1.25+ workgroups per CU overlap each other, two below that, a 4-deep ring for grids of at most half a workgroup per CU (re-measured after
 // the two-buffer loop was tuned: it now beats the ring on 129..256-workgroup grids, e.g. 36 vs 41 us on
 // the U-Net 128 -> 128 4x4 layer)
+#ifndef GLDS_ST4_MAX
+#define GLDS_ST4_MAX 128
+#endif
+// (two buffers up to 320 workgroups: same-box A/B of the bench step, slices/s resident, two boxes -- 256: -0.4 %,
+// 320: +0.4 / +0.5 %, 384: +0.4 %, 512 (rounds 2-4): reference, 1024: -0.7 %; ring of four up to 64 or 256: -0.3 %)
+#ifndef GLDS_ST2_MAX
+#define GLDS_ST2_MAX 320
+#endif
 static int glds_stages(long long blocks) {
-  return blocks <= 128 ? 4 : (blocks <= 512 ? 2 : 1);
+  return blocks <= GLDS_ST4_MAX ? 4 : (blocks <= GLDS_ST2_MAX ? 2 : 1);
 }
 
 int gconv_glds_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {

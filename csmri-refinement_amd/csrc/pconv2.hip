@@ -308,6 +308,13 @@ static void p2_grid(const csmri_gconv_desc* d, int* ntile, int* nb, int* workers
   *workers = (*ntile + rounds - 1) / rounds;
 }
 
+// Smallest grid (tile blocks) that takes this kernel.  Alone, layers with less than a full chip of blocks lose to
+// gconv_glds with split-K (half-empty chip, one workgroup per CU); INSIDE the step the VGG branch runs beside the
+// discriminator's kernels and the idle CUs are not idle: same-box A/B of the bench step (slices/s resident) 256 -> 128
+// +1.1 %, -> 64 +1.9 %, -> 32 +1.9 %, 512 -2 % (tools/ab_old_new.sh, profiles/r04_same_box_ab.json)
+#ifndef P2_MIN_BLOCKS
+#define P2_MIN_BLOCKS 64
+#endif
 int pconv2_eligible(const csmri_gconv_desc* d) {
   if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
   if (d->nclass > 1 || d->splitk > 1 || d->upsample || d->in1 || d->stats_partial) return 0;
@@ -323,7 +330,7 @@ int pconv2_eligible(const csmri_gconv_desc* d) {
   if ((long long)d->Cout * d->TH * d->TW * d->Cin * 2 >= (1ll << 31)) return 0;
   int ntile, nb, workers;
   p2_grid(d, &ntile, &nb, &workers);
-  return (long long)ntile * nb >= 256;
+  return (long long)ntile * nb >= P2_MIN_BLOCKS;
 }
 
 int pconv2_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
