@@ -276,6 +276,12 @@ extern "C" size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d) {
   return (size_t)nclass * d->splitk * desc_M(d) * d->Cout * sizeof(float);
 }
 
+#ifndef SK_T1
+#define SK_T1 512
+#endif
+#ifndef SK_T2
+#define SK_T2 768
+#endif
 extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   { csmri_gconv_desc t = *d; t.splitk = 1;
     if (thin_out1_eligible(&t) || tconv_eligible(&t) || pconv2_eligible(&t)) return 1; }
@@ -294,7 +300,7 @@ extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   // (tools/sk_sweep.sh); at 32 steps (U-Net 128 -> 128 4x4) the same split loses 2x
   const bool deep = tiles <= 256 && nsteps >= 64 && !d->out_halo && nclass == 1;
   if (tiles >= 224 && !deep) return 1;
-  const int target = deep ? 512 : tiles >= 192 ? 768 : 512;
+  const int target = deep ? SK_T1 : tiles >= 192 ? SK_T2 : SK_T1;
   int sk = (int)((target + tiles - 1) / tiles);
   int maxsk = nsteps / 8; if (maxsk < 1) maxsk = 1;
   if (sk > maxsk) sk = maxsk;

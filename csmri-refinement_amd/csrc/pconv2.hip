@@ -1,6 +1,6 @@
 // pconv2: patch-structured convolution (tconv.hip's idea carried to many channels) as a persistent, role-split, fully
-// pipelined kernel -- stride-1 3 x 3 layers with Cin % 64 == 0 and Cout % 128 == 0 on a full chip of tile blocks (VGG19
-// conv2_1 .. conv4_4 at batch 16 and most of their data gradients at batch 8).  It replaced round 2's pconv (128 input
+// pipelined kernel -- stride-1 3 x 3 layers with Cin % 64 == 0 and Cout % 128 == 0 from 64 tile blocks on (VGG19
+// conv2_1 .. conv5_4 at batch 16 and their data gradients at batch 8; see P2_MIN_BLOCKS).  It replaced round 2's pconv (128 input
 // channels) and gconv_glds256 (256 x 256 tiles), which no benchmarked layer reached any more.
 //
 // Why: the 128 x 128 implicit-GEMM tile of gconv_glds.hip moves 32 KiB from L2 into LDS per 2.1 MFLOP (64 FLOP/B); at

@@ -252,6 +252,9 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
 
 // ---------------------------------------------------------------------------------------------
 static int tc_npix(const csmri_gconv_desc* d) { return (15 * d->in_s + d->TH) * (15 * d->in_s + d->TW); }
+#ifndef TCONV_MIN_HW
+#define TCONV_MIN_HW (64 * 64)
+#endif
 int tconv_eligible(const csmri_gconv_desc* d) {
   if (d->dtype != CSMRI_BF16 || d->dy_step != 1 || d->dx_step != 1) return 0;
   // stride 2: the discriminator's first layer (one real input channel padded to 8; reference models/discriminators.py:137-150)
@@ -261,7 +264,7 @@ int tconv_eligible(const csmri_gconv_desc* d) {
   const int tpc = d->Cin >= 32 ? 1 : 32 / d->Cin;
   if (d->TW % tpc) return 0;
   if (d->out_sy != 1 || d->out_sx != 1) return 0;
-  if ((long long)d->Ho * d->Wo < 64 * 64) return 0;            // small maps: generic / split-K path
+  if ((long long)d->Ho * d->Wo < TCONV_MIN_HW) return 0;        // small maps: generic / split-K path
   const size_t lds = (size_t)(d->Cin / 8) * ((tc_npix(d) + 63) / 64) * 1024;
   if (lds > 96 * 1024) return 0;
   return 1;

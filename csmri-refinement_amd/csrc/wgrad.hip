@@ -867,9 +867,12 @@ static bool wpatch_eligible(const csmri_wgrad_desc* d) {
   const long long tiles = (long long)d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16);
   return tiles >= 512;                                           // large maps only
 }
+#ifndef WPATCH_GROUPS
+#define WPATCH_GROUPS 512
+#endif
 static int wpatch_groups(const csmri_wgrad_desc* d) {
   const long long tiles = (long long)d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16);
-  long long g = 512;                                             // persistent workgroups
+  long long g = WPATCH_GROUPS;                                   // persistent workgroups
   if (g > tiles / 4) g = tiles / 4;                              // at least 4 tiles per workgroup
   // every workgroup leaves a slab of Cout x NK floats: keep the slab traffic below the operands' own bytes
   const long long slab = (long long)d->Cout * d->KH * d->KW * d->Cin * 4;
@@ -1043,6 +1046,9 @@ static WConfig pick_wconfig(const csmri_wgrad_desc* d) {
 }
 static int wgrad_ps(int dtype) { return dtype == CSMRI_BF16 ? 64 : 16; }
 
+#ifndef WSK_TARGET
+#define WSK_TARGET 512
+#endif
 extern "C" int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d) {
   if (wthin_out_eligible(d)) return wthin_splits(d);
   if (wpatch_eligible(d)) return wpatch_groups(d);
@@ -1050,7 +1056,7 @@ extern "C" int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d) {
   const long long NK = (long long)d->KH * d->KW * d->Cin;
   const long long tiles = (long long)cdiv(NK, c.BP) * cdiv(d->Cout, c.BQ);
   const int nsteps = cdiv((long long)d->B * d->Ho * d->Wo, wgrad_ps(d->dtype));
-  const int target = 512;
+  const int target = WSK_TARGET;
   int sk = (int)((target + tiles - 1) / tiles);
   int maxsk = nsteps / 4; if (maxsk < 1) maxsk = 1;
   if (sk > maxsk) sk = maxsk;
