@@ -300,10 +300,13 @@ static int p2_plane(const csmri_gconv_desc* d) {
 }
 
 static int p2_bn(const csmri_gconv_desc* d) { (void)d; return 128; }
+#ifndef P2_CUS
+#define P2_CUS 256
+#endif
 static void p2_grid(const csmri_gconv_desc* d, int* ntile, int* nb, int* workers) {
   *ntile = d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16);
   *nb = d->Cout / p2_bn(d);
-  int maxw = 256 / *nb; if (maxw < 1) maxw = 1;
+  int maxw = P2_CUS / *nb; if (maxw < 1) maxw = 1;
   const int rounds = (*ntile + maxw - 1) / maxw;
   *workers = (*ntile + rounds - 1) / rounds;
 }

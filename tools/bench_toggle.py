@@ -10,4 +10,10 @@ from csmri_hip import ops  # noqa: E402
 for name in filter(None, os.environ.get('CSMRI_OFF', '').split(',')):
   assert hasattr(ops, name), name
   setattr(ops, name, False)
+# CSMRI_RUNNER="vgg_fork_late=1,other=0": class attributes of the adversarial runner (its A/B switches)
+if os.environ.get('CSMRI_RUNNER'):
+  from training.adversarial_runner import AdversarialRunner
+  for kv in os.environ['CSMRI_RUNNER'].split(','):
+    k, v = kv.split('=')
+    setattr(AdversarialRunner, k, type(getattr(AdversarialRunner, k, 0))(int(v)) if hasattr(AdversarialRunner, k) else int(v))
 bench.main()
