@@ -73,7 +73,8 @@ def parse():
   p.add_argument('--device-resident', action='store_true',
                  help='A/B: batches resident in HBM when the timed region starts (default: pinned host batches, '
                       'H2D on a copy stream INSIDE the timed region, as SURVEY 8d defines the metric)')
-  p.add_argument('--copy-streams', type=int, default=2, help='HIP streams the H2D copies of a batch are spread over')
+  p.add_argument('--copy-streams', type=int, default=0,
+                 help='HIP streams the H2D copies of a batch are spread over (0 = by batch size: one, two from 64 MB on)')
   p.add_argument('--no-input-ab', action='store_true',
                  help='skip the second timed pass (batches resident in HBM) that fills `input_ab`')
   p.add_argument('--settle-s', type=float, default=0.6,
@@ -443,7 +444,12 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
                     for i in range(N_HOST_BATCHES)]
   dev = torch.device('cuda', torch.cuda.current_device())
   resident = bool(args.device_resident)
-  PinnedHostLoader.COPY_STREAMS = args.copy_streams
+  batch_bytes = sum(v.numel() * v.element_size() for v in host_batches[0].values())
+  # one hipMemcpyAsync stream is served by one SDMA engine: the 134 MB C2 batch needs two to fit under the step
+  # (8,000 -> 12,000 slices/s); the 17 MB C3 batch is done long before the step ends, and a second stream only
+  # adds interference (same box, host-batch leg: 1 stream 1500-1515 slices/s, 2 streams 1408-1479, 3 streams 1445;
+  # resident 1520)
+  PinnedHostLoader.COPY_STREAMS = args.copy_streams if args.copy_streams > 0 else (2 if batch_bytes >= (64 << 20) else 1)
 
   def loader_factory(n, resident=resident):
     return PinnedHostLoader(host_batches, n, dev, resident=resident)
@@ -574,7 +580,7 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
                   {'host': round(slices / dt, 2), 'resident': round(slices / dt_resident, 2), 'unit': 'slices/s',
                    'note': 'value = host (H2D of every batch inside the timed region); resident = the same K steps '
                            'timed again with the batches already in HBM'},
-      'host_numa': dict(NUMA_INFO) or None,
+      'host_numa': dict(NUMA_INFO) or None, 'copy_streams': None if resident else PinnedHostLoader.COPY_STREAMS,
       'timed_region_s': round(dt, 3), 'settle_steps': settle_steps,
       'prefetch': 'frozen RecNet forward of batch t+1 on a side stream during step t' if prefetch_on else None,
       'launch_mode': mode,
