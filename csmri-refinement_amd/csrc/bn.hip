@@ -6,10 +6,13 @@
 #include "common.h"
 
 #define BN_MAX_ROWS 2048
+#ifndef BN_EPB
+#define BN_EPB 16384      // elements per workgroup (same-box A/B of the step: 8192 / 32768, profiles/r04_same_box_ab.json)
+#endif
 // workgroups (= partial rows) for a [npix][C] tensor: about 16K elements each, at least one pixel per
 // pixel lane of the 256-thread workgroup, so that wide-channel / few-pixel maps still fill the chip
 extern "C" int csmri_bn_stats_rows(int npix, int C) {
-  int ppb = 16384 / (C > 0 ? C : 1);
+  int ppb = BN_EPB / (C > 0 ? C : 1);
   const int lanes = C >= 4 ? 1024 / C : 256;
   if (ppb < lanes) ppb = lanes;
   if (ppb < 1) ppb = 1;

@@ -374,10 +374,13 @@ static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
   return CSMRI_OK;
 }
 
+#ifndef GRED_MAX_BLOCKS
+#define GRED_MAX_BLOCKS 4096
+#endif
 static int launch_reduce(const GParams& p, hipStream_t st) {
   long long total = (long long)p.M * (p.Cout / 4) * p.nclass;
   if (total * 4 >= (1ll << 31)) return CSMRI_E_UNSUPPORTED;
-  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  int blocks = (int)((total + 255) / 256); if (blocks > GRED_MAX_BLOCKS) blocks = GRED_MAX_BLOCKS;
   hipLaunchKernelGGL(gconv_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
