@@ -264,7 +264,11 @@ static GConfig pick_config(const csmri_gconv_desc* d) {
 
 static int desc_M(const csmri_gconv_desc* d) { return d->B * d->Ho * d->Wo; }
 
-extern "C" int csmri_gconv_stats_rows(const csmri_gconv_desc* d) {
+extern "C" int csmri_gconv_stats_rows(const csmri_gconv_desc* d0) {
+  csmri_gconv_desc t = *d0;                          // (asked before the caller has allocated the rows: dispatch as the launch will)
+  if (!t.stats_partial) t.stats_partial = (float*)16;
+  const csmri_gconv_desc* d = &t;
+  if (uconv_eligible(d)) return uconv_stats_rows(d);
   if (tconv_eligible(d)) return tconv_stats_rows(d);
   GConfig c = pick_config(d);
   return cdiv(desc_M(d), c.BM) * c.WM;
@@ -284,7 +288,7 @@ extern "C" size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d) {
 #endif
 extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   { csmri_gconv_desc t = *d; t.splitk = 1;
-    if (thin_out1_eligible(&t) || tconv_eligible(&t) || pconv2_eligible(&t)) return 1; }
+    if (thin_out1_eligible(&t) || tconv_eligible(&t) || pconv2_eligible(&t) || uconv_eligible(&t)) return 1; }
   GConfig c = pick_config(d);
   if (gconv_glds_eligible(d)) { c.BM = 128; c.BN = gconv_glds_bn(d); }
   if (d->dtype == CSMRI_FP8) { c.BM = 128; c.BN = gconv_fp8_bn(d); c.KC = 1; }
@@ -392,6 +396,7 @@ extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int
   if (d->dtype == CSMRI_FP8) { gconv_fp8_kernel_name(d, buf, n); return CSMRI_OK; }
   if (thin_out1_eligible(d)) { thin_kernel_name(d, buf, n); return CSMRI_OK; }
   if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3, 128>"); return CSMRI_OK; }
+  if (uconv_eligible(d)) { uconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (gconv_glds_eligible(d)) { gconv_glds_kernel_name(d, buf, n); return CSMRI_OK; }
   GConfig c = pick_config(d);
@@ -423,6 +428,7 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
   }
   if (thin_out1_eligible(d)) return thin_out1_launch(p, d, st);
   if (pconv2_eligible(d)) return pconv2_launch(p, d, st);
+  if (uconv_eligible(d)) return uconv_launch(p, d, st);
   if (tconv_eligible(d)) return tconv_launch(p, d, st);
   if (gconv_glds_eligible(d)) {
     rc = gconv_glds_launch(p, d, st);

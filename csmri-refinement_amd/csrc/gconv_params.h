@@ -19,6 +19,7 @@ struct GParams {
   int dense_out;              // output position index == m (no window / stride / offset / classes): no division at all
   int off32;                  // every input / output byte offset fits 32 bits
   const float* dq0; const float* dq1;   // fp8 operands: device scalars whose product dequantises the accumulators
+  int us_n, us_x, us_y;                 // uconv: strips in all, strips per row of strips, rows of strips per image
 };
 
 // where output position (b, ty, tx) of the tensor goes: window -> dense `out`, else halo buffer
@@ -51,6 +52,12 @@ int tconv_eligible(const csmri_gconv_desc* d);
 int tconv_stats_rows(const csmri_gconv_desc* d);
 int tconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 void tconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
+
+// uconv.hip
+int uconv_eligible(const csmri_gconv_desc* d);
+int uconv_stats_rows(const csmri_gconv_desc* d);
+int uconv_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
+void uconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
 
 // pconv2.hip
 int pconv2_eligible(const csmri_gconv_desc* d);
