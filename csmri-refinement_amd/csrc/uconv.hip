@@ -7,9 +7,9 @@
 // Structure
 //   * One workgroup of 8 waves per CU, persistent.  Waves 0..3 multiply, waves 4..7 only move data (an LDS-DMA piece
 //     costs its issuing wave 60-185 cycles: MI355X_MICROARCH.md cycle constants).
-//   * Work unit = a STRIP of 8 output rows x 16 output columns x NF*16 output channels, one per compute wave; a PASS =
-//     4 strips.  Strips are independent (each has its own input patch in LDS), so ragged extents (the 259 x 259 /
-//     131 x 131 outputs of the reflection-padded data gradients) cost 8-row, not 16- or 32-row, granularity.
+//   * A PASS = one output tile of 16 rows x 32 columns x NF*16 channels; compute wave (sr, sc) owns the STRIP of 8 rows x
+//     16 columns at (8 sr, 16 sc).  The tile's input patch ((16+TH-1) x (32+TW-1) pixels, one 32-channel chunk = 64 B per
+//     pixel) is staged ONCE per chunk and shared by the four waves.
 //   * K order inside a pass: 32-channel chunk (outer), filter COLUMN tx, then the rows of the strip's patch.  For one
 //     (chunk, tx) "iteration" a wave holds the TH x NF weight fragments of that filter column in registers and slides
 //     down the patch: the fragment of patch row R (16 pixels x 32 channels, ONE ds_read_b128) feeds the MFMAs of output
@@ -17,16 +17,26 @@
 //     (ROWS*TH*NF) = 0.21 (4x4, NF=4), 0.30 (NF=2) against tconv's / pconv2's 0.5-0.75 -- the bound measured on pconv2.
 //     The weight registers are refilled IN PLACE for the next iteration: filter row ty is dead after patch row
 //     ROWS-1+ty and first needed again at patch row ty of the next iteration, 16-24 MFMAs later.
-//   * Weights stream through a ring of 3 stages (one stage = one iteration's TH x NF*16 x 32 block, 8-16 KiB); the
-//     patch of 32-channel chunk c of the next pass is loaded into the buffer chunk c of this pass has left (one chunk:
-//     two pass buffers).  ONE workgroup barrier per iteration = per 64-128 MFMAs of a wave (pconv2: two per 32).
+//   * Weights: one STAGE = one iteration's TH x NF*16 x 32 block (8-16 KiB).  Where all NCH*TW stages fit beside the two
+//     patch buffers they are loaded once per workgroup (RESIDENT: every instance but 64 -> 64 channels 4 x 4); otherwise
+//     they stream through a ring of 4 stages.  The patch of chunk c of the next pass goes into the buffer chunk c of this
+//     pass has left (one chunk: two pass buffers).  Barriers: RESIDENT two per chunk (buffer hand-over), else one per
+//     iteration = per 128 MFMAs of a wave (pconv2: two per 32).
 //   * Loaders wait with counted vmcnt; a buffer is read after the barrier behind the wait that retired it and refilled
 //     after the barrier behind its last read (cdna_hip_programming.md, "Read a staged buffer one phase AFTER ...").
-//   * Epilogue of output row r (bias, slope, activation-derivative gate, BatchNorm partial sums, bf16 store) is emitted
-//     between the MFMAs of the pass's last iteration, as soon as the row's last filter row has been added; the
-//     BatchNorm partial sums live in registers for the whole launch (one stats row per wave).
-// LDS images: patch = tconv's plane-major image per strip ([8-channel plane][pixel][16 B], PLANE % 256 == 0: conflict-
-// free ds_read_b128 at every tap shift); weights = mma_core.h's 64-byte rows, swizzled at the DMA source.
+//   * Epilogue of output row r (bias, slope, BatchNorm partial sums, bf16 store) sits between the MFMAs of the pass's
+//     last iteration, as soon as the row's last filter row has been added: straight-line code -- the outputs leave through
+//     buffer stores whose out-of-range offsets drop invalid lanes -- with fragment pairs exchanged between lane rows
+//     (v_permlane16_swap) so that a lane stores 16 B and a pixel 64 contiguous bytes per instruction.  The BatchNorm
+//     partial sums live in registers for the whole launch (one stats row per wave).
+// Why these choices (measured, profiles/r05_uconv_*): the first version (per-strip patches in tconv's plane-major image,
+// weights re-streamed every pass, gconv_out_pos + 8-byte stores) ran at 30-36 cycles per MFMA: its epilogue compiled into
+// vector loads of the kernel arguments and exec branches around every store (14,000 cycles per pass), its 64 x 16-byte
+// DMA pieces cost the loaders 160-700 cycles each, and the per-CU LDS-DMA intake (patch with a 1.7x halo + all weights
+// per pass = 14-21 B/clk of the ~30 B/clk a CU can take) kept the compute waves at the barriers.
+// LDS images: patch = pixel-major, 64 B per pixel, the four 16-byte slots XOR-swizzled by (pixel >> 1) & 3 at the DMA
+// source (conflict-free ds_read_b128 at every tap shift; an LDS-DMA piece is 16 pixels x 64 contiguous bytes); weights =
+// mma_core.h's 64-byte rows, swizzled at the DMA source.
 #include <utility>
 #include "mma_core.h"
 #include "gconv_params.h"
@@ -38,10 +48,12 @@ typedef __attribute__((address_space(3))) void* ul_t;
 #ifndef UCONV_ABLATE
 #define UCONV_ABLATE 0     // diagnostic builds only (tools/run/r05_ablate.sh): 1 no epilogue, 2 no DMA, 4 no LDS reads in the loop
 #endif
-#define U_ROWS 8
-#define U_PITCH 20         // pixels per patch row in LDS (16 + taps - 1 = 18 or 19 used)
-#define U_STRIPS 4
-#define U_RING 3
+#define U_ROWS 8           // output rows of a strip (one compute wave)
+#define U_TR 16            // tile = 2 x 2 strips
+#define U_TC 32
+#define U_PITCH 36         // pixels per patch row in LDS (32 + taps - 1 = 34 or 35 used; even: see the swizzle)
+#define U_NPC 44           // LDS-DMA pieces (16 pixels x 64 B) per patch buffer: 11 per loader wave
+#define U_LDS (160 * 1024)
 #define U_STATS 1
 #define U_BIAS 2
 #define U_GATE 4
@@ -79,21 +91,22 @@ __device__ __forceinline__ void u_lgkm(u32x4_t& f) { asm volatile("s_waitcnt lgk
 
 template <int TH, int TW, int NCH, int NF, int MODE>
 __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
-  constexpr int ROWS = U_ROWS, NR = ROWS + TH - 1, PITCH = U_PITCH, NPIX = NR * PITCH;
-  constexpr int NPC = (NPIX + 15) / 16;             // LDS-DMA pieces (16 pixels x 64 B) per strip and 32-channel chunk
-  constexpr int SBUF = NPC * 1024, PBUF = U_STRIPS * SBUF;
+  constexpr int ROWS = U_ROWS, NR = ROWS + TH - 1, PITCH = U_PITCH, NPC = U_NPC, PBUF = NPC * 1024;
   constexpr int WST = TH * NF * 1024, WOFF = 2 * PBUF;
   constexpr int NIT = NCH * TW;                     // iterations (chunk, tx) per pass
-  constexpr int WPI = TH * NF / 4;                  // weight pieces per loader and stage
-  constexpr int PPS0 = (NPC + 1) / 2, PPS1 = NPC - PPS0;   // patch pieces per loader in a phase's slots 0 and 1
-  constexpr bool STATS = (MODE & U_STATS) != 0, BIAS = (MODE & U_BIAS) != 0, GATE = (MODE & U_GATE) != 0, WIN = (MODE & U_WIN) != 0;
-  static_assert((TH * NF) % 4 == 0 && TW >= 3 && TH >= 3 && NCH >= 1 && NCH <= 2, "shape");
-  static_assert(16 + TW - 1 <= PITCH && 2 * PBUF + U_RING * WST <= 160 * 1024, "LDS");
+  constexpr int RFIT = (U_LDS - 2 * PBUF) / WST, RINGN = RFIT >= NIT ? NIT : 4;
+  constexpr bool RESIDENT = RINGN == NIT;
+  constexpr int WPI = TH * NF / 4, PPL = NPC / 4;   // weight pieces per loader and stage; patch pieces per loader and phase
+  // patch pieces a loader issues in slot j of a phase (streaming form; RESIDENT: all in slot 0)
+  constexpr int PP0 = RESIDENT ? PPL : (TW == 3 ? 6 : 4), PP1 = RESIDENT ? 0 : (TW == 3 ? 5 : 4), PP2 = PPL - PP0 - PP1;
+  constexpr bool STATS = (MODE & U_STATS) != 0, BIAS = (MODE & U_BIAS) != 0, WIN = (MODE & U_WIN) != 0;
+  static_assert((TH * NF) % 4 == 0 && (NF % 2) == 0 && TW >= 3 && TW <= 4 && TH >= 3 && NCH >= 1 && NCH <= 2, "shape");
+  static_assert((U_TR + TH - 1) * PITCH <= NPC * 16 && U_TC + TW - 1 <= PITCH && (PITCH % 4) == 0 && NPC % 4 == 0, "patch");
+  static_assert(2 * PBUF + RINGN * WST <= U_LDS && RINGN >= 3, "LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nstrips = p.us_n, SX = p.us_x, SY = p.us_y, NB = p.ntiles;
-  const int npass = (nstrips + U_STRIPS - 1) / U_STRIPS;
+  const int npass = p.us_n, TX = p.us_x, TY = p.us_y, NB = p.ntiles;
   // which output-channel block, which worker (pconv2's mapping: an XCD keeps ONE channel block's weights in its L2)
   int nblk, worker, workers;
   {
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
 
   if (wv >= 4) {
     // =================================================== loader waves ===================================================
-    const int L = wv - 4;                              // loader L moves strip L's patch and weight pieces j = L (mod 4)
+    const int L = wv - 4;                              // loader L moves patch pieces and weight pieces j = L (mod 4)
     const int wrow = lane >> 2;
     const int kc = (lane & 3) ^ tile_swz(wrow);        // (tile_swz depends on (row >> 2) & 3 only: the same for row + 16 pn)
     const char* wsrc = p.w + ((size_t)(n0 + wrow) * p.Kp + kc * 8) * 2;
@@ -126,26 +139,21 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
         if (!(UCONV_ABLATE & 2)) __builtin_amdgcn_global_load_lds((ug_t)src, (ul_t)(dst + 4096 * k), 16, 0, 0);
       }
       ++w_i;
-      w_ring = w_ring + WST == U_RING * WST ? 0u : w_ring + WST;
+      w_ring = w_ring + WST == RINGN * WST ? 0u : w_ring + WST;
       if (++w_tx == TW) { w_tx = 0; if (++w_c == NCH) w_c = 0; }
     };
     const int Hv = p.ups ? 2 * p.Hin : p.Hin, Wv = p.ups ? 2 * p.Win : p.Win;
-    // Patch image of a strip: pixel-major, 64 B (one 32-channel chunk) per pixel, pixel P = patch row * PITCH + column.  An
-    // LDS-DMA piece is 16 consecutive pixels x 64 B: every lane quad fetches ONE pixel's 64 contiguous bytes (16 segments
-    // of 64 B per instruction; the plane-major image of tconv / pconv2 fetches 64 segments of 16 B, and the loaders were
-    // issue-bound: 160-700 cycles per piece, profiles/r05_uconv_stamps.log).  The four 16-byte slots of a pixel are
-    // XOR-swizzled by (P >> 1) & 3 -- on the SOURCE side, the LDS-DMA destination is linear -- which makes the fragment reads
-    // (16 consecutive pixels per 16-lane group, slot = channel group) conflict-free at every tap shift.
-    int spix[NPC];
+    // piece j = L + 4 k covers pixels 16 j .. 16 j + 15 of the patch (pixel P = patch row * PITCH + column); a lane quad
+    // fetches ONE pixel's 64 contiguous bytes, slot s of the quad the channel group s ^ ((P >> 1) & 3)
+    int spix[PPL];
     const int lpix = lane >> 2, lplane = (lane & 3) ^ ((lane >> 3) & 3);   // (P >> 1) & 3 = (lane >> 3) & 3: 16 j is 0 mod 8
-    auto strip_pixels = [&](int pass) {                // pass = global pass index of this worker's next pass
-      const int sid = pass * U_STRIPS + L;
-      const bool sv = sid < nstrips;
-      const int sx = sid % SX, t_ = sid / SX, sy = t_ % SY, b = t_ / SY;
-      const int y0 = sy * ROWS + p.dy0, x0 = sx * 16 + p.dx0;
+    auto tile_pixels = [&](int pass) {                 // pass = global pass (= tile) index
+      const bool sv = pass < npass;
+      const int tx_ = pass % TX, t_ = pass / TX, ty_ = t_ % TY, b = t_ / TY;
+      const int y0 = ty_ * U_TR + p.dy0, x0 = tx_ * U_TC + p.dx0;
 #pragma unroll
-      for (int j = 0; j < NPC; ++j) {
-        const int P = j * 16 + lpix;
+      for (int k = 0; k < PPL; ++k) {
+        const int P = (L + 4 * k) * 16 + lpix;
         const int py = P / PITCH, px = P - py * PITCH;
         int u = y0 + py, w = x0 + px;
         if (p.border == CSMRI_BORDER_REFLECT) {
@@ -155,31 +163,32 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
         }
         const bool ok = sv & ((unsigned)u < (unsigned)Hv) & ((unsigned)w < (unsigned)Wv);
         if (p.ups) { u >>= 1; w >>= 1; }
-        spix[j] = ok ? (b * p.Hin + u) * p.Win + w : -1;
+        spix[k] = ok ? (b * p.Hin + u) * p.Win + w : -1;
       }
     };
     const char* zero_page = u_zero_page;
-    auto patch_slice = [&](auto hc, int c, int buf) {  // pieces [0, PPS0) or [PPS0, NPC) of chunk c into pass/chunk buffer `buf`
-      constexpr int h = decltype(hc)::value;
+    auto patch_pieces = [&](auto k0c, auto k1c, int c, int buf) {   // pieces k0 <= k < k1 of chunk c into buffer `buf`
+      constexpr int k0 = decltype(k0c)::value, k1 = decltype(k1c)::value;
       const int ch = c * 32;
       const bool second = ch >= p.c0;                  // wave-uniform (c0 % 32 == 0)
       const char* cb = (second ? p.in1 + (size_t)(ch - p.c0) * 2 : p.in0 + (size_t)ch * 2) + lplane * 16;
       const unsigned psb = (unsigned)(second ? p.ps1 : p.ps0) * 2u;
-      char* dbase = smem + buf * PBUF + L * SBUF;
+      char* dbase = smem + buf * PBUF + L * 1024;
 #pragma unroll
-      for (int j = h * PPS0; j < (h ? NPC : PPS0); ++j) {
-        const char* s = spix[j] >= 0 ? cb + (size_t)((unsigned)spix[j] * psb) : zero_page;
-        if (!(UCONV_ABLATE & 2)) __builtin_amdgcn_global_load_lds((ug_t)s, (ul_t)(dbase + j * 1024), 16, 0, 0);
+      for (int k = k0; k < k1; ++k) {
+        const char* s = spix[k] >= 0 ? cb + (size_t)((unsigned)spix[k] * psb) : zero_page;
+        if (!(UCONV_ABLATE & 2)) __builtin_amdgcn_global_load_lds((ug_t)s, (ul_t)(dbase + k * 4096), 16, 0, 0);
       }
     };
-    // prologue: patch of phase 0, stages 0..2
+#define U_IC(v_) std::integral_constant<int, (v_)>{}
+    // prologue: patch of phase 0, the first stages (RESIDENT: all of them)
     U_STAMP_DECL;
-    strip_pixels(worker);
-    patch_slice(std::integral_constant<int, 0>{}, 0, 0);
-    patch_slice(std::integral_constant<int, 1>{}, 0, 0);
-    issue_w(); issue_w(); issue_w();
+    tile_pixels(worker);
+    patch_pieces(U_IC(0), U_IC(PPL), 0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < RINGN; ++s_) issue_w();
     U_STAMP(0);                                        // prologue issue
-    u_vmwait<2 * WPI>();                               // patch 0 and stage 0
+    if constexpr (RESIDENT) u_vmwait<0>(); else u_vmwait<(RINGN - 1) * WPI>();   // patch 0 and stage 0
     U_STAMP(1);                                        // prologue landing
     __builtin_amdgcn_s_barrier();                      // B_init
     U_STAMP(2);
@@ -190,22 +199,42 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
       const int cn = NCH == 1 ? 0 : ((ph + 1) & 1);    // chunk of the next phase
       u_unroll(std::make_integer_sequence<int, TW>{}, [&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        // everything up to stage i+1 (and, in a phase's last slot, the next phase's patch) has landed
-        if (i + 3 >= NTOT) u_vmwait<0>();
-        else if (j == 0 || j == TW - 1 || !next_phase) u_vmwait<WPI>();
-        else if (j == 1) u_vmwait<PPS0 + WPI>();
-        else u_vmwait<PPS1 + WPI>();
-        U_STAMP(3);                                    // waiting for DMA
-        __builtin_amdgcn_s_barrier();                  // B_i
-        U_STAMP(4);                                    // waiting for the compute waves
-        if constexpr (j < 2) {
-          if (next_phase) {
-            if (j == 0 && cn == 0) strip_pixels(worker + ((ph + 1) / NCH) * workers);
-            patch_slice(std::integral_constant<int, j>{}, cn, (ph + 1) & 1);
+        if constexpr (RESIDENT) {
+          // two hand-overs per phase: after slot 0's barrier the other buffer is free; before the last slot's barrier the
+          // next phase's patch has landed
+          if constexpr (j == TW - 1) { u_vmwait<0>(); U_STAMP(3); __builtin_amdgcn_s_barrier(); U_STAMP(4); }
+          if constexpr (j == 0) {
+            U_STAMP(3);
+            __builtin_amdgcn_s_barrier();
+            U_STAMP(4);
+            if (next_phase) {
+              if (cn == 0) tile_pixels(worker + ((ph + 1) / NCH) * workers);
+              patch_pieces(U_IC(0), U_IC(PPL), cn, (ph + 1) & 1);
+            }
+            U_STAMP(5);
           }
+        } else {
+          // everything up to stage i+1 (and, in a phase's last slot, the next phase's patch) has landed.  Younger in issue
+          // order than stage i+1 (issued in slot i-3): all of slots i-2 and i-1 (patch pieces first, then the stage)
+          if (i + RINGN >= NTOT) u_vmwait<0>();
+          else if (j == TW - 1) u_vmwait<WPI>();
+          else if (j == 0) { if (ph == 0) u_vmwait<2 * WPI>(); else u_vmwait<PP2 + 2 * WPI>(); }
+          else if (j == 1) { if (next_phase) u_vmwait<PP0 + 2 * WPI>(); else u_vmwait<2 * WPI>(); }
+          else { if (next_phase) u_vmwait<PP0 + PP1 + 2 * WPI>(); else u_vmwait<2 * WPI>(); }
+          U_STAMP(3);                                  // waiting for DMA
+          __builtin_amdgcn_s_barrier();                // B_i
+          U_STAMP(4);                                  // waiting for the compute waves
+          if (next_phase) {
+            if constexpr (j == 0) {
+              if (cn == 0) tile_pixels(worker + ((ph + 1) / NCH) * workers);
+              patch_pieces(U_IC(0), U_IC(PP0), cn, (ph + 1) & 1);
+            }
+            if constexpr (j == 1) patch_pieces(U_IC(PP0), U_IC(PP0 + PP1), cn, (ph + 1) & 1);
+            if constexpr (j == 2 && PP2 > 0 && TW == 4) patch_pieces(U_IC(PP0 + PP1), U_IC(PPL), cn, (ph + 1) & 1);
+          }
+          if (w_i < NTOT) issue_w();
+          U_STAMP(5);                                  // issuing
         }
-        if (w_i < NTOT) issue_w();
-        U_STAMP(5);                                    // issuing
         ++i;
       });
     }
@@ -216,14 +245,16 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
   // ===================================================== compute waves =====================================================
   __builtin_amdgcn_s_setprio(2);
   const int r16 = lane & 15, g = lane >> 4;
+  const int sr = wv >> 1, sc = wv & 1;                 // this wave's strip of the tile
   const unsigned lds0 = (unsigned)(size_t)(ul_t)smem;
-  // fragment address of patch row 0 for filter column tx (pixel c = tx + r16, slot = channel group g ^ swizzle); patch row R
-  // adds R * PITCH * 64 (an immediate) and, for odd R, flips slot bit 1: (P >> 1) & 3 = (2 R + (c >> 1)) & 3
+  // fragment address of the strip's patch row 0 for filter column tx (pixel column c = 16 sc + tx + r16, slot = channel
+  // group g ^ swizzle); patch row R adds R * PITCH * 64 (an immediate) and, for odd R, flips slot bit 1:
+  // (P >> 1) & 3 = (2 R + (c >> 1)) & 3 for P = (8 sr + R) * PITCH + c with PITCH = 36
   unsigned abase[TW];
 #pragma unroll
   for (int t = 0; t < TW; ++t) {
-    const int c = t + r16;
-    abase[t] = lds0 + wv * SBUF + c * 64 + ((g ^ ((c >> 1) & 3)) << 4);
+    const int c = 16 * sc + t + r16;
+    abase[t] = lds0 + (8 * sr * PITCH + c) * 64 + ((g ^ ((c >> 1) & 3)) << 4);
   }
   const unsigned wbase = lds0 + WOFF + tile_off(r16, g);
   f32x4_t acc[ROWS][NF];
@@ -250,20 +281,17 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
   // epilogue arguments, pinned in SGPRs.  (Written as gconv_out_pos(p, ..) the per-lane choice between p.out / p.out2
   // compiled into vector loads of the KERNEL ARGUMENTS themselves -- select of two kernarg addresses, global_load,
   // s_waitcnt vmcnt(0) -- in front of every store.)  The outputs leave through buffer stores: an invalid lane (ragged
-  // edge of the strip, the other tensor of the windowed form) carries an offset past the descriptor's range and is
+  // edge of the tile, the other tensor of the windowed form) carries an offset past the descriptor's range and is
   // dropped by the hardware, so the epilogue is straight-line code the scheduler can place between the MFMAs.
-  int e_ops = p.ops, e_o2ps = p.o2ps, e_gps = p.gps, e_Ht = p.Hout_t, e_Wt = p.Wout_t, e_Ho = p.Ho, e_Wo = p.Wo;
+  int e_ops = p.ops, e_o2ps = p.o2ps, e_Ht = p.Hout_t, e_Wt = p.Wout_t, e_Ho = p.Ho, e_Wo = p.Wo;
   int e_ooy = p.ooy, e_oox = p.oox, e_wy0 = p.win_y0, e_wx0 = p.win_x0, e_wh = p.win_h, e_ww = p.win_w;
-  float e_slope = p.slope, e_gslope = p.gslope;
-  asm volatile("" : "+s"(e_ops), "+s"(e_o2ps), "+s"(e_gps), "+s"(e_Ht), "+s"(e_Wt));
+  float e_slope = p.slope;
+  asm volatile("" : "+s"(e_ops), "+s"(e_o2ps), "+s"(e_Ht), "+s"(e_Wt), "+s"(e_slope));
   asm volatile("" : "+s"(e_Ho), "+s"(e_Wo), "+s"(e_ooy), "+s"(e_oox), "+s"(e_wy0), "+s"(e_wx0), "+s"(e_wh), "+s"(e_ww));
-  asm volatile("" : "+s"(e_slope), "+s"(e_gslope));
   const unsigned e_obytes = (unsigned)p.B * (WIN ? p.win_h * p.win_w : p.Hout_t * p.Wout_t) * (unsigned)p.ops * 2u;
   const unsigned e_hbytes = (unsigned)p.B * p.Hout_t * p.Wout_t * (unsigned)p.o2ps * 2u;
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)e_obytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_halo = __builtin_amdgcn_make_buffer_rsrc(WIN ? p.out2 : p.out, 0, (int)(WIN ? e_hbytes : 0u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_gate = __builtin_amdgcn_make_buffer_rsrc((void*)(GATE ? p.gsrc : p.out), 0,
-      (int)(GATE ? (unsigned)p.B * (WIN ? p.win_h * p.win_w : p.Hout_t * p.Wout_t) * (unsigned)p.gps * 2u : 0u), 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   u32x4_t W[TH][NF], f[3];
   U_STAMP_DECL;
@@ -287,42 +315,38 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
     });
     u_lgkm<0>(f[1]);
   }
-  unsigned r_next = WST;                               // ring offset of the stage the NEXT iteration reads
+  unsigned r_next = WST;                               // ring offset of the stage the NEXT iteration reads (streaming form)
 
   for (int ps = 0; ps < my_passes; ++ps) {
-    // this pass's strip (epilogue coordinates)
-    const int sid = (worker + ps * workers) * U_STRIPS + wv;
-    const bool sv = sid < nstrips;
-    const int sx = sid % SX, t_ = sid / SX, sy = t_ % SY, sb = t_ / SY;
-    const int oy0 = sy * ROWS, ox = sx * 16 + r16;
-    // output offsets of the strip (bf16 tensors < 2 GiB: uconv_eligible): what does not depend on the row, once per pass
+    // this pass's tile and this wave's strip (epilogue coordinates)
+    const int tile = worker + ps * workers;
+    const bool sv = tile < npass;
+    const int tx_ = tile % TX, t_ = tile / TX, ty_ = t_ % TY, sb = t_ / TY;
+    const int oy0 = ty_ * U_TR + sr * ROWS, ox = tx_ * U_TC + sc * 16 + r16;
+    // output offsets of the strip (bf16 tensors < 2 GiB: uconv_eligible): what does not depend on the row, once per pass.
+    // After the exchange of fragment pairs a lane stores 8 consecutive channels: lane row g holds channels
+    // 8 (g >> 1) + 16 (g & 1) .. + 7 of the pair's 32
     const int tyb = oy0 + e_ooy, txl = ox + e_oox;                 // tensor coordinates of row 0 (out_sy = out_sx = 1)
     const bool colv = sv && ox < e_Wo;
     const unsigned fpix0 = (unsigned)((sb * e_Ht + tyb) * e_Wt + txl);          // position in the [B, Hout_t, Wout_t] tensor
     const int cx = txl - e_wx0, cy0 = tyb - e_wy0;
     const bool cin_ = !WIN || (unsigned)cx < (unsigned)e_ww;
     const unsigned wpix0 = (unsigned)((sb * e_wh + cy0) * e_ww + cx);          // position in the dense window tensor
-    const unsigned lch = (unsigned)(n0 + g * 4) * 2u;                          // this lane's channel quad of fragment 0
+    const unsigned lch = (unsigned)(n0 + 8 * (g >> 1) + 16 * (g & 1)) * 2u;
     const unsigned ob0 = (WIN ? wpix0 : fpix0) * (unsigned)(e_ops * 2) + lch, obr = (unsigned)((WIN ? e_ww : e_Wt) * e_ops * 2);
     const unsigned hb0 = fpix0 * (unsigned)(e_o2ps * 2) + lch, hbr = (unsigned)(e_Wt * e_o2ps * 2);
-    const unsigned gb0 = (WIN ? wpix0 : fpix0) * (unsigned)(e_gps * 2) + lch, gbr = (unsigned)((WIN ? e_ww : e_Wt) * e_gps * 2);
     auto epilogue_row = [&](auto rc_) {
       constexpr int r = decltype(rc_)::value;
       const bool mv = colv && oy0 + r < e_Ho;
       const bool inside = cin_ && (!WIN || (unsigned)(cy0 + r) < (unsigned)e_wh);
       const unsigned offo = (mv && inside) ? ob0 + r * obr : OOB;
       const unsigned offh = (WIN && mv && !inside) ? hb0 + r * hbr : OOB;
-      u32x2_t gate[GATE ? NF : 1];
-      if constexpr (GATE) {
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-          gate[i] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_gate, (int)((mv && inside) ? gb0 + r * gbr + i * 32 : OOB), 0, 0));
-      }
+      u32x2_t pk[NF];
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         f32x4_t v = acc[r][i];
         acc[r][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (UCONV_ABLATE & 1) { asm volatile("" :: "v"(v)); continue; }
+        if (UCONV_ABLATE & 1) { asm volatile("" :: "v"(v)); pk[i] = (u32x2_t){0u, 0u}; continue; }
         if constexpr (BIAS) {
           v += bias[i];
 #pragma unroll
@@ -332,15 +356,17 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) { const float vq = mv ? v[q] : 0.f; s1[i][q] += vq; s2[i][q] += vq * vq; }
         }
-        if constexpr (GATE) {
-          const f32x4_t gs = (f32x4_t){__uint_as_float(gate[i][0] << 16), __uint_as_float(gate[i][0] & 0xffff0000u),
-                                       __uint_as_float(gate[i][1] << 16), __uint_as_float(gate[i][1] & 0xffff0000u)};
+        pk[i] = pack4_bf16(v);
+      }
+      if (UCONV_ABLATE & 1) return;
+      // fragments i, i+1: lane rows 1, 3 of fragment i change places with lane rows 0, 2 of fragment i+1
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = gs[q] > 0.f ? v[q] : v[q] * e_gslope;
-        }
-        const u32x2_t pk = pack4_bf16(v);
-        __builtin_amdgcn_raw_buffer_store_b64(pk, rs_out, (int)(offo + i * 32), 0, 0);
-        if constexpr (WIN) __builtin_amdgcn_raw_buffer_store_b64(pk, rs_halo, (int)(offh + i * 32), 0, 0);
+      for (int i = 0; i < NF; i += 2) {
+        const auto x0 = __builtin_amdgcn_permlane16_swap(pk[i][0], pk[i + 1][0], false, false);
+        const auto x1 = __builtin_amdgcn_permlane16_swap(pk[i][1], pk[i + 1][1], false, false);
+        const u32x4_t d = (u32x4_t){x0[0], x1[0], x0[1], x1[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs_out, (int)(offo + i * 32), 0, 0);
+        if constexpr (WIN) __builtin_amdgcn_raw_buffer_store_b128(d, rs_halo, (int)(offh + i * 32), 0, 0);
       }
     };
 
@@ -348,6 +374,8 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
       constexpr int IT = decltype(itc)::value, tx = IT % TW, c = IT / TW;
       constexpr bool LAST = IT == NIT - 1;
       constexpr int txn = (IT + 1) % NIT % TW, cn = (IT + 1) % NIT / TW;
+      // does this iteration carry a workgroup barrier?  streaming: always (stage i+1); RESIDENT: the phase's hand-overs
+      constexpr bool BAR = !RESIDENT || tx == 0 || tx == TW - 1;
       const int buf = NCH == 1 ? (ps & 1) : c;
       const int bufn = NCH == 1 ? (LAST ? ((ps + 1) & 1) : (ps & 1)) : cn;
       // (the buffer offsets are made opaque here: the compiler otherwise hoists every iteration's four addresses to the top
@@ -356,8 +384,8 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
       asm volatile("" : "+s"(boff), "+s"(boffn));
       const unsigned pa = abase[tx] + boff, pan = abase[txn] + boffn;
       const unsigned pao = pa ^ 32u, pano = pan ^ 32u;
-      const unsigned wn = wbase + r_next;
-      r_next = r_next + WST == U_RING * WST ? 0u : r_next + WST;
+      const unsigned wn = wbase + (RESIDENT ? (unsigned)(((IT + 1) % NIT) * WST) : r_next);
+      if constexpr (!RESIDENT) r_next = r_next + WST == RINGN * WST ? 0u : r_next + WST;
       u_unroll(std::make_integer_sequence<int, NR>{}, [&](auto rc) {
         constexpr int R = decltype(rc)::value, G = IT * NR + R;
         // (1) the fragment two patch rows ahead (the last two: rows 0, 1 of the next iteration)
@@ -381,8 +409,8 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
             acc[r][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, W[ty][i]),
                                                                 __builtin_bit_cast(bf16x8_t, f[G % 3]), acc[r][i], 0, 0, 0);
         }
-        // (5) B_i: stage i+1 (and, in a phase's last iteration, the next phase's patch) are visible from here on
-        if constexpr (R == ROWS - 1) { U_STAMP(1); __builtin_amdgcn_s_barrier(); U_STAMP(2); }   // 1: multiplying, 2: barrier
+        // (5) barrier: the next stage (and, in a phase's last iteration, the next phase's patch) are visible from here on
+        if constexpr (R == ROWS - 1 && BAR) { U_STAMP(1); __builtin_amdgcn_s_barrier(); U_STAMP(2); }   // 1: multiplying, 2: barrier
         // (6) filter row R-(ROWS-1) is dead: refill it for the next iteration
         if constexpr (R >= ROWS - 1) {
           constexpr int ty = R - (ROWS - 1);
@@ -448,10 +476,10 @@ static int u_nf(const csmri_gconv_desc* d) {
   return (UCONV_NF4 && !d->stats_partial) ? 4 : 2;
 }
 static void u_grid(const csmri_gconv_desc* d, int* nstrips, int* sx, int* sy, int* nb, int* workers) {
-  *sx = (d->Wo + 15) / 16; *sy = (d->Ho + U_ROWS - 1) / U_ROWS;
-  *nstrips = d->B * *sx * *sy;
+  *sx = (d->Wo + U_TC - 1) / U_TC; *sy = (d->Ho + U_TR - 1) / U_TR;
+  *nstrips = d->B * *sx * *sy;                       // tiles (= passes)
   *nb = d->Cout / (16 * u_nf(d));
-  const int npass = (*nstrips + U_STRIPS - 1) / U_STRIPS;
+  const int npass = *nstrips;
   int maxw = UCONV_CUS / *nb; if (maxw < 1) maxw = 1;
   const int rounds = (npass + maxw - 1) / maxw;
   *workers = (npass + rounds - 1) / rounds;
@@ -489,8 +517,8 @@ int uconv_stats_rows(const csmri_gconv_desc* d0) {
 
 template <int TH, int TW, int NCH, int NF, int MODE>
 static int launch_uconv(const GParams& p, int grid, hipStream_t st) {
-  constexpr int NR = U_ROWS + TH - 1, NPC = (NR * U_PITCH + 15) / 16;
-  constexpr int lds = 2 * U_STRIPS * NPC * 1024 + U_RING * TH * NF * 1024;
+  constexpr int WST = TH * NF * 1024, NIT = NCH * TW, RFIT = (U_LDS - 2 * U_NPC * 1024) / WST, RINGN = RFIT >= NIT ? NIT : 4;
+  constexpr int lds = 2 * U_NPC * 1024 + RINGN * WST;
   auto kern = uconv_kernel<TH, TW, NCH, NF, MODE>;
   CSMRI_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
