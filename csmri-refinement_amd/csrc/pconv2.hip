@@ -57,11 +57,12 @@ template <int TH, int TW, int BN>
 __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
   constexpr int NT = TH * TW, TPW = 16 + TW - 1, TPH = 16 + TH - 1, NPIX = TPH * TPW;
   constexpr int PLANE = (NPIX * 16 + 255) & ~255, PBUF = 8 * PLANE, WST = BN * 128, NG = 6;
+  constexpr int BOFF = 2 * PBUF + 4 * WST;                     // bias of the workgroup's channel block (BN floats)
   constexpr int FN = BN / 32;                                   // 16-channel fragments per compute wave
   constexpr int WP = BN / 32;                                   // weight pieces (8 rows x 128 B) per loader and stage
   static_assert(BN == 128 || BN == 64, "output-channel block");
   constexpr int PPT = NT >= 12 ? 1 : 2, PTAPS = 12 / PPT;      // patch pieces per loader and tap; taps that carry them
-  static_assert(NT >= 4 && PTAPS + 3 <= NT && NPIX >= 64 && NPIX <= NG * 64 && 2 * PBUF + 4 * WST <= 160 * 1024, "patch / ring do not fit");
+  static_assert(NT >= 4 && PTAPS + 3 <= NT && NPIX >= 64 && NPIX <= NG * 64 && 2 * PBUF + 4 * WST + BN * 4 <= 160 * 1024, "patch / ring do not fit");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,36 +205,77 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
   // fragment addresses: one VGPR per operand and K half; fragment index and tap are immediate offsets
   const unsigned abase = lds0 + g * PLANE + ((4 * wm * TPW + r16) << 4);
   const unsigned wb0 = lds0 + 2 * PBUF + p2_woff(wn * (BN / 2) + r16, g), wb1 = lds0 + 2 * PBUF + p2_woff(wn * (BN / 2) + r16, 4 + g);
+  // Epilogue of a tile: bf16 outputs through range-checked buffer stores (an invalid lane carries an offset past the
+  // descriptor's range: no exec branches), fragment pairs exchanged between lane rows so that a lane stores 16 B and a pixel
+  // 64 contiguous bytes per instruction, the bias read from LDS, and ALL gate loads of the tile in flight before the first
+  // is used.  (The common epilogue it replaced -- gconv_out_pos, one global load of the bias and of the gate per fragment,
+  // each behind its own s_waitcnt vmcnt(0), 8-byte stores -- cost the VGG layers 6-26 us per launch with the bias and
+  // 3-15 us with the gate, profiles/r05_epilogue_cost.log: 16-32 serial L2 / HBM round trips per tile with all twelve
+  // waves of the workgroup waiting at the next barrier.)
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0,
+      (int)((unsigned)p.B * p.Hout_t * p.Wout_t * (unsigned)p.ops * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_gate = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gsrc ? p.gsrc : p.out), 0,
+      (int)(p.gsrc ? (unsigned)p.B * p.Hout_t * p.Wout_t * (unsigned)p.gps * 2u : 0u), 0x00020000);
+  const bool has_bias = p.bias != nullptr, has_gate = p.gsrc != nullptr, has_act = p.slope != 1.f;
+  const float e_slope = p.slope, e_gslope = p.gslope;
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned nown = (unsigned)(n0 + wn * (BN / 2));
+  const unsigned lch_st = (nown + 8 * (g >> 1) + 16 * (g & 1)) * 2u;     // store: 8 consecutive channels after the exchange
+  const unsigned lch_ld = (nown + g * 4) * 2u;                            // gate: this lane's own channel quad
   auto epilogue = [&](int T) {
     const int b = T / tiles_img, t = T - b * tiles_img;
     const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
     const int y0 = tyi * 16, x0 = txi * 16;
+    unsigned opix[4]; bool mvv[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int oy = y0 + 4 * wm + f, ox = x0 + r16;
-      const bool mv = oy < p.Ho && ox < p.Wo;
-      const OutPos op = gconv_out_pos(p, b, oy * p.osy + p.ooy, ox * p.osx + p.oox);
+      mvv[f] = oy < p.Ho && ox < p.Wo;
+      opix[f] = (unsigned)((b * p.Hout_t + oy + p.ooy) * p.Wout_t + ox + p.oox);
+    }
+    u32x2_t gt[4][FN];
+    if (has_gate) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+          gt[f][i] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(
+              rs_gate, (int)(mvv[f] ? opix[f] * (unsigned)(p.gps * 2) + lch_ld + i * 32 : OOB), 0, 0));
+    }
+    f32x4_t bb[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) bb[i] = has_bias ? *(const f32x4_t*)(smem + BOFF + (wn * (BN / 2) + i * 16 + g * 4) * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const unsigned off = mvv[f] ? opix[f] * (unsigned)(p.ops * 2) + lch_st : OOB;
+      u32x2_t pk[FN];
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
-        const int n = n0 + wn * (BN / 2) + i * 16 + g * 4;
-        f32x4_t v = acc[i][f];
+        f32x4_t v = acc[i][f] + bb[i];
         acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (!mv) continue;
-        if (p.bias) v += *(const f32x4_t*)(p.bias + n);
-        if (p.slope != 1.f) {
+        if (has_act) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * p.slope : v[r];
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], v[r] * e_slope);      // 0 <= slope <= 1 (pconv2_eligible)
         }
-        if (p.gsrc && op.g_ok) {
-          f32x4_t gs = load4(p.gsrc, op.gpix + n, p.gdt);
+        if (has_gate) {
+          const f32x4_t gs = (f32x4_t){__uint_as_float(gt[f][i][0] << 16), __uint_as_float(gt[f][i][0] & 0xffff0000u),
+                                       __uint_as_float(gt[f][i][1] << 16), __uint_as_float(gt[f][i][1] & 0xffff0000u)};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gs[r] > 0.f ? v[r] : v[r] * p.gslope;
+          for (int r = 0; r < 4; ++r) v[r] = gs[r] > 0.f ? v[r] : v[r] * e_gslope;
         }
-        store4(op.base, op.opix + n, p.out_dt, v);
+        pk[i] = pack4_bf16(v);
+      }
+#pragma unroll
+      for (int i = 0; i < FN; i += 2) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[i][0], pk[i + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[i][1], pk[i + 1][1], false, false);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){s0[0], s1[0], s0[1], s1[1]}, rs_out, (int)(off + i * 32), 0, 0);
       }
     }
   };
 
+  if (has_bias && tid < BN) ((float*)(smem + BOFF))[tid] = p.bias[n0 + tid];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                       // patch 0 and stage 0 have landed
   if (wn) __builtin_amdgcn_s_barrier();               // channel half 1: half a step behind
   int c_cc = 0, c_tile = worker;
@@ -320,7 +362,12 @@ static void p2_grid(const csmri_gconv_desc* d, int* ntile, int* nb, int* workers
 #endif
 int pconv2_eligible(const csmri_gconv_desc* d) {
   if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
-  if (d->nclass > 1 || d->splitk > 1 || d->upsample || d->in1 || d->stats_partial) return 0;
+  if (d->nclass > 1 || d->splitk > 1 || d->upsample || d->in1 || d->stats_partial || d->out_halo) return 0;
+  // epilogue: bf16 tensors addressed with 32-bit byte offsets, leaky slope applied as max(v, slope v)
+  if (d->out_dtype != CSMRI_BF16 || (d->g_src && d->g_dtype != CSMRI_BF16)) return 0;
+  if (!(d->act_slope >= 0.f && d->act_slope <= 1.f)) return 0;
+  { const long long px = (long long)d->B * d->Hout_t * d->Wout_t;
+    if (px * d->out_pix_stride * 2 >= (1ll << 31) || px * (d->g_src ? d->g_pix_stride : 0) * 2 >= (1ll << 31)) return 0; }
   if (d->TH != 3 || d->TW != 3 || d->out_sy != 1 || d->out_sx != 1) return 0;
   // Measured (profiles/r03_pconv2_layers.log): against gconv_glds / gconv_glds256 / pconv / tconv, alone with warm caches
   // +15 % at 512 input channels (1.20 vs 1.05 PFLOP/s on VGG conv4_x, batch 16), +27 % at 64 -> 128 (VGG conv2_1),
@@ -342,7 +389,7 @@ int pconv2_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) 
   p2_grid(d, &ntile, &nb, &workers);
   p.mtiles = ntile; p.ntiles = nb;
   const int bn = p2_bn(d);
-  const int lds = 2 * 8 * p2_plane(d) + 4 * bn * 128;
+  const int lds = 2 * 8 * p2_plane(d) + 4 * bn * 128 + bn * 4;
   CSMRI_SET_MAX_LDS((pconv2_kernel<3, 3, 128>), 160 * 1024);
   hipLaunchKernelGGL((pconv2_kernel<3, 3, 128>), dim3(workers * nb), dim3(768), lds, st, p);
   CSMRI_LAUNCH_CHECK();

@@ -258,10 +258,6 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
   }
   const unsigned wbase = lds0 + WOFF + tile_off(r16, g);
   f32x4_t acc[ROWS][NF];
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-    for (int i = 0; i < NF; ++i) acc[r][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float s1[STATS ? NF : 1][4], s2[STATS ? NF : 1][4];
   if constexpr (STATS) {
 #pragma unroll
@@ -277,6 +273,11 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
 #pragma unroll
     for (int i = 0; i < NF; ++i) asm volatile("" : "+v"(bias[i]));
   }
+  // (the accumulators start from the bias: no add in the epilogue)
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[r][i] = BIAS ? bias[i] : (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   // epilogue arguments, pinned in SGPRs.  (Written as gconv_out_pos(p, ..) the per-lane choice between p.out / p.out2
   // compiled into vector loads of the KERNEL ARGUMENTS themselves -- select of two kernarg addresses, global_load,
@@ -285,8 +286,7 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
   // dropped by the hardware, so the epilogue is straight-line code the scheduler can place between the MFMAs.
   int e_ops = p.ops, e_o2ps = p.o2ps, e_Ht = p.Hout_t, e_Wt = p.Wout_t, e_Ho = p.Ho, e_Wo = p.Wo;
   int e_ooy = p.ooy, e_oox = p.oox, e_wy0 = p.win_y0, e_wx0 = p.win_x0, e_wh = p.win_h, e_ww = p.win_w;
-  float e_slope = p.slope;
-  asm volatile("" : "+s"(e_ops), "+s"(e_o2ps), "+s"(e_Ht), "+s"(e_Wt), "+s"(e_slope));
+  asm volatile("" : "+s"(e_ops), "+s"(e_o2ps), "+s"(e_Ht), "+s"(e_Wt));
   asm volatile("" : "+s"(e_Ho), "+s"(e_Wo), "+s"(e_ooy), "+s"(e_oox), "+s"(e_wy0), "+s"(e_wx0), "+s"(e_wh), "+s"(e_ww));
   const unsigned e_obytes = (unsigned)p.B * (WIN ? p.win_h * p.win_w : p.Hout_t * p.Wout_t) * (unsigned)p.ops * 2u;
   const unsigned e_hbytes = (unsigned)p.B * p.Hout_t * p.Wout_t * (unsigned)p.o2ps * 2u;
@@ -345,12 +345,11 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         f32x4_t v = acc[r][i];
-        acc[r][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        acc[r][i] = BIAS ? bias[i] : (f32x4_t){0.f, 0.f, 0.f, 0.f};
         if (UCONV_ABLATE & 1) { asm volatile("" :: "v"(v)); pk[i] = (u32x2_t){0u, 0u}; continue; }
         if constexpr (BIAS) {
-          v += bias[i];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], v[q] * e_slope);     // 0 <= slope <= 1 (uconv_eligible)
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);               // bias + ReLU (uconv_eligible: slope 0)
         }
         if constexpr (STATS) {
 #pragma unroll
@@ -500,7 +499,7 @@ int uconv_eligible(const csmri_gconv_desc* d) {
   const int mode = u_mode(d);
   // the activation slope is applied with the bias only (VGG: bias + ReLU; the U-Net layers are followed by BatchNorm)
   if (!(mode & U_BIAS) && d->act_slope != 1.f) return 0;
-  if ((mode & U_BIAS) && !(d->act_slope >= 0.f && d->act_slope <= 1.f)) return 0;
+  if ((mode & U_BIAS) && d->act_slope != 0.f) return 0;
   if (d->TH == 4 && d->TW == 4) return mode == 0 || mode == U_STATS || mode == U_WIN;
   if (d->TH == 3 && d->TW == 3) return d->Cin == 64 && d->Cout % 64 == 0 && (mode == U_BIAS || mode == 0);
   return 0;

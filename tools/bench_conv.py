@@ -48,12 +48,15 @@ def pads_for(k, s):
 def run(name, mode='fwd', iters=20):
   cin, cout, k, s, border, up, h, w, b = CASES[name]
   wt = torch.nn.Parameter((torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)).cuda())
-  layer = ops.ConvLayer(wt, None, s, pads_for(k, s), border, torch.bfloat16, upsample=up)
+  bias = torch.nn.Parameter(torch.randn(cout).cuda() * 0.1) if mode == 'fwdb' else None
+  layer = ops.ConvLayer(wt, bias, s, pads_for(k, s), border, torch.bfloat16, upsample=up)
   x = torch.randn(b, h, w, ops.pad8(cin), device='cuda').bfloat16()
   y, _ = ops.conv_forward(layer, x, None, False)
   gy = torch.randn_like(y)
   fn = {'fwd': lambda: ops.conv_forward(layer, x, None, False),
+        'fwdb': lambda: ops.conv_forward(layer, x, None, True, 0.0),          # bias + ReLU (the VGG forward)
         'dgrad': lambda: ops.conv_dgrad(layer, gy, (h, w)),
+        'dgradg': lambda: ops.conv_dgrad(layer, gy, (h, w), g_src=x, g_slope=0.0),   # gated by the producer's ReLU (VGG backward)
         'wgrad': lambda: ops.conv_wgrad(layer, x, None, gy)}[mode]
   for _ in range(3):
     fn()
@@ -71,7 +74,7 @@ def run(name, mode='fwd', iters=20):
 
 if __name__ == '__main__':
   names = [a for a in sys.argv[1:] if a in CASES] or list(CASES)
-  modes = [a for a in sys.argv[1:] if a in ('fwd', 'dgrad', 'wgrad')] or ['fwd']
+  modes = [a for a in sys.argv[1:] if a in ('fwd', 'fwdb', 'dgrad', 'dgradg', 'wgrad')] or ['fwd']
   for n in names:
     for m in modes:
       run(n, m)
