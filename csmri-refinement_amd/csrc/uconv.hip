@@ -48,6 +48,9 @@ typedef __attribute__((address_space(3))) void* ul_t;
 #ifndef UCONV_ABLATE
 #define UCONV_ABLATE 0     // diagnostic builds only (tools/run/r05_ablate.sh): 1 no epilogue, 2 no DMA, 4 no LDS reads in the loop
 #endif
+#ifndef UCONV_PRIO
+#define UCONV_PRIO 1       // 1: compute waves at priority 2; 0: none; 2: loader waves at priority 3
+#endif
 #define U_ROWS 8           // output rows of a strip (one compute wave)
 #define U_TR 16            // tile = 2 x 2 strips
 #define U_TC 32
@@ -121,23 +124,30 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
   const int NTOT = my_passes * NIT;
   if (NTOT == 0) return;
 
+  // weight stage (tx, chunk c) into ring offset `ring`: wave L_ of its role moves pieces j = L_ (mod 4)
+  const int wrow = lane >> 2;
+  const int kc = (lane & 3) ^ tile_swz(wrow);          // (tile_swz depends on (row >> 2) & 3 only: the same for row + 16 pn)
+  const char* wsrc = p.w + ((size_t)(n0 + wrow) * p.Kp + kc * 8) * 2;
+  auto issue_stage = [&](int L_, int tx_, int c_, unsigned ring) {
+    char* dst = smem + WOFF + ring + L_ * 1024;
+    const unsigned koff = (unsigned)((tx_ * p.Cin + c_ * 32) * 2);
+#pragma unroll
+    for (int k = 0; k < WPI; ++k) {
+      const int j = L_ + 4 * k, ty = j / NF, pn = j % NF;
+      const char* src = wsrc + ((size_t)pn * 16 * p.Kp + (size_t)ty * TW * p.Cin) * 2 + koff;
+      if (!(UCONV_ABLATE & 2)) __builtin_amdgcn_global_load_lds((ug_t)src, (ul_t)(dst + 4096 * k), 16, 0, 0);
+    }
+  };
+
   if (wv >= 4) {
     // =================================================== loader waves ===================================================
     const int L = wv - 4;                              // loader L moves patch pieces and weight pieces j = L (mod 4)
-    const int wrow = lane >> 2;
-    const int kc = (lane & 3) ^ tile_swz(wrow);        // (tile_swz depends on (row >> 2) & 3 only: the same for row + 16 pn)
-    const char* wsrc = p.w + ((size_t)(n0 + wrow) * p.Kp + kc * 8) * 2;
-    int w_i = 0, w_tx = 0, w_c = 0;
+    if (UCONV_PRIO == 2) __builtin_amdgcn_s_setprio(3);
+    // (the first RINGN stages are issued by the compute waves, idle in the prologue)
+    int w_i = RINGN, w_tx = RINGN % TW, w_c = (RINGN / TW) % NCH;
     unsigned w_ring = 0;
     auto issue_w = [&]() {
-      char* dst = smem + WOFF + w_ring + L * 1024;
-      const unsigned koff = (unsigned)((w_tx * p.Cin + w_c * 32) * 2);
-#pragma unroll
-      for (int k = 0; k < WPI; ++k) {
-        const int j = L + 4 * k, ty = j / NF, pn = j % NF;
-        const char* src = wsrc + ((size_t)pn * 16 * p.Kp + (size_t)ty * TW * p.Cin) * 2 + koff;
-        if (!(UCONV_ABLATE & 2)) __builtin_amdgcn_global_load_lds((ug_t)src, (ul_t)(dst + 4096 * k), 16, 0, 0);
-      }
+      issue_stage(L, w_tx, w_c, w_ring);
       ++w_i;
       w_ring = w_ring + WST == RINGN * WST ? 0u : w_ring + WST;
       if (++w_tx == TW) { w_tx = 0; if (++w_c == NCH) w_c = 0; }
@@ -185,10 +195,8 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
     U_STAMP_DECL;
     tile_pixels(worker);
     patch_pieces(U_IC(0), U_IC(PPL), 0, 0);
-#pragma unroll
-    for (int s_ = 0; s_ < RINGN; ++s_) issue_w();
     U_STAMP(0);                                        // prologue issue
-    if constexpr (RESIDENT) u_vmwait<0>(); else u_vmwait<(RINGN - 1) * WPI>();   // patch 0 and stage 0
+    u_vmwait<0>();                                     // patch 0
     U_STAMP(1);                                        // prologue landing
     __builtin_amdgcn_s_barrier();                      // B_init
     U_STAMP(2);
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
   }
 
   // ===================================================== compute waves =====================================================
-  __builtin_amdgcn_s_setprio(2);
+  if (UCONV_PRIO == 1) __builtin_amdgcn_s_setprio(2);
   const int r16 = lane & 15, g = lane >> 4;
   const int sr = wv >> 1, sc = wv & 1;                 // this wave's strip of the tile
   const unsigned lds0 = (unsigned)(size_t)(ul_t)smem;
@@ -295,7 +303,11 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
   constexpr unsigned OOB = 0x80000000u;
   u32x4_t W[TH][NF], f[3];
   U_STAMP_DECL;
-  __builtin_amdgcn_s_barrier();                        // B_init: patch of phase 0 and stage 0 have landed
+  // prologue: the first RINGN weight stages (RESIDENT: all of them) while the loaders fetch the first patch
+#pragma unroll
+  for (int s_ = 0; s_ < RINGN; ++s_) issue_stage(wv, s_ % TW, (s_ / TW) % NCH, (unsigned)(s_ * WST));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                        // B_init: patch of phase 0 and the first stages have landed
   U_STAMP(0);                                          // waiting for the first patch
   u_unroll(std::make_integer_sequence<int, TH * NF>{}, [&](auto kc_) {
     constexpr int k = decltype(kc_)::value;
