@@ -12,15 +12,8 @@
 // sums the slabs in fixed order (deterministic) and accumulates into the fp32
 // gradient in the reference's [Cout][Cin][KH][KW] layout.
 #include "mma_core.h"
+#include "wgrad_params.h"
 
-struct WParams {
-  const char* in0; const char* in1; int ps0, ps1, c0;
-  int B, Hin, Win, Cin, ups, border;
-  int KH, KW, S, pt, pl;
-  const char* dy; int dyps; int Ho, Wo, Cout;
-  float* slab; int splitk; int M, NK, nsteps, steps_per_split, ptiles, qtiles;
-  int stages;   // wpatch: 2 = the next tile's images stream in under this tile's MFMAs (LDS permitting), 1 = in place
-};
 
 template <int DT>
 __device__ __forceinline__ void transpose_block(const u32x4_t* in, u32x4_t* out) {
@@ -388,22 +381,6 @@ __global__ __launch_bounds__(256) void wgrad_finish_multi_kernel(const WFinishTa
 // transposed read: a 16-lane group reads a 4-pixel x 16-channel block and each lane receives
 // one channel's 4 pixels).  16-byte chunks of a pixel row are XOR-swizzled per row so that the
 // transposed reads of a 32-lane half (8 pixel rows x 2 chunks) hit 16 distinct slots.
-template <int CPR> __device__ __forceinline__ int img_off(int row, int chunk) {
-  int f;
-  if constexpr (CPR >= 16) f = ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
-  else if constexpr (CPR == 8) f = (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
-  else if constexpr (CPR == 4) f = ((row >> 3) & 1) << 1;
-  else f = 0;
-  return row * CPR * 16 + ((chunk ^ f) << 4);
-}
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-struct s16x8_pair { s16x4_t lo, hi; };
-__device__ __forceinline__ bf16x8_t tr_frag(const char* img, int off_lo, int off_hi) {
-  s16x8_pair r;
-  r.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(img + off_lo));
-  r.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(img + off_hi));
-  return __builtin_bit_cast(bf16x8_t, r);
-}
 
 // ---------------------------------------------------------------------------------------------
 // wgrad_glds_kernel: the [pixel][channel] images are filled by LDS-DMA (global_load_lds_dwordx4): no staging
@@ -413,8 +390,6 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* img, int off_lo, int off
 // owns slot s of pixel row r fetches chunk s ^ f(r).  One LDS buffer, two barriers per 64-pixel
 // step; 3-4 workgroups per CU overlap each other's loads and MFMAs.
 __device__ __attribute__((aligned(16))) char w_zero_page[16];
-typedef __attribute__((address_space(1))) const void* wgptr_t;
-typedef __attribute__((address_space(3))) void* wlptr_t;
 
 //
 // wgrad_glds_row_kernel: the same kernel for geometries whose 64-pixel K steps are aligned with
@@ -1051,6 +1026,7 @@ static int wgrad_ps(int dtype) { return dtype == CSMRI_BF16 ? 64 : 16; }
 #endif
 extern "C" int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d) {
   if (wthin_out_eligible(d)) return wthin_splits(d);
+  if (wrow_eligible(d)) return wrow_groups(d);
   if (wpatch_eligible(d)) return wpatch_groups(d);
   WConfig c = pick_wconfig(d);
   const long long NK = (long long)d->KH * d->KW * d->Cin;
@@ -1110,6 +1086,7 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
 extern "C" int csmri_wgrad_kernel_name(const csmri_wgrad_desc* d, char* buf, int n) {
   CSMRI_CHECK_ARG(d && buf && n > 0);
   if (wthin_out_eligible(d)) { snprintf(buf, n, "wthin_out_kernel"); return CSMRI_OK; }
+  if (wrow_eligible(d)) { wrow_kernel_name(d, buf, n); return CSMRI_OK; }
   if (wpatch_eligible(d)) {
     snprintf(buf, n, "wpatch_kernel<%d, %d, %d>", d->Cin, d->Cin == 128 ? 32 : wpatch_cout(d),
              d->Cin == 128 ? 8 : (d->Cin == 64 && wpatch_cout(d) == 64 ? 8 : 4));
@@ -1157,13 +1134,13 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   }
   int rc;
 #define WG(DT_, BP_, BQ_, WP_, WQ_) rc = launch_wgrad<DT_, BP_, BQ_, WP_, WQ_>(p, st)
-  const bool patch = thin || wpatch_eligible(d);          // (both leave their bias-gradient partial rows behind the slabs)
+  const bool patch = thin || wpatch_eligible(d) || wrow_eligible(d);   // (all leave their bias-gradient partial rows behind the slabs)
   if (thin) {
     rc = wthin_launch(p, d, st);
   } else if (patch) {
     WParams q = p;
-    q.nsteps = d->db ? 1 : 0;                      // wpatch reuses the field: also produce the bias-gradient partials
-    rc = wpatch_launch(q, d, st);
+    q.nsteps = d->db ? 1 : 0;                      // wpatch / wrow reuse the field: also produce the bias-gradient partials
+    rc = wrow_eligible(d) ? wrow_launch(q, d, st) : wpatch_launch(q, d, st);
   } else if (d->dtype == CSMRI_BF16) {
     if (c.BQ == 128) rc = launch_wgrad_glds<128, 128, 2, 2>(p, st);
     else if (c.BQ == 64 && c.BP == 256) rc = launch_wgrad_glds<256, 64, 4, 1>(p, st);
@@ -1249,7 +1226,7 @@ extern "C" int csmri_wgrad_finish_multi(const csmri_wgrad_desc* descs, int n, vo
       t.Cout = d->Cout; t.NK = d->KH * d->KW * d->Cin; t.Cin = d->Cin; t.KH = d->KH; t.KW = d->KW;
       t.Cout_real = d->Cout_real; t.Cin_real = d->Cin_real; t.accumulate = d->accumulate;
       t.slab = d->slab; t.dw = d->dw;
-      const bool patch = wpatch_eligible(d) || wthin_out_eligible(d) || d->defer_finish == 2;
+      const bool patch = wpatch_eligible(d) || wrow_eligible(d) || wthin_out_eligible(d) || d->defer_finish == 2;
       t.db = patch ? d->db : nullptr;                  // (other kernels: bias gradient already written by csmri_wgrad)
       t.part = d->slab + (size_t)t.splitk * d->Cout * t.NK; t.part_rows = t.splitk;
       long long nb = t.splitk <= 8 ? (long long)t.Cout_real * ((t.Cin_real + 63) / 64)
