@@ -30,7 +30,7 @@ Extra legs (rank 0, outside the timed region):
   roofline_hbm  the same brackets around the HBM-bound entry points (data consistency, BatchNorm passes,
                 Adam) with their algorithmic bytes vs 8 TB/s
   cpu_baseline  the CPU oracle's (plain torch fp32) step on the SAME batch (N=1 only): >= 5 timed steps after a
-                warm-up at 32 threads (--cpu-all-threads probes 64 and os.cpu_count() as well and keeps the best);
+                warm-up at the better of 32 / 64 threads (probed, one step each; --cpu-all-threads adds os.cpu_count());
                 plus the PSNR of both paths on the same batch/weights.
 """
 import argparse
@@ -249,11 +249,12 @@ def _thread_counts(all_threads):
   """Thread counts the CPU baseline is probed at.  Small-batch conv2d stops scaling well before the box's hardware
   threads and then collapses: measured on the GPU boxes (2 x EPYC 9575F, 256 threads) 1.5-1.8 slices/s at 32 threads,
   1.0 at 64 (profiles/r04_bench_n1.json: every round's probe picked 32) and 0.046 at 256 (174 s per step,
-  profiles/r02_bench_n1_a.json): the default is 32 alone, --cpu-all-threads adds 64 and os.cpu_count()."""
+  profiles/r02_bench_n1_a.json): the default probes 32 and 64 (one step each: the reported baseline is the best
+  count on THIS box, not an assumed one), --cpu-all-threads adds os.cpu_count()."""
   n = os.cpu_count() or 1
-  counts = {min(32, n)}
+  counts = {min(32, n), min(64, n)}
   if all_threads:
-    counts.update((min(64, n), n))
+    counts.add(n)
   return sorted(counts)
 
 
@@ -473,12 +474,9 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
   if not no_graphs:
     # capture the step once (eager warm-up steps inside); the timed region replays hipGraphs (with more than one rank
     # the gradient collectives stay eager between the captured segments)
-    try:
-      runner.enable_graphs({k: v.to(dev) for k, v in host_batches[0].items()})
-    except Exception as e:            # keep the measurement alive: eager launches, same kernels
-      sys.stderr.write('bench: hipGraph capture failed (%r); running eager\n' % (e,))
-      runner.disable_graphs()
-      no_graphs = True
+    # (a capture failure is an ERROR: an eager run is ~2x slower and must not be recorded as this build's number;
+    #  --no-graphs asks for the eager run explicitly)
+    runner.enable_graphs({k: v.to(dev) for k, v in host_batches[0].items()})
   if warmup > 0:
     runner.train_epoch(loader_factory(warmup), 1, steps_per_train_summary=10 ** 9)
   torch.cuda.synchronize()

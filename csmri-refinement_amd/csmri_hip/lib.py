@@ -152,7 +152,7 @@ _SIGS = {
     'csmri_fft2': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'csmri_fft2_bf16': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'csmri_dc_bf16': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    'csmri_dc_in_bf16': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'csmri_dc_in_bf16': (i32, [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     'csmri_nchw_to_nhwc': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),
     'csmri_nhwc_to_nchw': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'csmri_nchw_to_nhwc_add': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, i32, vp]),

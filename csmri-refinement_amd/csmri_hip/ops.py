@@ -1581,10 +1581,11 @@ class Fft2d(torch.autograd.Function):
     return fft2(g.contiguous(), not ctx.inverse, True), None
 
 
-def dc_raw(x, k0, mask_u8, pad_dtype=None, out_fp32=False):
+def dc_raw(x, k0, mask_u8, pad_dtype=None, out_fp32=False, x_split=False):
   """x: interleaved complex fp32 [B,H,W,2] or channels 0,1 of a [B,H,W,8] fp32
   conv output; k0: dense [B,H,W,2]; mask uint8 [B,H,W].  Returns (out [B,H,W,2]
-  fp32, channel-padded copy [B,H,W,8] of pad_dtype or None)."""
+  fp32, channel-padded copy [B,H,W,8] of pad_dtype or None).  x_split: a bf16 x read with out_fp32 is a
+  CSMRI_BF16_SPLIT tensor (channels (0,1) + (2,3)); otherwise only channels 0,1 are read."""
   _need_gpu(x)
   x = as_nhwc(x)
   assert x.dtype in (torch.float32, torch.bfloat16) and x.shape[3] >= 2
@@ -1598,8 +1599,8 @@ def dc_raw(x, k0, mask_u8, pad_dtype=None, out_fp32=False):
     pad_code = lib.BF16_SPLIT if split else dt_of(out_pad)
   if x.dtype == torch.bfloat16 and out_fp32:      # bf16 input (a padded gradient), fp32 arithmetic and result
     out = torch.empty(b, h, w, 2, dtype=torch.float32, device=x.device)
-    lib.call('csmri_dc_in_bf16', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
-             ptr(out_pad), pad_code, b, h, w, stream())
+    lib.call('csmri_dc_in_bf16', x.data_ptr(), lib.BF16_SPLIT if x_split else lib.BF16, x.stride(2), ptr(k0),
+             mask_u8.data_ptr(), out.data_ptr(), ptr(out_pad), pad_code, b, h, w, stream())
   elif x.dtype == torch.bfloat16:     # bf16 image storage (k0 stays fp32): the "bf16 cFFT" of config 5
     lib.call('csmri_dc_bf16', x.data_ptr(), x.stride(2), ptr(k0), mask_u8.data_ptr(), out.data_ptr(),
              ptr(out_pad), pad_code, b, h, w, stream())
@@ -1622,6 +1623,9 @@ class DataConsistency(torch.autograd.Function):
     out, out_pad = dc_raw(x, k0, mask_u8, pad_dtype)
     ctx.save_for_backward(mask_u8)
     ctx.cx, ctx.xdt = x.shape[3], x.dtype
+    # the padded copy handed out is a split image: the gradient that comes back for it is one too (the fused backward
+    # writes dX in the format of its x)
+    ctx.pad_split = isinstance(pad_dtype, tuple)
     ctx.set_materialize_grads(False)       # (no zero fills for whichever of the two outputs is unused)
     if out_pad is None:
       return out
@@ -1633,10 +1637,14 @@ class DataConsistency(torch.autograd.Function):
       return None, None, None, None
     mask_u8, = ctx.saved_tensors
     if g is None and gpad.dtype == torch.bfloat16 and ctx.xdt == torch.float32 and is_nhwc(gpad):
-      gx, gp = dc_raw(gpad, None, mask_u8, ctx.xdt if ctx.cx == 8 else None, out_fp32=True)
+      gx, gp = dc_raw(gpad, None, mask_u8, ctx.xdt if ctx.cx == 8 else None, out_fp32=True, x_split=ctx.pad_split)
       return (gp if ctx.cx == 8 else gx), None, None, None
     if gpad is not None:                   # both outputs used (or an unusual dtype): sum in the dense layout
-      gp2 = copy_channels(as_nhwc(gpad), 2, ctx.xdt)
+      gpn = as_nhwc(gpad)
+      if ctx.pad_split and gpn.shape[3] >= 4:          # split gradient: hi + lo (rare path: plain torch ops)
+        gp2 = (gpn[..., 0:2].float() + gpn[..., 2:4].float()).to(ctx.xdt).contiguous()
+      else:
+        gp2 = copy_channels(gpn, 2, ctx.xdt)
       g = gp2 if g is None else as_nhwc(g).to(ctx.xdt) + gp2
     g = as_nhwc(g)
     if g.dtype != ctx.xdt:

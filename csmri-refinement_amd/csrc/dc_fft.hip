@@ -190,8 +190,11 @@ template <int IO> __device__ __forceinline__ void stc(void* p, size_t complex_id
 
 #define DC_THREADS 256               // row passes: 4 waves = 4 rows per workgroup
 #define DC_CTHREADS 512              // column pass: 8 waves = one column of the strip each
-#define DC_STRIP 8                   // columns per workgroup in pass 2 (64-byte row segments)
-#define DC_PITCH (DC_STRIP + 1)      // float2 pitch of the LDS strip image (conflict-free column reads)
+// columns per workgroup in pass 2 (template parameter STRIP): 8 = 64-byte row segments, 16 = whole 128-byte lines (every
+// fetched line used once: 8 fetched 134.5 MB for 71.4 MB of inputs, r04 PMC).  Same-box A/B (profiles/r05_dc_strip_ab.log):
+// 16 is 3 % faster at 64 x 256^2 and 15-30 % SLOWER at 8 x 256^2, 2 x 512^2 and 16 x 512^2 (half the workgroups, one per CU
+// at 512 rows): the pass is bound by latency and occupancy, not by the fetched bytes.  dc_strip() picks.
+#define DC_PITCH (STRIP + 1)         // float2 pitch of the LDS strip image (conflict-free column reads)
 
 // passes 1 and 3 (and the row halves of csmri_fft2): 1-D transforms along W, one per wave (two for W = 32).
 //   INV = false: src natural order with pixel stride src_ps floats -> dst natural order (dense)
@@ -250,11 +253,11 @@ __global__ __launch_bounds__(DC_THREADS) void dc_rows_kernel(const void* __restr
   }
 }
 
-// pass 2: a strip of DC_STRIP columns of one image.
+// pass 2: a strip of STRIP columns of one image.
 //   MODE 0  FFT along H -> x scale -> mask merge (+ k0) -> inverse FFT along H   (csmri_dc / csmri_undersample)
 //   MODE 1  FFT along H only (x scale), natural order out                        (csmri_fft2 forward)
 //   MODE 2  inverse FFT along H only (x scale)                                   (csmri_fft2 inverse)
-template <int LOGN, int MODE, int IO>
+template <int LOGN, int MODE, int IO, int STRIP>
 __global__ __launch_bounds__(DC_CTHREADS) void dc_cols_kernel(void* __restrict__ data, const float2* __restrict__ k0,
                                                              const uint8_t* __restrict__ mask, int W, float scale,
                                                              float2* __restrict__ kout, int keep_sampled) {
@@ -263,18 +266,18 @@ __global__ __launch_bounds__(DC_CTHREADS) void dc_cols_kernel(void* __restrict__
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float2* A = (float2*)smem;                       // [H][DC_PITCH]
   float2* K = A + H * DC_PITCH;                    // [H][DC_PITCH]  k0 strip, then the merged k-space (kout)
-  uint8_t* M = (uint8_t*)(K + H * DC_PITCH);       // [H][DC_STRIP]
+  uint8_t* M = (uint8_t*)(K + H * DC_PITCH);       // [H][STRIP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int strips = W / DC_STRIP;
-  const int img = blockIdx.x / strips, c0 = (blockIdx.x - img * strips) * DC_STRIP;
+  const int strips = W / STRIP;
+  const int img = blockIdx.x / strips, c0 = (blockIdx.x - img * strips) * STRIP;
   const size_t base = (size_t)img * H * W + c0;
-  for (int idx = tid; idx < H * DC_STRIP; idx += DC_CTHREADS) {
-    const int h = idx / DC_STRIP, c = idx - h * DC_STRIP;
+  for (int idx = tid; idx < H * STRIP; idx += DC_CTHREADS) {
+    const int h = idx / STRIP, c = idx - h * STRIP;
     const size_t o = base + (size_t)h * W + c;
     A[h * DC_PITCH + c] = ldc<IO>(data, 2 * o);
     if (MODE == 0) {
       if (k0) K[h * DC_PITCH + c] = k0[o];
-      M[h * DC_STRIP + c] = mask[o];
+      M[h * STRIP + c] = mask[o];
     }
   }
   __syncthreads();
@@ -282,11 +285,13 @@ __global__ __launch_bounds__(DC_CTHREADS) void dc_cols_kernel(void* __restrict__
   LaneTw<LOGN> tw;
   tw.init(l);
   const int kbase = C::R * rev_bits(l, C::LOGL);
-  constexpr int COLS_PER_WAVE = DC_STRIP / (DC_CTHREADS / 64);      // 1 (H = 32: two columns per wave on its half-waves, 4 waves idle)
-  static_assert(COLS_PER_WAVE == 1, "one column per wave");
-  const bool has_col = wave * C::TPW < DC_STRIP;        // wave-uniform
-  if (has_col) {
-    const int c = wave * C::TPW + (lane >> C::LOGL);
+  // a wave transforms C::TPW columns at a time (1; H = 32: two, on its half-waves): the strip takes PASSES rounds of the
+  // workgroup's 8 waves
+  constexpr int WAVES = DC_CTHREADS / 64, PASSES = (STRIP + WAVES * C::TPW - 1) / (WAVES * C::TPW);
+#pragma unroll 1
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int c = (ps * WAVES + wave) * C::TPW + (lane >> C::LOGL);
+    if ((ps * WAVES + wave) * C::TPW >= STRIP) break;          // wave-uniform
     float2 v[C::R];
     if (MODE != 2) {
 #pragma unroll
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(DC_CTHREADS) void dc_cols_kernel(void* __restrict__
         float2 k = v[q];
         k.x *= scale; k.y *= scale;
         // (1 - m) * k + k0 with m in {0,1}: bit-exact integer mask test; keep_sampled (forward model): m * k
-        float2 o = (M[ky * DC_STRIP + c] != 0) == (keep_sampled != 0) ? k : make_float2(0.f, 0.f);
+        float2 o = (M[ky * STRIP + c] != 0) == (keep_sampled != 0) ? k : make_float2(0.f, 0.f);
         if (k0) { const float2 z = K[ky * DC_PITCH + c]; o.x += z.x; o.y += z.y; }
         if (kout) K[ky * DC_PITCH + c] = o;
         v[q] = o;
@@ -321,8 +326,8 @@ __global__ __launch_bounds__(DC_CTHREADS) void dc_cols_kernel(void* __restrict__
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < H * DC_STRIP; idx += DC_CTHREADS) {
-    const int h = idx / DC_STRIP, c = idx - h * DC_STRIP;
+  for (int idx = tid; idx < H * STRIP; idx += DC_CTHREADS) {
+    const int h = idx / STRIP, c = idx - h * STRIP;
     const size_t o = base + (size_t)h * W + c;
     stc<IO>(data, o, A[h * DC_PITCH + c]);
     if (MODE == 0 && kout) kout[o] = K[h * DC_PITCH + c];
@@ -355,16 +360,24 @@ static int rows_pass(int logw, bool inv, const void* src, int src_ps, void* dst,
   return CSMRI_E_UNSUPPORTED;
 }
 
-template <int LOGN, int MODE, int IO>
-static int launch_cols(void* data, const float2* k0, const uint8_t* mask, int B, int W, float scale,
-                       float2* kout, int keep, hipStream_t st) {
+template <int LOGN, int MODE, int IO, int STRIP>
+static int launch_cols_s(void* data, const float2* k0, const uint8_t* mask, int B, int W, float scale,
+                         float2* kout, int keep, hipStream_t st) {
   constexpr int H = 1 << LOGN;
-  constexpr int lds = 2 * H * DC_PITCH * (int)sizeof(float2) + H * DC_STRIP;
-  CSMRI_SET_MAX_LDS((dc_cols_kernel<LOGN, MODE, IO>), lds);
-  hipLaunchKernelGGL((dc_cols_kernel<LOGN, MODE, IO>), dim3(B * (W / DC_STRIP)), dim3(DC_CTHREADS), lds, st,
+  constexpr int lds = 2 * H * DC_PITCH * (int)sizeof(float2) + H * STRIP;
+  CSMRI_SET_MAX_LDS((dc_cols_kernel<LOGN, MODE, IO, STRIP>), lds);
+  hipLaunchKernelGGL((dc_cols_kernel<LOGN, MODE, IO, STRIP>), dim3(B * (W / STRIP)), dim3(DC_CTHREADS), lds, st,
                      data, k0, mask, W, scale, kout, keep);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
+}
+// 16-column strips where they still give >= 4 workgroups per CU and two of them fit a CU's LDS (<= 256 rows)
+static int dc_strip(int B, int H, int W) { return (H <= 256 && (long long)B * (W / 16) >= 1024) ? 16 : 8; }
+template <int LOGN, int MODE, int IO>
+static int launch_cols(void* data, const float2* k0, const uint8_t* mask, int B, int W, float scale,
+                       float2* kout, int keep, hipStream_t st) {
+  if (dc_strip(B, 1 << LOGN, W) == 16) return launch_cols_s<LOGN, MODE, IO, 16>(data, k0, mask, B, W, scale, kout, keep, st);
+  return launch_cols_s<LOGN, MODE, IO, 8>(data, k0, mask, B, W, scale, kout, keep, st);
 }
 template <int MODE, int IO>
 static int cols_pass(int logh, void* data, const float2* k0, const uint8_t* mask, int B, int W, float scale,
@@ -413,11 +426,16 @@ extern "C" int csmri_dc_bf16(const void* x, int x_pix_stride, const float* k0, c
 // fp32 arithmetic and output, the input image read as bf16 (channels 0,1 of a bf16 tensor with pixel stride
 // x_pix_stride): the DC adjoint applied directly to the channel-padded bf16 gradient a convolution's
 // data-gradient kernel wrote, without a conversion pass in between
-extern "C" int csmri_dc_in_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, float* out,
-                                void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream) {
-  if (x_pix_stride >= 4 && x_pix_stride % 4 == 0)     // channel-padded pixels: channels (0,1) + (2,3), see CSMRI_BF16_SPLIT
+extern "C" int csmri_dc_in_bf16(const void* x, int x_dtype, int x_pix_stride, const float* k0, const uint8_t* mask,
+                                float* out, void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream) {
+  CSMRI_CHECK_ARG(x_dtype == CSMRI_BF16 || x_dtype == CSMRI_BF16_SPLIT);
+  // the caller DECLARES the format: CSMRI_BF16_SPLIT reads channels (0,1) + (2,3) of a channel-padded pixel, CSMRI_BF16
+  // channels 0,1 alone whatever the other channels hold
+  if (x_dtype == CSMRI_BF16_SPLIT) {
+    CSMRI_CHECK_ARG(x_pix_stride >= 4 && x_pix_stride % 4 == 0);
     return dc_passes<CSMRI_F32, DC_IO_BF16_PADDED>(x, x_pix_stride, k0, mask, out, out_pad, out_pad_dtype, B, H, W,
                                                     (hipStream_t)stream);
+  }
   return dc_passes<CSMRI_F32, CSMRI_BF16>(x, x_pix_stride, k0, mask, out, out_pad, out_pad_dtype, B, H, W,
                                            (hipStream_t)stream);
 }

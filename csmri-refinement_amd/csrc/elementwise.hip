@@ -576,7 +576,7 @@ extern "C" int csmri_copy_channels(const void* src, int src_dtype, int src_pix_s
   return CSMRI_OK;
 }
 
-extern "C" int csmri_version(void) { return 100; }
+extern "C" int csmri_version(void) { return 101; }   // 101: csmri_dc_in_bf16 takes x_dtype; csmri_dropout2d_mask state is uint64[3]
 extern "C" const char* csmri_error_string(int code) {
   switch (code) {
     case CSMRI_OK: return "ok";

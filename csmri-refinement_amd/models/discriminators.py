@@ -145,6 +145,7 @@ class CNNDiscriminator(nn.Module):
     outputs equal ``groups`` separate calls -- with half the kernel launches."""
     x = nhwc if nhwc is not None else ops.ToNHWC.apply(inp, self.dtype, ops.pad8(self.num_inputs))
     ensure_pack_group(self)
+    self.last_dropout_masks = []      # the masks of THIS call only (a list that grew every step pinned their buffers)
     feats, chans = [], []
     drawn = self._draw_masks(x.shape[0], x.device) if self.training else None
     n_drop = sum(1 for _, bn_, d_, _ in self._layers if bn_ is not None and d_)
@@ -185,6 +186,7 @@ class CNNDiscriminator(nn.Module):
     updates and Dropout2d draws are per group, in group order: the same numbers as ``groups`` separate calls."""
     assert self.training and nhwc.shape[0] % groups == 0
     ensure_pack_group(self)
+    self.last_dropout_masks = []      # the masks of THIS pass only
     n = nhwc.shape[0] // groups
     drawn = self._draw_masks(nhwc.shape[0], nhwc.device)
     n_drop = sum(1 for _, bn_, d_, _ in self._layers if bn_ is not None and d_)

@@ -331,10 +331,11 @@ int csmri_dc_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_
                   void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream);
 /* csmri_dc (fp32 arithmetic, intermediate and output) with the input image read as bf16, x_pix_stride in bf16
  * elements: the adjoint of DataConsistencyInKspace.perform (myfft.py:145-163 under autograd, k0 = NULL) applied
- * straight to the channel-padded bf16 gradient of the next conv block's input.  With x_pix_stride >= 4 the value read
- * is channels (0,1) + channels (2,3): a CSMRI_BF16_SPLIT gradient in full, a plain one unchanged (its channels 2,3
- * are zero). */
-int csmri_dc_in_bf16(const void* x, int x_pix_stride, const float* k0, const uint8_t* mask, float* out,
+ * straight to the channel-padded bf16 gradient of the next conv block's input.  x_dtype declares the format of x:
+ * CSMRI_BF16 reads channels 0,1 (whatever the pad channels hold), CSMRI_BF16_SPLIT reads channels (0,1) + (2,3) of a
+ * pixel of >= 4 channels -- a gradient the fused backward wrote with dx_split (ABI 101: the format used to be inferred
+ * from the stride). */
+int csmri_dc_in_bf16(const void* x, int x_dtype, int x_pix_stride, const float* k0, const uint8_t* mask, float* out,
                      void* out_pad, int out_pad_dtype, int B, int H, int W, void* stream);
 
 /* layout converters (H2D boundary: batch dict tensors are NCHW fp32,
@@ -583,7 +584,8 @@ int csmri_disc_accuracy(const float* prob_fake, const float* prob_real, int B, i
  * Bernoulli(1 - p) draw per (image, channel), survivors scaled by 1 / (1 - p)), all dropout layers in ONE launch:
  *   mask[i] = keep_i / (1 - p),  keep_i = [u_i < 1 - p],
  *   u_i = (Philox4x32-10(counter = (i / 4, 0, call_lo, call_hi), key = (seed_lo, seed_hi))[i % 4] >> 8) * 2^-24
- * state: DEVICE uint64[3] = {seed, call, 0}; the launch increments `call` (hipGraph-replay safe: every replay draws
+ * state: DEVICE uint64[3] = {seed, call, 0} (ABI 101; two words before: a caller that still passes two gets an
+ * out-of-bounds atomic -- check csmri_version() >= 101); the launch increments `call` (hipGraph-replay safe: every replay draws
  * new masks, and an eager run draws the same sequence); the third word counts the launch's workgroups as they finish
  * (the last one advances `call`) and is zero between launches.  mask: 16-byte aligned.  The masks are APPLIED by csmri_bn_act / the BatchNorm
  * backward (`dropmask`); tests inject masks there directly.  n <= 2^24. */

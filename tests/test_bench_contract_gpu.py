@@ -75,3 +75,35 @@ def test_bench_under_torch_distributed_run_single_rank():
   d = _one_line(out)
   _check_headline(d, 3, 2)
   assert d['config']['parallelism'] == 'dp1' and 'one graph per step' in d['launch_mode']
+
+
+def _two_rank_bench(extra):
+  """bench.py as the driver launches it for N = 2 -- torch.distributed.run, two processes -- on the ONE GPU of the test
+  box: CSMRI_DIST_BACKEND=gloo carries the collectives (both ranks share device 0), everything else is the N > 1 code
+  path: per-rank shards, the barrier + max-over-ranks timing, the settle loop's all-reduced step count, rank 0's line."""
+  port = 29500 + os.getpid() % 100
+  env = dict(os.environ, CSMRI_DIST_BACKEND='gloo')
+  return subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                         '--master-addr', '127.0.0.1', '--master-port', str(port),
+                         os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+                         '--no-cpu-baseline', '--no-other-configs', '--no-roofline', '--settle-s', '0.2'] + extra,
+                        capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+
+
+def test_bench_under_torch_distributed_run_two_ranks():
+  """the first multi-GPU driver run must not be the first time `bench.py --gpus 2` executes."""
+  d = _one_line(_two_rank_bench([]))
+  assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and d['unit'] == 'slices/s'
+  assert d['config']['parallelism'] == 'dp2' and d['config']['per_gpu_batch'] == 8 and d['config']['global_batch'] == 16
+  # with more than one rank the step is four captured segments with the gradient collectives between them
+  assert '4' in d['launch_mode'] or 'four' in d['launch_mode'], d['launch_mode']
+  # whole-job aggregate: both ranks' slices over the max-over-ranks time
+  assert abs(d['value'] - 16 / (d['ms_per_step'] * 1e-3)) < 0.02 * d['value']
+  assert d['warmup_total_steps'] == d['warmup'] + d['settle_steps']
+
+
+def test_bench_c2_under_torch_distributed_run_two_ranks():
+  d = _one_line(_two_rank_bench(['--config', 'c2']))
+  assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and 'C2' in d['config']['workload']
+  assert d['config']['global_batch'] == 2 * d['config']['per_gpu_batch']
+  assert abs(d['value'] - d['config']['global_batch'] / (d['ms_per_step'] * 1e-3)) < 0.02 * d['value']

@@ -843,11 +843,17 @@ def test_split_bf16_image_format(hip):
   assert float((pf[..., :2] + pf[..., 2:4] - of).abs().max() / of.abs().max()) < 2.0 ** -15
   # the adjoint on a split gradient == the fp32 adjoint of (hi + lo); on a plain padded gradient == of its channels 0,1
   gsp = pad                                                   # any split tensor serves as a gradient
-  a_split, _ = ops.dc_raw(gsp, None, mask, None, out_fp32=True)
+  a_split, _ = ops.dc_raw(gsp, None, mask, None, out_fp32=True, x_split=True)
   a_ref, _ = ops.dc_raw((pf[..., :2] + pf[..., 2:4]).contiguous(), None, mask, None)
   a_plain, _ = ops.dc_raw(pad2, None, mask, None, out_fp32=True)
   a_ref_plain, _ = ops.dc_raw(pad2.float()[..., :2].contiguous(), None, mask, None)
   assert rel_l2(a_split.cpu(), a_ref.cpu()) < 1e-6 and rel_l2(a_plain.cpu(), a_ref_plain.cpu()) < 1e-6
+  # the format is DECLARED (ABI 101), not inferred from the stride: a PLAIN padded gradient whose channels 2..7 are not
+  # zero (a user-supplied gradient, one summed with another consumer of the padded tensor) is read on channels 0,1 alone
+  noisy = torch.randn(b, h, w, 8, generator=g).bfloat16().cuda()
+  a_noisy, _ = ops.dc_raw(noisy, None, mask, None, out_fp32=True)
+  a_ref_noisy, _ = ops.dc_raw(noisy.float()[..., :2].contiguous(), None, mask, None)
+  assert rel_l2(a_noisy.cpu(), a_ref_noisy.cpu()) < 1e-6
 
 
 def test_convblock_fused_split_images(hip):
