@@ -280,6 +280,9 @@ extern "C" size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d) {
   return (size_t)nclass * d->splitk * desc_M(d) * d->Cout * sizeof(float);
 }
 
+#ifndef UCONV_BEFORE_PCONV2
+#define UCONV_BEFORE_PCONV2 0     // 64 -> 128 channels 3 x 3 (VGG conv2_1): which of the two patch kernels takes it
+#endif
 #ifndef SK_T1
 #define SK_T1 512
 #endif
@@ -395,6 +398,7 @@ extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int
   CSMRI_CHECK_ARG(d && buf && n > 0);
   if (d->dtype == CSMRI_FP8) { gconv_fp8_kernel_name(d, buf, n); return CSMRI_OK; }
   if (thin_out1_eligible(d)) { thin_kernel_name(d, buf, n); return CSMRI_OK; }
+  if (UCONV_BEFORE_PCONV2 && uconv_eligible(d)) { uconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3, 128>"); return CSMRI_OK; }
   if (uconv_eligible(d)) { uconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
@@ -427,6 +431,7 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
     return CSMRI_OK;
   }
   if (thin_out1_eligible(d)) return thin_out1_launch(p, d, st);
+  if (UCONV_BEFORE_PCONV2 && uconv_eligible(d)) return uconv_launch(p, d, st);
   if (pconv2_eligible(d)) return pconv2_launch(p, d, st);
   if (uconv_eligible(d)) return uconv_launch(p, d, st);
   if (tconv_eligible(d)) return tconv_launch(p, d, st);

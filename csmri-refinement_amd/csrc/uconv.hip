@@ -99,11 +99,13 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
   constexpr int NIT = NCH * TW;                     // iterations (chunk, tx) per pass
   constexpr int RFIT = (U_LDS - 2 * PBUF) / WST, RINGN = RFIT >= NIT ? NIT : 4;
   constexpr bool RESIDENT = RINGN == NIT;
+  constexpr bool RTC = NCH > 2;                     // runtime chunk loop (code size): a block = one chunk's TW iterations
+  constexpr int NITU = RTC ? TW : NIT;
   constexpr int WPI = TH * NF / 4, PPL = NPC / 4;   // weight pieces per loader and stage; patch pieces per loader and phase
   // patch pieces a loader issues in slot j of a phase (streaming form; RESIDENT: all in slot 0)
   constexpr int PP0 = RESIDENT ? PPL : (TW == 3 ? 6 : 4), PP1 = RESIDENT ? 0 : (TW == 3 ? 5 : 4), PP2 = PPL - PP0 - PP1;
   constexpr bool STATS = (MODE & U_STATS) != 0, BIAS = (MODE & U_BIAS) != 0, WIN = (MODE & U_WIN) != 0;
-  static_assert((TH * NF) % 4 == 0 && (NF % 2) == 0 && TW >= 3 && TW <= 4 && TH >= 3 && NCH >= 1 && NCH <= 2, "shape");
+  static_assert((TH * NF) % 4 == 0 && (NF % 2) == 0 && TW >= 3 && TW <= 4 && TH >= 3 && NCH >= 1 && NCH <= 8, "shape");
   static_assert((U_TR + TH - 1) * PITCH <= NPC * 16 && U_TC + TW - 1 <= PITCH && (PITCH % 4) == 0 && NPC % 4 == 0, "patch");
   static_assert(2 * PBUF + RINGN * WST <= U_LDS && RINGN >= 3, "LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
     const int nphase = my_passes * NCH;
     for (int ph = 0; ph < nphase; ++ph) {
       const bool next_phase = ph + 1 < nphase;
-      const int cn = NCH == 1 ? 0 : ((ph + 1) & 1);    // chunk of the next phase
+      const int cn = (ph + 1) % NCH;                   // chunk of the next phase
       u_unroll(std::make_integer_sequence<int, TW>{}, [&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if constexpr (RESIDENT) {
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
     });
     u_lgkm<0>(f[1]);
   }
-  unsigned r_next = WST;                               // ring offset of the stage the NEXT iteration reads (streaming form)
+  unsigned r_next = WST;                               // ring offset of the stage the NEXT iteration reads
 
   for (int ps = 0; ps < my_passes; ++ps) {
     // this pass's tile and this wave's strip (epilogue coordinates)
@@ -381,24 +383,28 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
       }
     };
 
-    u_unroll(std::make_integer_sequence<int, NIT>{}, [&](auto itc) {
-      constexpr int IT = decltype(itc)::value, tx = IT % TW, c = IT / TW;
-      constexpr bool LAST = IT == NIT - 1;
-      constexpr int txn = (IT + 1) % NIT % TW, cn = (IT + 1) % NIT / TW;
+    // A BLOCK = the iterations unrolled in one piece: the whole pass (NCH <= 2) or one 32-channel chunk (more chunks:
+    // the chunk loop is a runtime loop, the epilogue sits in the last chunk's copy of the block)
+    auto block = [&](auto lastc, int ph0) {            // ph0: phase (chunk) index of the block's first iteration
+    constexpr bool LASTBLOCK = decltype(lastc)::value;
+    u_unroll(std::make_integer_sequence<int, NITU>{}, [&](auto itc) {
+      constexpr int IT = decltype(itc)::value, tx = IT % TW;
+      constexpr bool LAST = LASTBLOCK && IT == NITU - 1;
+      constexpr int txn = (tx + 1) % TW;
       // does this iteration carry a workgroup barrier?  streaming: always (stage i+1); RESIDENT: the phase's hand-overs
       constexpr bool BAR = !RESIDENT || tx == 0 || tx == TW - 1;
-      const int buf = NCH == 1 ? (ps & 1) : c;
-      const int bufn = NCH == 1 ? (LAST ? ((ps + 1) & 1) : (ps & 1)) : cn;
+      const int buf = (ph0 + IT / TW) & 1;             // patch buffer of this phase; the next iteration's after a phase's last
+      const int bufn = tx == TW - 1 ? (buf ^ 1) : buf;
       // (the buffer offsets are made opaque here: the compiler otherwise hoists every iteration's four addresses to the top
       //  of the pass and spills them)
       unsigned boff = buf * PBUF, boffn = bufn * PBUF;
       asm volatile("" : "+s"(boff), "+s"(boffn));
       const unsigned pa = abase[tx] + boff, pan = abase[txn] + boffn;
       const unsigned pao = pa ^ 32u, pano = pan ^ 32u;
-      const unsigned wn = wbase + (RESIDENT ? (unsigned)(((IT + 1) % NIT) * WST) : r_next);
-      if constexpr (!RESIDENT) r_next = r_next + WST == RINGN * WST ? 0u : r_next + WST;
+      const unsigned wn = wbase + r_next;              // (RESIDENT: the ring is the whole pass, RINGN == NIT)
+      r_next = r_next + WST == RINGN * WST ? 0u : r_next + WST;
       u_unroll(std::make_integer_sequence<int, NR>{}, [&](auto rc) {
-        constexpr int R = decltype(rc)::value, G = IT * NR + R;
+        constexpr int R = decltype(rc)::value, G = IT * NR + R;   // (step index inside the block)
         // (1) the fragment two patch rows ahead (the last two: rows 0, 1 of the next iteration)
         if constexpr (UCONV_ABLATE & 4) { asm volatile("" : "+v"(f[(G + 2) % 3]) : "v"(pa), "v"(pan), "v"(pao), "v"(pano)); }
         else if constexpr (R + 2 < NR) U_READ(f[(G + 2) % 3], ((R & 1) ? pao : pa), (R + 2) * PITCH * 64);
@@ -435,17 +441,24 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
         if constexpr (!LAST) __builtin_amdgcn_sched_barrier(0);
       });
     });
-    epilogue_row(std::integral_constant<int, ROWS - 1>{});
+    if constexpr (LASTBLOCK) epilogue_row(std::integral_constant<int, ROWS - 1>{});
     U_STAMP(3);                                        // tail of the pass (from its last barrier): MFMAs + epilogue
-    // pass boundary: nothing in flight across the loop's back edge; next pass's rows 0, 1 sit in f[NIT*NR % 3], f[.. + 1]
+    // block boundary: nothing in flight across a loop's back edge; the next block's rows 0, 1 sit in f[NITU*NR % 3], f[.. + 1]
     u_unroll(std::make_integer_sequence<int, TH>{}, [&](auto tc) {
       constexpr int ty = decltype(tc)::value;
       u_lgkm<0, NF>(f[0], W[ty], true);
     });
     u_lgkm<0>(f[1]); u_lgkm<0>(f[2]);
-    constexpr int rot = (NIT * NR) % 3;
+    constexpr int rot = (NITU * NR) % 3;
     if constexpr (rot == 1) { const u32x4_t t0 = f[0]; f[0] = f[1]; f[1] = f[2]; f[2] = t0; }
     if constexpr (rot == 2) { const u32x4_t t0 = f[0]; f[0] = f[2]; f[2] = f[1]; f[1] = t0; }
+    };
+    if constexpr (RTC) {
+      for (int c = 0; c < NCH - 1; ++c) block(std::false_type{}, ps * NCH + c);
+      block(std::true_type{}, ps * NCH + NCH - 1);
+    } else {
+      block(std::true_type{}, ps * NCH);
+    }
   }
 
   U_STAMP_DUMP;
@@ -499,7 +512,7 @@ static void u_grid(const csmri_gconv_desc* d, int* nstrips, int* sx, int* sy, in
 int uconv_eligible(const csmri_gconv_desc* d) {
   if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
   if (d->nclass > 1 || d->splitk > 1 || d->out_sy != 1 || d->out_sx != 1) return 0;
-  if (!(d->Cin == 32 || d->Cin == 64)) return 0;
+  if (!(d->Cin == 32 || d->Cin == 64 || (d->Cin == 128 && d->TH == 4))) return 0;
   if (d->in1 && (d->c0 % 32)) return 0;
   if (!(d->Cout == 32 || d->Cout % 64 == 0)) return 0;
   if ((long long)d->Ho * d->Wo < UCONV_MIN_HW) return 0;
@@ -545,17 +558,21 @@ int uconv_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
   const int grid = workers * nb, mode = u_mode(d), nch = d->Cin / 32, nf = u_nf(d);
 #define UC(TH_, NCH_, NF_, MODE_) return launch_uconv<TH_, TH_, NCH_, NF_, MODE_>(p, grid, st)
   if (d->TH == 4) {
-    if (mode == U_STATS) { if (nch == 1) UC(4, 1, 2, U_STATS); UC(4, 2, 2, U_STATS); }
+    if (mode == U_STATS) { if (nch == 1) UC(4, 1, 2, U_STATS); if (nch == 2) UC(4, 2, 2, U_STATS); UC(4, 4, 2, U_STATS); }
     if (mode == U_WIN) {
       if (nch == 1 && nf == 2) UC(4, 1, 2, U_WIN);
       if (nch == 1 && nf == 4) UC(4, 1, 4, U_WIN);
       if (nch == 2 && nf == 2) UC(4, 2, 2, U_WIN);
-      UC(4, 2, 4, U_WIN);
+      if (nch == 2) UC(4, 2, 4, U_WIN);
+      if (nf == 2) UC(4, 4, 2, U_WIN);
+      UC(4, 4, 4, U_WIN);
     }
     if (nch == 1 && nf == 2) UC(4, 1, 2, 0);
     if (nch == 1 && nf == 4) UC(4, 1, 4, 0);
     if (nch == 2 && nf == 2) UC(4, 2, 2, 0);
-    UC(4, 2, 4, 0);
+    if (nch == 2) UC(4, 2, 4, 0);
+    if (nf == 2) UC(4, 4, 2, 0);
+    UC(4, 4, 4, 0);
   }
   if (mode == U_BIAS) UC(3, 2, 4, U_BIAS);
   UC(3, 2, 4, 0);

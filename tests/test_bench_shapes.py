@@ -190,11 +190,11 @@ def test_dispatch_variants_are_all_exercised():
   fam = set(n.split('<')[0].replace('void ', '') for n in names)
   splitk = any(e[2] > 1 and e[0] == 'gconv' for v in SEEN.values() for e in v)
   assert splitk, 'no split-K convolution among the bench shapes'
-  need = {'tconv_kernel', 'gconv_kernel', 'gconv_glds_kernel', 'pconv2_kernel',
-          'thin_out1_tile_kernel', 'wpatch_kernel', 'wgrad_glds_row_kernel', 'wthin_out_kernel'}
+  need = {'tconv_kernel', 'uconv_kernel', 'gconv_kernel', 'gconv_glds_kernel', 'pconv2_kernel',
+          'thin_out1_tile_kernel', 'wpatch_kernel', 'wrow_kernel', 'wgrad_glds_row_kernel', 'wthin_out_kernel'}
   assert need <= fam, (need - fam, fam)
-  path = os.path.join(ROOT, 'profiles', 'r04_bench_n1.json')
-  assert os.path.exists(path), 'commit the bench line of this build as profiles/r04_bench_n1.json'
+  path = os.path.join(ROOT, 'profiles', 'r05_bench_n1.json')
+  assert os.path.exists(path), 'commit the bench line of this build as profiles/r05_bench_n1.json'
   table = json.load(open(path))['conv_kernels']
   # second stages / fused blocks that are not csmri_gconv / csmri_wgrad main kernels (covered by tests/test_hip_ops.py)
   other = {'gconv_reduce_kernel', 'convblock_fwd_kernel'}
