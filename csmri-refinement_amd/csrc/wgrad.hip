@@ -672,7 +672,8 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
   constexpr int XROWS = 1024 / (CPR * 16), YROWS = 1024 / (CQ * 16);   // rows per LDS-DMA instruction
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int TPW = 16 + p.KW - 1, TPH = 16 + p.KH - 1, npix = TPH * TPW;
+  const int S = p.S;                                // 1, or 2 for the discriminator's first layer (CIN = 8)
+  const int TPW = 15 * S + p.KW, TPH = 15 * S + p.KH, npix = TPH * TPW;
   const int xinstr = (npix + XROWS - 1) / XROWS;
   const int IMG_X = xinstr * 1024;                  // dY image follows the patch
   const int IMG_BOTH = IMG_X + 256 * COUT * 2;      // one stage = patch + dY tile; two stages (double buffer)
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
   const unsigned magic = 0xFFFFFFFFu / (unsigned)TPW + 1u;
   // lane constants of the fragment reads: K chunk kc = tile rows 2kc, 2kc+1; this lane's pixel k = 8g + tq (+4)
   const int klo = 8 * g + tq;
-  const int prow = (klo >> 4) * TPW + (klo & 15);   // patch row of pixel k for tap (0,0), tile row 0
+  const int prow = S * ((klo >> 4) * TPW + (klo & 15));   // patch row of pixel k for tap (0,0), tile row 0
 
   // this wave's taps (tap pairs for CIN = 8, where the tap is a lane property) as patch-row offsets ty * TPW + tx:
   // decoded ONCE -- the integer division by the filter width sat inside the K loop (PMC: 9.5 VALU per MFMA)
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
     for (int i = wid; i < xinstr; i += WAVES) {
       const int P = i * XROWS + xr;
       const int py = (int)__umulhi((unsigned)P, magic), px = P - py * TPW;
-      int u = y0 - p.pt + py, w = x0 - p.pl + px;
+      int u = y0 * S - p.pt + py, w = x0 * S - p.pl + px;
       if (p.border == CSMRI_BORDER_REFLECT) {
         u = u < 0 ? -u : u; u = min(u, 2 * (Hv - 1) - u);
         w = w < 0 ? -w : w; w = min(w, 2 * (Wv - 1) - w);
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
         const int unit = wid + a * WAVES;
         if constexpr (CIN >= 16) {
           if (unit >= taps) break;                    // wave-uniform
-          const int rlo = prow + 2 * kc * TPW + toff[a], rhi = rlo + 4;
+          const int rlo = prow + S * 2 * kc * TPW + toff[a], rhi = rlo + 4 * S;
           const int xlo = img_off<CPR>(rlo, tp >> 1) + (tp & 1) * 8, xhi = img_off<CPR>(rhi, tp >> 1) + (tp & 1) * 8;
 #pragma unroll
           for (int c = 0; c < CF; ++c) {
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
           if (2 * unit >= taps) break;                // wave-uniform
           // lanes tp = 0,1 address the first tap of the pair, tp = 2,3 the second (the last pair of an odd
           // tap count repeats the first tap; its half of the result is never written)
-          const int rlo = prow + 2 * kc * TPW + toff[a], rhi = rlo + 4;
+          const int rlo = prow + S * 2 * kc * TPW + toff[a], rhi = rlo + 4 * S;
           const bf16x8_t xf = tr_frag(ximg, rlo * 16 + (tp & 1) * 8, rhi * 16 + (tp & 1) * 8);
 #pragma unroll
           for (int n = 0; n < NF; ++n)
@@ -834,7 +835,9 @@ __global__ __launch_bounds__(WAVES * 64) void wpatch_kernel(const WParams p) {
 
 static int wpatch_cout(const csmri_wgrad_desc* d) { return d->Cout <= 16 ? 16 : d->Cout; }
 static bool wpatch_eligible(const csmri_wgrad_desc* d) {
-  if (d->dtype != CSMRI_BF16 || d->stride != 1) return false;
+  // stride 2: the discriminator's first layer (one real input channel padded to 8; reference models/discriminators.py:137-150),
+  // which the generic row kernel ran at 8.6 TFLOP/s (62 us for 50 MB of operands)
+  if (d->dtype != CSMRI_BF16 || !(d->stride == 1 || (d->stride == 2 && d->Cin == 8 && !d->upsample && !d->in1))) return false;
   if (!(d->Cin == 8 || d->Cin == 32 || d->Cin == 64 || (d->Cin == 128 && d->Cout == 64))) return false;
   if (!(d->Cout == 8 || d->Cout == 16 || d->Cout == 32 || d->Cout == 64)) return false;
   if (d->KH * d->KW > 16 || d->KH < 1 || d->KW < 1) return false;
@@ -860,7 +863,7 @@ static int wpatch_groups(const csmri_wgrad_desc* d) {
 template <int CIN, int COUT, int WAVES>
 static int launch_wpatch(const WParams& p0, hipStream_t st, int qtiles = 1) {
   WParams p = p0;
-  const int TPW = 16 + p.KW - 1, TPH = 16 + p.KH - 1;
+  const int TPW = 15 * p.S + p.KW, TPH = 15 * p.S + p.KH;
   const int xrows = 1024 / (CIN / 8 * 16);
   const int one = ((TPH * TPW + xrows - 1) / xrows) * 1024 + 256 * COUT * 2;
   // two stages where two workgroups per CU still fit (<= 80 KiB each); the big-patch variants stay single-staged
@@ -1002,6 +1005,87 @@ static int wthin_launch(const WParams& p, const csmri_wgrad_desc* d, hipStream_t
   return CSMRI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Thin layer on a LARGE map: the weight gradient of a 1 x 1 convolution with one or two real output channels (U-Net head
+// 32 -> 1, reference models/unet.py:241 backward): dW[co][ci] = sum_m dY[m][co] x[m][ci], 42 MB of operands and 34 MFLOP.
+// wpatch ran it on MFMA tiles whose N side is that one channel: 52 us.  Here a thread owns one 16-byte chunk (8 channels)
+// of a pixel lane and streams its pixels in BATCHES of 8 loads (x chunk + the dY word) ahead of the arithmetic -- the
+// one-pixel-per-iteration form of wthin_out_kernel measured 76 us on this layer (a dependent L2 round trip per pixel).
+// Pixel lanes combine by wave shuffles, the four waves through LDS in fixed order; slabs and bias partial rows as wpatch.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CPR>
+__global__ __launch_bounds__(256) void whead_kernel(const WParams p, int want_db, int cout_real) {
+  constexpr int LANES = 256 / CPR, U = 8;
+  __shared__ float red[4][CPR][17];
+  __shared__ float redb[4][2];
+  const int q = threadIdx.x % CPR, pl = threadIdx.x / CPR;
+  const int z = blockIdx.x, Z = gridDim.x;
+  const int per = (p.M + Z - 1) / Z, m_begin = z * per, m_end = min(p.M, m_begin + per);
+  float acc[2][8], accb[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+  const char* xb = p.in0 + q * 16;
+  for (int m0 = m_begin; m0 < m_end; m0 += LANES * U) {
+    u32x4_t xr[U]; unsigned gr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = m0 + u * LANES + pl, mm = m < m_end ? m : m_begin;      // clamped: counted with a zero factor below
+      xr[u] = *(const u32x4_t*)(xb + (size_t)mm * p.ps0 * 2);
+      gr[u] = *(const unsigned*)(p.dy + (size_t)mm * p.dyps * 2);            // channels 0, 1 of the padded dY pixel
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float f = (m0 + u * LANES + pl) < m_end ? 1.f : 0.f;
+      const float g0 = __uint_as_float(gr[u] << 16) * f, g1 = __uint_as_float(gr[u] & 0xffff0000u) * f;
+      accb[0] += g0; accb[1] += g1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x0 = __uint_as_float(xr[u][i] << 16), x1 = __uint_as_float(xr[u][i] & 0xffff0000u);
+        acc[0][2 * i] += x0 * g0; acc[0][2 * i + 1] += x1 * g0;
+        acc[1][2 * i] += x0 * g1; acc[1][2 * i + 1] += x1 * g1;
+      }
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[0][j] += __shfl_xor(acc[0][j], o); acc[1][j] += __shfl_xor(acc[1][j], o); }
+    accb[0] += __shfl_xor(accb[0], o); accb[1] += __shfl_xor(accb[1], o);
+  }
+  if (lane < CPR) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[wave][lane][j] = acc[0][j]; red[wave][lane][8 + j] = acc[1][j]; }
+  }
+  if (lane == 0) { redb[wave][0] = accb[0]; redb[wave][1] = accb[1]; }
+  __syncthreads();
+  if ((int)threadIdx.x < CPR * 8 * cout_real) {
+    const int co = threadIdx.x / (CPR * 8), r = threadIdx.x % (CPR * 8), k = r / 8, j = r % 8;
+    p.slab[((size_t)z * p.Cout + co) * p.NK + k * 8 + j] =
+        red[0][k][co * 8 + j] + red[1][k][co * 8 + j] + red[2][k][co * 8 + j] + red[3][k][co * 8 + j];
+  }
+  if (want_db && (int)threadIdx.x < cout_real)
+    p.slab[(size_t)Z * p.Cout * p.NK + (size_t)z * p.Cout + threadIdx.x] =
+        redb[0][threadIdx.x] + redb[1][threadIdx.x] + redb[2][threadIdx.x] + redb[3][threadIdx.x];
+}
+static bool whead_eligible(const csmri_wgrad_desc* d) {
+  if (d->dtype != CSMRI_BF16 || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad_t || d->pad_l) return false;
+  if (d->Cout != 8 || d->Cout_real > 2 || d->in1 || d->upsample || !(d->Cin == 32 || d->Cin == 64)) return false;
+  if (d->Hin != d->Ho || d->Win != d->Wo) return false;
+  return (long long)d->B * d->Ho * d->Wo >= 65536;
+}
+static int whead_splits(const csmri_wgrad_desc* d) {
+  const long long M = (long long)d->B * d->Ho * d->Wo;
+  long long z = M / 2048; if (z > 256) z = 256; if (z < 1) z = 1;        // (the slab reduction sums z rows serially per element)
+  return (int)z;
+}
+static int whead_launch(const WParams& p, const csmri_wgrad_desc* d, hipStream_t st) {
+  if (d->Cin == 32) hipLaunchKernelGGL(whead_kernel<4>, dim3(p.splitk), dim3(256), 0, st, p, d->db ? 1 : 0, d->Cout_real);
+  else hipLaunchKernelGGL(whead_kernel<8>, dim3(p.splitk), dim3(256), 0, st, p, d->db ? 1 : 0, d->Cout_real);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+
 struct WConfig { int BP, BQ; };
 // geometries the row-aligned LDS-DMA kernel takes (64-pixel K steps aligned with output rows)
 static bool wgrad_row_aligned(const csmri_wgrad_desc* d) {
@@ -1026,6 +1110,7 @@ static int wgrad_ps(int dtype) { return dtype == CSMRI_BF16 ? 64 : 16; }
 #endif
 extern "C" int csmri_wgrad_suggest_splitk(const csmri_wgrad_desc* d) {
   if (wthin_out_eligible(d)) return wthin_splits(d);
+  if (whead_eligible(d)) return whead_splits(d);
   if (wrow_eligible(d)) return wrow_groups(d);
   if (wpatch_eligible(d)) return wpatch_groups(d);
   WConfig c = pick_wconfig(d);
@@ -1086,6 +1171,7 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
 extern "C" int csmri_wgrad_kernel_name(const csmri_wgrad_desc* d, char* buf, int n) {
   CSMRI_CHECK_ARG(d && buf && n > 0);
   if (wthin_out_eligible(d)) { snprintf(buf, n, "wthin_out_kernel"); return CSMRI_OK; }
+  if (whead_eligible(d)) { snprintf(buf, n, "whead_kernel<%d>", d->Cin / 8); return CSMRI_OK; }
   if (wrow_eligible(d)) { wrow_kernel_name(d, buf, n); return CSMRI_OK; }
   if (wpatch_eligible(d)) {
     snprintf(buf, n, "wpatch_kernel<%d, %d, %d>", d->Cin, d->Cin == 128 ? 32 : wpatch_cout(d),
@@ -1127,7 +1213,8 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // a split whose step range is empty still has to define its slab: zero everything first
   // when the split count does not divide evenly (cheap; slabs are small next to activations)
-  const bool thin = wthin_out_eligible(d);       // (write every slab entry they own themselves)
+  const bool head = whead_eligible(d);
+  const bool thin = wthin_out_eligible(d) || head;   // (write every slab entry they own themselves)
   if (!thin && (long long)p.steps_per_split * (p.splitk - 1) >= p.nsteps) {
     hipError_t e = hipMemsetAsync(d->slab, 0, (size_t)p.splitk * d->Cout * p.NK * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
@@ -1136,7 +1223,7 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
 #define WG(DT_, BP_, BQ_, WP_, WQ_) rc = launch_wgrad<DT_, BP_, BQ_, WP_, WQ_>(p, st)
   const bool patch = thin || wpatch_eligible(d) || wrow_eligible(d);   // (all leave their bias-gradient partial rows behind the slabs)
   if (thin) {
-    rc = wthin_launch(p, d, st);
+    rc = head ? whead_launch(p, d, st) : wthin_launch(p, d, st);
   } else if (patch) {
     WParams q = p;
     q.nsteps = d->db ? 1 : 0;                      // wpatch / wrow reuse the field: also produce the bias-gradient partials
@@ -1226,7 +1313,7 @@ extern "C" int csmri_wgrad_finish_multi(const csmri_wgrad_desc* descs, int n, vo
       t.Cout = d->Cout; t.NK = d->KH * d->KW * d->Cin; t.Cin = d->Cin; t.KH = d->KH; t.KW = d->KW;
       t.Cout_real = d->Cout_real; t.Cin_real = d->Cin_real; t.accumulate = d->accumulate;
       t.slab = d->slab; t.dw = d->dw;
-      const bool patch = wpatch_eligible(d) || wrow_eligible(d) || wthin_out_eligible(d) || d->defer_finish == 2;
+      const bool patch = wpatch_eligible(d) || wrow_eligible(d) || wthin_out_eligible(d) || whead_eligible(d) || d->defer_finish == 2;
       t.db = patch ? d->db : nullptr;                  // (other kernels: bias gradient already written by csmri_wgrad)
       t.part = d->slab + (size_t)t.splitk * d->Cout * t.NK; t.part_rows = t.splitk;
       long long nb = t.splitk <= 8 ? (long long)t.Cout_real * ((t.Cin_real + 63) / 64)

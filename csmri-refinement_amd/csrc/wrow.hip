@@ -260,8 +260,7 @@ static int wrow_seg(const csmri_wgrad_desc* d) {
 }
 bool wrow_eligible(const csmri_wgrad_desc* d) {
   if (d->dtype != CSMRI_BF16 || d->stride != 1 || d->KH != 4 || d->KW != 4) return false;
-  if (!(d->Cin == 32 || d->Cin == 64 || d->Cin == 128) || !(d->Cout == 32 || d->Cout == 64)) return false;
-  if (d->Cin == 128 && d->Cout != 64) return false;
+  if (!(d->Cin == 32 || d->Cin == 64 || d->Cin == 128) || !(d->Cout == 32 || d->Cout == 64 || d->Cout == 128)) return false;
   if (d->in1 && (d->c0 % 8)) return false;
   if (d->Wo % 32 || d->Ho < 64 || d->Wo < 64 || wrow_seg(d) == 0) return false;
   if (d->Ho != (d->upsample ? 2 * d->Hin : d->Hin) || d->Wo != (d->upsample ? 2 * d->Win : d->Win)) return false;   // SAME padding
