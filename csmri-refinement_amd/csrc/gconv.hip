@@ -399,7 +399,7 @@ extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int
   if (d->dtype == CSMRI_FP8) { gconv_fp8_kernel_name(d, buf, n); return CSMRI_OK; }
   if (thin_out1_eligible(d)) { thin_kernel_name(d, buf, n); return CSMRI_OK; }
   if (UCONV_BEFORE_PCONV2 && uconv_eligible(d)) { uconv_kernel_name(d, buf, n); return CSMRI_OK; }
-  if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3, 128>"); return CSMRI_OK; }
+  if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3, %d>", pconv2_bn(d)); return CSMRI_OK; }
   if (uconv_eligible(d)) { uconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (gconv_glds_eligible(d)) { gconv_glds_kernel_name(d, buf, n); return CSMRI_OK; }

@@ -61,6 +61,7 @@ void uconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
 
 // pconv2.hip
 int pconv2_eligible(const csmri_gconv_desc* d);
+int pconv2_bn(const csmri_gconv_desc* d);
 int pconv2_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
 
 // gconv_glds.hip

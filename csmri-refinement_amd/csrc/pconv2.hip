@@ -341,7 +341,13 @@ static int p2_plane(const csmri_gconv_desc* d) {
   return (npix * 16 + 255) & ~255;
 }
 
-static int p2_bn(const csmri_gconv_desc* d) { (void)d; return 128; }
+#ifndef P2_BN64_BELOW
+#define P2_BN64_BELOW 256      // fewer 128-channel tile blocks than CUs: 64-channel blocks, twice the workgroups (conv5 at batch 16: 51 -> 30 us, conv4 data gradients at batch 8: 50 -> 37 us; profiles/r05_pconv2_bn64.log)
+#endif
+static int p2_bn(const csmri_gconv_desc* d) {
+  const long long blocks128 = (long long)d->B * ((d->Ho + 15) / 16) * ((d->Wo + 15) / 16) * (d->Cout / 128);
+  return blocks128 < P2_BN64_BELOW ? 64 : 128;
+}
 #ifndef P2_CUS
 #define P2_CUS 256
 #endif
@@ -360,6 +366,7 @@ static void p2_grid(const csmri_gconv_desc* d, int* ntile, int* nb, int* workers
 #ifndef P2_MIN_BLOCKS
 #define P2_MIN_BLOCKS 64
 #endif
+int pconv2_bn(const csmri_gconv_desc* d) { return p2_bn(d); }
 int pconv2_eligible(const csmri_gconv_desc* d) {
   if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
   if (d->nclass > 1 || d->splitk > 1 || d->upsample || d->in1 || d->stats_partial || d->out_halo) return 0;
@@ -390,8 +397,13 @@ int pconv2_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) 
   p.mtiles = ntile; p.ntiles = nb;
   const int bn = p2_bn(d);
   const int lds = 2 * 8 * p2_plane(d) + 4 * bn * 128 + bn * 4;
-  CSMRI_SET_MAX_LDS((pconv2_kernel<3, 3, 128>), 160 * 1024);
-  hipLaunchKernelGGL((pconv2_kernel<3, 3, 128>), dim3(workers * nb), dim3(768), lds, st, p);
+  if (bn == 64) {
+    CSMRI_SET_MAX_LDS((pconv2_kernel<3, 3, 64>), 160 * 1024);
+    hipLaunchKernelGGL((pconv2_kernel<3, 3, 64>), dim3(workers * nb), dim3(768), lds, st, p);
+  } else {
+    CSMRI_SET_MAX_LDS((pconv2_kernel<3, 3, 128>), 160 * 1024);
+    hipLaunchKernelGGL((pconv2_kernel<3, 3, 128>), dim3(workers * nb), dim3(768), lds, st, p);
+  }
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

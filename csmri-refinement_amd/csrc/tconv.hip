@@ -31,7 +31,7 @@ typedef __attribute__((address_space(3))) void* tlptr_t;
 #define TCONV_CPS64 4      // 64 MFMAs per wave between barriers in the 64-channel, 64-output streamed loop
 #endif
 template <int CIN, int FN, bool STREAM>
-__global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GParams p) {
+__global__ __launch_bounds__(256, (CIN <= 32 && FN < 4) ? 4 : 2) void tconv_kernel(const GParams p) {
   constexpr int VPP = CIN / 8;                      // planes (16-byte chunks per pixel)
   constexpr int TPC = CIN >= 32 ? 1 : 32 / CIN;     // taps per K chunk
   constexpr int KCH = CIN >= 32 ? CIN / 32 : 1;     // K chunks per tap
@@ -121,6 +121,11 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
   for (int i = 0; i < FN; ++i)
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // bias of this lane's channel quads: in flight while the patch is staged (the epilogue adds it without a load)
+  f32x4_t bb[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+    bb[i] = (p.bias && n0 + i * 16 + g * 4 < p.Cout) ? *(const f32x4_t*)(p.bias + n0 + i * 16 + g * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // lane constants: fragment f = output row 4*wv+f, pixel r16; k-group g -> (plane, pixel shift)
   const int gplane = CIN >= 32 ? g : (g % VPP), gshift = CIN >= 32 ? 0 : g / VPP;
   int abase[4], wbase[FN];
@@ -191,39 +196,109 @@ __global__ __launch_bounds__(256, CIN <= 32 ? 4 : 2) void tconv_kernel(const GPa
   }
 
   T_STAMP(2);
-  // ---- epilogue (same contract as gconv) -----------------------------------------------------
+  // ---- epilogue (same contract as gconv).  Straight-line: the outputs leave through range-checked buffer stores (an
+  // invalid lane, or the other tensor of the windowed form, carries an offset past the descriptor's range), the bias was
+  // loaded at the top of the kernel, all gate loads of the tile are in flight before the first is used, and bf16 fragment
+  // pairs are exchanged between lane rows so that a lane stores 16 B.  (The common epilogue -- gconv_out_pos, one global load
+  // of bias / gate per fragment behind its own vmcnt(0), 8-byte stores under exec branches -- cost the first VGG layer 25 us.)
+  const int es = p.out_dt == CSMRI_F32 ? 4 : 2, ges = p.gdt == CSMRI_F32 ? 4 : 2;
+  const unsigned opx = (unsigned)p.B * (p.out2 ? p.win_h * p.win_w : p.Hout_t * p.Wout_t);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(opx * (unsigned)p.ops * es), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_halo = __builtin_amdgcn_make_buffer_rsrc(p.out2 ? p.out2 : p.out, 0,
+      (int)(p.out2 ? (unsigned)p.B * p.Hout_t * p.Wout_t * (unsigned)p.o2ps * es : 0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_gate = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gsrc ? p.gsrc : p.out), 0,
+      (int)(p.gsrc ? opx * (unsigned)p.gps * ges : 0u), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr bool PAIRS = FN % 2 == 0;                  // 16-byte stores need two fragments (32 channels)
+  const bool bf_out = p.out_dt != CSMRI_F32, has_gate = p.gsrc != nullptr, has_act = p.slope != 1.f, has_stats = p.stats != nullptr;
+  // channel offset of this lane inside a fragment (pair): own quad, or 8 consecutive channels after the exchange
+  const unsigned lch_own = (unsigned)(n0 + g * 4), lch_pair = (unsigned)(n0 + 8 * (g >> 1) + 16 * (g & 1));
   float s1[FN][4], s2[FN][4];
-  if (p.stats) {
 #pragma unroll
-    for (int i = 0; i < FN; ++i)
+  for (int i = 0; i < FN; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[i][r] = 0.f; s2[i][r] = 0.f; }
-  }
+    for (int r = 0; r < 4; ++r) { s1[i][r] = 0.f; s2[i][r] = 0.f; }
+  unsigned offo[4], offh[4], offg[4]; bool mvv[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const int oy = y0 + 4 * wv + f, ox = x0 + r16;
     const bool mv = oy < p.Ho && ox < p.Wo;
-    const OutPos op = gconv_out_pos(p, b, oy * p.osy + p.ooy, ox * p.osx + p.oox);
+    const int ty_ = oy * p.osy + p.ooy, tx_ = ox * p.osx + p.oox;
+    const unsigned fpix = (unsigned)((b * p.Hout_t + ty_) * p.Wout_t + tx_);
+    bool inside = true; unsigned opix = fpix;
+    if (p.out2) {
+      const int cy = ty_ - p.win_y0, cx = tx_ - p.win_x0;
+      inside = (unsigned)cy < (unsigned)p.win_h && (unsigned)cx < (unsigned)p.win_w;
+      opix = (unsigned)((b * p.win_h + cy) * p.win_w + cx);
+    }
+    mvv[f] = mv;
+    offo[f] = (mv && inside) ? opix * (unsigned)(p.ops * es) : OOB;
+    offh[f] = (mv && !inside) ? fpix * (unsigned)(p.o2ps * es) : OOB;
+    offg[f] = (mv && inside) ? opix * (unsigned)(p.gps * ges) : OOB;
+  }
+  f32x4_t gt[4][FN];
+  if (has_gate) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const unsigned go = offg[f] + (lch_own + i * 16) * ges;
+        if (p.gdt == CSMRI_F32) gt[f][i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_gate, (int)go, 0, 0));
+        else {
+          const u32x2_t u = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_gate, (int)go, 0, 0));
+          gt[f][i] = (f32x4_t){__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u),
+                               __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
+        }
+      }
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    f32x4_t vv[FN];
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
-      const int n = n0 + i * 16 + g * 4;
-      if (!(mv && n < p.Cout)) continue;
-      f32x4_t v = acc[i][f];
-      if (p.bias) v += *(const f32x4_t*)(p.bias + n);
-      if (p.stats) {
+      f32x4_t v = acc[i][f] + bb[i];
+      if (n0 + i * 16 + g * 4 >= p.Cout) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};        // channel blocks past Cout: nothing to add up
+      if (has_stats) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
+        for (int r = 0; r < 4; ++r) { const float q = mvv[f] ? v[r] : 0.f; s1[i][r] += q; s2[i][r] += q * q; }
       }
-      if (p.slope != 1.f) {
+      if (has_act) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * p.slope : v[r];
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], v[r] * p.slope);            // 0 <= slope <= 1 (tconv_eligible)
       }
-      if (p.gsrc && op.g_ok) {
-        f32x4_t gs = load4(p.gsrc, op.gpix + n, p.gdt);
+      if (has_gate) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gs[r] > 0.f ? v[r] : v[r] * p.gslope;
+        for (int r = 0; r < 4; ++r) v[r] = gt[f][i][r] > 0.f ? v[r] : v[r] * p.gslope;
       }
-      store4(op.base, op.opix + n, p.out_dt, v);
+      vv[i] = v;
+    }
+    if (bf_out) {
+      if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < FN; i += 2) {
+          const u32x2_t a = pack4_bf16(vv[i]), c = pack4_bf16(vv[i + 1]);
+          const auto x0_ = __builtin_amdgcn_permlane16_swap(a[0], c[0], false, false);
+          const auto x1_ = __builtin_amdgcn_permlane16_swap(a[1], c[1], false, false);
+          const u32x4_t d = (u32x4_t){x0_[0], x1_[0], x0_[1], x1_[1]};
+          const unsigned ch = (lch_pair + i * 16) * 2u;
+          const bool cok = n0 + i * 16 + 8 * (g >> 1) + 16 * (g & 1) < p.Cout;
+          __builtin_amdgcn_raw_buffer_store_b128(d, rs_out, (int)(cok ? offo[f] + ch : OOB), 0, 0);
+          if (p.out2) __builtin_amdgcn_raw_buffer_store_b128(d, rs_halo, (int)(cok ? offh[f] + ch : OOB), 0, 0);
+        }
+      } else {
+        const u32x2_t a = pack4_bf16(vv[0]);
+        const bool cok = n0 + g * 4 < p.Cout;
+        __builtin_amdgcn_raw_buffer_store_b64(a, rs_out, (int)(cok ? offo[f] + lch_own * 2u : OOB), 0, 0);
+        if (p.out2) __builtin_amdgcn_raw_buffer_store_b64(a, rs_halo, (int)(cok ? offh[f] + lch_own * 2u : OOB), 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const unsigned ch = (lch_own + i * 16) * 4u;
+        const bool cok = n0 + i * 16 + g * 4 < p.Cout;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vv[i]), rs_out, (int)(cok ? offo[f] + ch : OOB), 0, 0);
+        if (p.out2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vv[i]), rs_halo, (int)(cok ? offh[f] + ch : OOB), 0, 0);
+      }
     }
   }
   if (p.stats) {
@@ -265,6 +340,10 @@ int tconv_eligible(const csmri_gconv_desc* d) {
   if (d->TW % tpc) return 0;
   if (d->out_sy != 1 || d->out_sx != 1) return 0;
   if ((long long)d->Ho * d->Wo < TCONV_MIN_HW) return 0;        // small maps: generic / split-K path
+  if (!(d->act_slope >= 0.f && d->act_slope <= 1.f)) return 0;   // epilogue: max(v, slope v), 32-bit byte offsets
+  { const long long px = (long long)d->B * d->Hout_t * d->Wout_t;
+    if (px * d->out_pix_stride * 4 >= (1ll << 31) || px * (d->out_halo ? d->halo_pix_stride : 0) * 4 >= (1ll << 31) ||
+        px * (d->g_src ? d->g_pix_stride : 0) * 4 >= (1ll << 31)) return 0; }
   const size_t lds = (size_t)(d->Cin / 8) * ((tc_npix(d) + 63) / 64) * 1024;
   if (lds > 96 * 1024) return 0;
   return 1;

@@ -37,6 +37,8 @@ CASES = {
     'disc_final': (1024, 1, 4, 1, 'zero', False, 8, 8, 16),
     'disc_first': (1, 64, 4, 2, 'reflection', False, 256, 256, 16),
     'rec_last': (32, 2, 3, 1, 'zero', False, 256, 256, 8),
+    'vgg1_1': (3, 64, 3, 1, 'zero', False, 256, 256, 16),
+    'unet_first': (2, 32, 4, 1, 'reflection', False, 256, 256, 8),
     'd1cat': (128, 64, 4, 1, 'reflection', False, 128, 128, 8),
     'd1up': (128, 64, 4, 1, 'reflection', True, 64, 64, 8),
 }
