@@ -97,7 +97,10 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
   constexpr int ROWS = U_ROWS, NR = ROWS + TH - 1, PITCH = U_PITCH, NPC = U_NPC, PBUF = NPC * 1024;
   constexpr int WST = TH * NF * 1024, WOFF = 2 * PBUF;
   constexpr int NIT = NCH * TW;                     // iterations (chunk, tx) per pass
-  constexpr int RFIT = (U_LDS - 2 * PBUF) / WST, RINGN = RFIT >= NIT ? NIT : 4;
+  constexpr bool GATE = (MODE & U_GATE) != 0;
+  // (the gated form keeps 8 KiB of LDS for the gate bits: its weights stream)
+  constexpr int RFIT = (U_LDS - 2 * PBUF) / WST, RINGN = (RFIT >= NIT && !GATE) ? NIT : 4;
+  constexpr int GOFF = 2 * PBUF + RINGN * WST;      // gate bits: [strip][row][lane] words
   constexpr bool RESIDENT = RINGN == NIT;
   constexpr bool RTC = NCH > 2;                     // runtime chunk loop (code size): a block = one chunk's TW iterations
   constexpr int NITU = RTC ? TW : NIT;
@@ -105,9 +108,10 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
   // patch pieces a loader issues in slot j of a phase (streaming form; RESIDENT: all in slot 0)
   constexpr int PP0 = RESIDENT ? PPL : (TW == 3 ? 6 : 4), PP1 = RESIDENT ? 0 : (TW == 3 ? 5 : 4), PP2 = PPL - PP0 - PP1;
   constexpr bool STATS = (MODE & U_STATS) != 0, BIAS = (MODE & U_BIAS) != 0, WIN = (MODE & U_WIN) != 0;
-  static_assert((TH * NF) % 4 == 0 && (NF % 2) == 0 && TW >= 3 && TW <= 4 && TH >= 3 && NCH >= 1 && NCH <= 8, "shape");
+  static_assert((TH * NF) % 4 == 0 && (NF % 2) == 0 && TW >= 3 && TW <= 4 && TH >= 3 && NCH >= 1 && NCH <= 16, "shape");
   static_assert((U_TR + TH - 1) * PITCH <= NPC * 16 && U_TC + TW - 1 <= PITCH && (PITCH % 4) == 0 && NPC % 4 == 0, "patch");
-  static_assert(2 * PBUF + RINGN * WST <= U_LDS && RINGN >= 3, "LDS");
+  static_assert(2 * PBUF + RINGN * WST + (GATE ? 8192 : 0) <= U_LDS && RINGN >= 3, "LDS");
+  static_assert(!GATE || (!RESIDENT && TW == 3 && NF == 4), "gated form: streaming weights, 3 x 3, 64 channels");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -192,6 +196,45 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
         if (!(UCONV_ABLATE & 2)) __builtin_amdgcn_global_load_lds((ug_t)s, (ul_t)(dbase + k * 4096), 16, 0, 0);
       }
     };
+    // Gate bits (GATE): the activation-derivative gate of a data gradient -- out = g_src > 0 ? out : 0 (ReLU: VGG conv1_2,
+    // reference models/vgg.py:35 backward) -- costs the compute waves a global load per fragment (8 rows x 4 fragments per
+    // pass) exactly where they have no MFMAs left to hide it.  Loader L fetches the gate values of strip L one chunk ahead
+    // and leaves ONE 16-bit mask per (row, lane) in LDS; the epilogue reads a word and selects.
+    const __amdgpu_buffer_rsrc_t rs_gate = __builtin_amdgcn_make_buffer_rsrc((void*)(GATE ? p.gsrc : p.in0), 0,
+        (int)(GATE ? (unsigned)p.B * p.Hout_t * p.Wout_t * (unsigned)p.gps * 2u : 0u), 0x00020000);
+    u32x2_t graw[GATE ? U_ROWS : 1][GATE ? NF : 1];
+    auto gate_loads = [&](int pass) {                  // the gate values of this loader's strip of tile `pass`
+      const int g_ = lane >> 4, r16_ = lane & 15;
+      const bool sv = pass < npass;
+      const int tx_ = pass % TX, t_ = pass / TX, ty_ = t_ % TY, b = t_ / TY;
+      const int oy0 = ty_ * U_TR + (L >> 1) * ROWS, ox = tx_ * U_TC + (L & 1) * 16 + r16_;
+      const bool colv = sv && ox < p.Wo;
+      const unsigned pix0 = (unsigned)((b * p.Hout_t + oy0 + p.ooy) * p.Wout_t + ox + p.oox);
+      const unsigned lch = (unsigned)(n0 + g_ * 4) * 2u;
+#pragma unroll
+      for (int r = 0; r < U_ROWS; ++r) {
+        const unsigned off = (colv && oy0 + r < p.Ho) ? (pix0 + (unsigned)(r * p.Wout_t)) * (unsigned)(p.gps * 2) + lch : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+          graw[r][i] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_gate, (int)(off + i * 32), 0, 0));
+      }
+    };
+    auto gate_bits = [&]() {                           // 16 bits per (row, lane): bit 4 i + q = gate of channel 16 i + 4 g + q
+      unsigned* gb = (unsigned*)(smem + GOFF) + L * U_ROWS * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < U_ROWS; ++r) {
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned h = (q & 1) ? (graw[r][i][q >> 1] >> 16) : (graw[r][i][q >> 1] & 0xffffu);
+            m |= (((h - 1u) & 0xffffu) < 0x7f80u ? 1u : 0u) << (4 * i + q);      // bf16 value > 0 (not NaN)
+          }
+        gb[r * 64] = m;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
 #define U_IC(v_) std::integral_constant<int, (v_)>{}
     // prologue: patch of phase 0, the first stages (RESIDENT: all of them)
     U_STAMP_DECL;
@@ -229,11 +272,22 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
           if (i + RINGN >= NTOT) u_vmwait<0>();
           else if (j == TW - 1) u_vmwait<WPI>();
           else if (j == 0) { if (ph == 0) u_vmwait<2 * WPI>(); else u_vmwait<PP2 + 2 * WPI>(); }
-          else if (j == 1) { if (next_phase) u_vmwait<PP0 + 2 * WPI>(); else u_vmwait<2 * WPI>(); }
+          else if (j == 1) {
+            // (GATE: the 8 x NF gate loads of chunk 0's slot 0 are younger than stage i+1 too)
+            if (GATE && (ph % NCH) == 0 && next_phase) u_vmwait<PP0 + 2 * WPI + (GATE ? U_ROWS * NF : 0)>();
+            else if (next_phase) u_vmwait<PP0 + 2 * WPI>();
+            else u_vmwait<2 * WPI>();
+          }
           else { if (next_phase) u_vmwait<PP0 + PP1 + 2 * WPI>(); else u_vmwait<2 * WPI>(); }
           U_STAMP(3);                                  // waiting for DMA
           __builtin_amdgcn_s_barrier();                // B_i
           U_STAMP(4);                                  // waiting for the compute waves
+          if constexpr (GATE) {
+            // chunk 0, slot 0: this pass's gate values leave; chunk 1, slot 0: their masks go to LDS (published by the
+            // next barrier, one iteration before the pass's last, whose epilogue reads them)
+            if (j == 0 && (ph % NCH) == 0) gate_loads(worker + (ph / NCH) * workers);
+            if (j == 0 && (ph % NCH) == NCH - 1) gate_bits();
+          }
           if (next_phase) {
             if constexpr (j == 0) {
               if (cn == 0) tile_pixels(worker + ((ph + 1) / NCH) * workers);
@@ -355,6 +409,8 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
       const bool inside = cin_ && (!WIN || (unsigned)(cy0 + r) < (unsigned)e_wh);
       const unsigned offo = (mv && inside) ? ob0 + r * obr : OOB;
       const unsigned offh = (WIN && mv && !inside) ? hb0 + r * hbr : OOB;
+      unsigned gmask = 0xffffu;
+      if constexpr (GATE) gmask = ((const unsigned*)(smem + GOFF))[(wv * ROWS + r) * 64 + lane];
       u32x2_t pk[NF];
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
@@ -368,6 +424,10 @@ __global__ __launch_bounds__(512, 2) void uconv_kernel(const GParams p) {
         if constexpr (STATS) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) { const float vq = mv ? v[q] : 0.f; s1[i][q] += vq; s2[i][q] += vq * vq; }
+        }
+        if constexpr (GATE) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = (gmask >> (4 * i + q)) & 1u ? v[q] : 0.f;
         }
         pk[i] = pack4_bf16(v);
       }
@@ -512,7 +572,7 @@ static void u_grid(const csmri_gconv_desc* d, int* nstrips, int* sx, int* sy, in
 int uconv_eligible(const csmri_gconv_desc* d) {
   if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
   if (d->nclass > 1 || d->splitk > 1 || d->out_sy != 1 || d->out_sx != 1) return 0;
-  if (!(d->Cin == 32 || d->Cin == 64 || (d->Cin == 128 && d->TH == 4))) return 0;
+  if (!(d->Cin == 32 || d->Cin == 64 || d->Cin == 128 || (d->TH == 3 && (d->Cin == 256 || d->Cin == 512)))) return 0;
   if (d->in1 && (d->c0 % 32)) return 0;
   if (!(d->Cout == 32 || d->Cout % 64 == 0)) return 0;
   if ((long long)d->Ho * d->Wo < UCONV_MIN_HW) return 0;
@@ -526,7 +586,8 @@ int uconv_eligible(const csmri_gconv_desc* d) {
   if (!(mode & U_BIAS) && d->act_slope != 1.f) return 0;
   if ((mode & U_BIAS) && d->act_slope != 0.f) return 0;
   if (d->TH == 4 && d->TW == 4) return mode == 0 || mode == U_STATS || mode == U_WIN;
-  if (d->TH == 3 && d->TW == 3) return d->Cin == 64 && d->Cout % 64 == 0 && (mode == U_BIAS || mode == 0);
+  if ((mode & U_GATE) && d->g_slope != 0.f) return 0;           // gate bits: out = g_src > 0 ? out : 0
+  if (d->TH == 3 && d->TW == 3) return d->Cin >= 64 && d->Cout % 64 == 0 && (mode == U_BIAS || mode == U_GATE || mode == 0);
   return 0;
 }
 
@@ -541,8 +602,9 @@ int uconv_stats_rows(const csmri_gconv_desc* d0) {
 
 template <int TH, int TW, int NCH, int NF, int MODE>
 static int launch_uconv(const GParams& p, int grid, hipStream_t st) {
-  constexpr int WST = TH * NF * 1024, NIT = NCH * TW, RFIT = (U_LDS - 2 * U_NPC * 1024) / WST, RINGN = RFIT >= NIT ? NIT : 4;
-  constexpr int lds = 2 * U_NPC * 1024 + RINGN * WST;
+  constexpr bool GATE = (MODE & U_GATE) != 0;
+  constexpr int WST = TH * NF * 1024, NIT = NCH * TW, RFIT = (U_LDS - 2 * U_NPC * 1024) / WST, RINGN = (RFIT >= NIT && !GATE) ? NIT : 4;
+  constexpr int lds = 2 * U_NPC * 1024 + RINGN * WST + (GATE ? 8192 : 0);
   auto kern = uconv_kernel<TH, TW, NCH, NF, MODE>;
   CSMRI_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
@@ -574,8 +636,12 @@ int uconv_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
     if (nf == 2) UC(4, 4, 2, 0);
     UC(4, 4, 4, 0);
   }
-  if (mode == U_BIAS) UC(3, 2, 4, U_BIAS);
-  UC(3, 2, 4, 0);
+#define UC3(NCH_) do { if (mode == U_BIAS) UC(3, NCH_, 4, U_BIAS); if (mode == U_GATE) UC(3, NCH_, 4, U_GATE); UC(3, NCH_, 4, 0); } while (0)
+  if (nch == 2) UC3(2);
+  if (nch == 4) UC3(4);
+  if (nch == 8) UC3(8);
+  UC3(16);
+#undef UC3
 #undef UC
 }
 

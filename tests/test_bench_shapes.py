@@ -142,23 +142,49 @@ def test_bench_layer_vs_oracle_bf16(hip, case):
     xin = F.interpolate(xr, scale_factor=2, mode='nearest') if up else xr
     yr = F.conv2d(O.pad2d(xin, pads, mode), wr, br, stride=stride)
     ho, wo = yr.shape[2], yr.shape[3]
+    # the forward as the benchmarked step runs this layer family: U-Net / discriminator layers under BatchNorm -- no bias,
+    # BatchNorm partial sums out of the epilogue (reference models/unet.py:48, models/discriminators.py:140-143); VGG --
+    # bias + ReLU (models/vgg.py:35); the rest -- bias, no activation
+    bn = (name.startswith('unet') and name != 'unet_head') or (name.startswith('disc') and name[:5] not in ('disc1', 'disc_'))
+    vgg = name.startswith('vgg')
     if 'f' in checks:
-      y, _ = ops.conv_forward(layer, x0, x1, True, 1.0, False, None)
+      if bn:
+        y, st = ops.conv_forward(layer, x0, x1, False, 1.0, True, None)
+        ref = (yr - br.view(1, -1, 1, 1)).detach()
+      elif vgg:
+        y, st = ops.conv_forward(layer, x0, x1, True, 0.0, False, None)
+        ref = torch.relu(yr.detach())
+      else:
+        y, st = ops.conv_forward(layer, x0, x1, True, 1.0, False, None)
+        ref = yr.detach()
       torch.cuda.synchronize()
-      err = rel_l2(from_dev_nhwc(y, cout), yr.detach())
+      err = rel_l2(from_dev_nhwc(y, cout), ref)
       print('%-16s fwd   rel_l2 %.3e  %s' % (name, err, log[-1][1:]))
       assert err < 3e-3, (name, 'fwd', err)
       if y.shape[3] > cout:
         assert float(y[..., cout:].float().abs().max()) == 0.0
+      if bn:
+        # partial rows [2][Cout_pad][rows] of the fp32 accumulators: per-channel sum and sum of squares
+        part = st.reshape(2, layer.cout_p, -1).sum(-1).cpu()
+        s_ref, q_ref = ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))
+        e1 = float((part[0, :cout] - s_ref).abs().max() / (ref.abs().sum((0, 2, 3)).max() + 1e-30))
+        e2 = rel_l2(part[1, :cout], q_ref)
+        print('%-16s stats sum %.2e  sumsq %.2e' % (name, e1, e2))
+        assert e1 < 1e-4 and e2 < 1e-4, (name, 'stats', e1, e2)
     if 'd' in checks or 'w' in checks:
       gy = torch.randn(b, cout, ho, wo, generator=g).bfloat16().float()
       yr.backward(gy)
       gyd = to_dev_nhwc(gy, layer.cout_p)
       if 'd' in checks:
         n0 = len(log)
-        gx = ops.conv_dgrad(layer, gyd, (h, w))
+        if vgg:          # gated by the producer's ReLU (its output is this layer's input): models/vgg.py:35 backward
+          gx = ops.conv_dgrad(layer, gyd, (h, w), g_src=x0, g_slope=0.0)
+          gref = xr.grad * (x > 0).float()
+        else:
+          gx = ops.conv_dgrad(layer, gyd, (h, w))
+          gref = xr.grad
         torch.cuda.synchronize()
-        err = rel_l2(from_dev_nhwc(gx, cin), xr.grad)
+        err = rel_l2(from_dev_nhwc(gx, cin), gref)
         print('%-16s dgrad rel_l2 %.3e  %s' % (name, err, [e[1:] for e in log[n0:]]))
         assert err < 3e-3, (name, 'dgrad', err)
       if 'w' in checks:
