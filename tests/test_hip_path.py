@@ -1106,6 +1106,52 @@ def test_c2_recnet5_bf16_train_step_vs_oracle(env):
     assert agree >= 0.99, (k, agree)
 
 
+def test_c2_recnet5_bf16_b64_step_loss_and_psnr_vs_oracle(env):
+  """The C2 step at the batch size bench.py --config c2 runs (64 slices of 256 x 256; the 16-slice test above checks
+  every gradient, this one the sizes the persistent conv-block kernels and the 16-column DC strips only see at 64):
+  one Runner._train_step (reference training/runner.py:154-178), loss within 2e-3 relative and training PSNR within
+  0.01 dB of the fp32 CPU oracle's forward (O.recnet_forward + MSE, models/recnet.py:64-128) on the same weights, and a
+  second step on the same batch whose loss moved the way the oracle's step moves it (the update was applied)."""
+  Configuration, set_dtype = env
+  from training import build_runner
+  import utils
+  set_dtype('bf16')
+  conf = recnet_conf(Configuration, 5, 'bf16')
+  B = 64
+  conf.batch_size = B
+  utils.set_random_seeds(conf.seed)
+  runner = build_runner(conf, 'standard', '0', 'train')
+  P0 = {k: v.detach().cpu().clone() for k, v in runner.model.state_dict().items()}
+  batch = O.synth_batch(B, 256, 256, acc=4, seed=6464)
+  from csmri_hip import ops
+  log = ops.LAUNCH_LOG = []
+  try:
+    losses, metrics = runner.train_epoch(Loader([batch]), 1)
+    torch.cuda.synchronize()
+  finally:
+    ops.LAUNCH_LOG = None
+  kinds = [e[1] for e in log if e[0] == 'convblock']
+  assert kinds.count('convblock_fwd_kernel<true>') == 5 and kinds.count('convblock_bwd_kernel') == 5, kinds
+  with torch.no_grad():
+    pred = O.recnet_forward(P0, batch['inp'], batch['kspace'], batch['mask'], 5, 3)
+    ref_loss = float(torch.nn.functional.mse_loss(pred, batch['target']))
+    ref_psnr = O.psnr_batch(pred, batch['target'])
+  rel = abs(losses['loss_MSE'].value - ref_loss) / ref_loss
+  dpsnr = abs(metrics['psnr'].value - ref_psnr)
+  print('C2 bf16 B=64 step: loss hip %.7e oracle %.7e rel %.3e; psnr hip %.4f oracle %.4f (delta %.4f dB)' %
+        (losses['loss_MSE'].value, ref_loss, rel, metrics['psnr'].value, ref_psnr, dpsnr))
+  assert rel < 2e-3 and dpsnr < 0.01, (rel, dpsnr)
+  # the update: every parameter moved by at most ~lr (Adam's first step), and the next step's loss is lower
+  lr = conf.optimizer['learning_rate']
+  cur = runner.model.state_dict()
+  moved = max(float((cur[k].cpu() - P0[k]).abs().max()) for k in P0)
+  assert 0.5 * lr < moved < 1.5 * lr, (moved, lr)
+  losses2, _ = runner.train_epoch(Loader([batch]), 2)
+  torch.cuda.synchronize()
+  print('C2 bf16 B=64 second step: loss %.7e -> %.7e' % (losses['loss_MSE'].value, losses2['loss_MSE'].value))
+  assert losses2['loss_MSE'].value < losses['loss_MSE'].value
+
+
 @pytest.mark.parametrize('scale', [0.02, 0.25])
 def test_bf16_psnr_where_the_unet_contributes(env, scale):
   """The 0.01 dB criterion with the U-Net switched ON (SURVEY A-10: at the reference's
