@@ -59,6 +59,7 @@ def run(name, mode='fwd', iters=20):
   gy = torch.randn_like(y)
   fn = {'fwd': lambda: ops.conv_forward(layer, x, None, False),
         'fwdb': lambda: ops.conv_forward(layer, x, None, True, 0.0),          # bias + ReLU (the VGG forward)
+        'fwds': lambda: ops.conv_forward(layer, x, None, False, 1.0, True),   # BatchNorm partial sums (the U-Net forward)
         'dgrad': lambda: ops.conv_dgrad(layer, gy, (h, w)),
         'dgradg': lambda: ops.conv_dgrad(layer, gy, (h, w), g_src=x, g_slope=0.0),   # gated by the producer's ReLU (VGG backward)
         'wgrad': lambda: ops.conv_wgrad(layer, x, None, gy)}[mode]
@@ -78,7 +79,7 @@ def run(name, mode='fwd', iters=20):
 
 if __name__ == '__main__':
   names = [a for a in sys.argv[1:] if a in CASES] or list(CASES)
-  modes = [a for a in sys.argv[1:] if a in ('fwd', 'fwdb', 'dgrad', 'dgradg', 'wgrad')] or ['fwd']
+  modes = [a for a in sys.argv[1:] if a in ('fwd', 'fwdb', 'fwds', 'dgrad', 'dgradg', 'wgrad')] or ['fwd']
   for n in names:
     for m in modes:
       run(n, m)
