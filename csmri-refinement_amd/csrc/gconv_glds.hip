@@ -15,6 +15,8 @@
 // Needs Cin % 64 == 0 (a K step never straddles a tap) and Cout % BN == 0; everything else goes
 // to gconv.hip.  Epilogue (bias / leaky / act-derivative / BN partial sums / split-K slab) is the
 // one of gconv.hip.
+#include <algorithm>
+#include <type_traits>
 #include "mma_core.h"
 #include "gconv_params.h"
 
@@ -257,55 +259,125 @@ __global__ __launch_bounds__(64 * NW, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gc
   }
 #endif
   // ---- epilogue (same contract as gconv_kernel) --------------------------------------------
-  float s1[FN][4], s2[FN][4];
-  if (p.stats) {
+  // Straight-line since round 5, like pconv2 / tconv / uconv: the outputs leave through range-checked buffer stores (an
+  // invalid lane -- tile rows past M, the other tensor of the windowed form -- carries an offset past the descriptor's
+  // range and is dropped by the hardware), a fragment row's gate values are loaded as one batch, bf16 fragment pairs are
+  // exchanged between lane rows so that a lane stores 16 B.  The old form (gconv_out_pos with the per-lane choice of
+  // p.out / p.out2 -- compiled into vector loads of the kernel arguments --, 8-byte stores under exec branches) cost a
+  // short-K tile more than its K loop: the stride-2 data gradients of the discriminator's first layers run 8-16 steps
+  // per workgroup.
+  const int r16e = lane & 15, ge = lane >> 4;
+  if (p.splitk > 1) {
+    // a split launch stores slab rows indexed by m: no output position needed
 #pragma unroll
-    for (int i = 0; i < FN; ++i)
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0 + wm * WTM + j * 16 + r16e;
+      if (m < p.M) {
+        float* row = p.slab + (((size_t)cls * p.splitk + ks) * p.M + m) * p.Cout + n0 + wn * WTN + ge * 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[i][r] = 0.f; s2[i][r] = 0.f; }
+        for (int i = 0; i < FN; ++i) *(f32x4_t*)(row + i * 16) = acc[i][j];
+      }
+    }
+    return;
   }
+  const int es = p.out_dt == CSMRI_F32 ? 4 : 2, ges = p.gdt == CSMRI_F32 ? 4 : 2;
+  const unsigned opx = (unsigned)p.B * (p.out2 ? p.win_h * p.win_w : p.Hout_t * p.Wout_t);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(opx * (unsigned)p.ops * es), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_halo = __builtin_amdgcn_make_buffer_rsrc(p.out2 ? p.out2 : p.out, 0,
+      (int)(p.out2 ? (unsigned)p.B * p.Hout_t * p.Wout_t * (unsigned)p.o2ps * es : 0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_gate = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gsrc ? p.gsrc : p.out), 0,
+      (int)(p.gsrc ? opx * (unsigned)p.gps * ges : 0u), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(FN % 2 == 0, "16-byte stores pair two channel fragments");
+  const bool bf_out = p.out_dt != CSMRI_F32, has_gate = p.gsrc != nullptr, has_act = p.slope != 1.f, has_stats = p.stats != nullptr;
+  const int nb = n0 + wn * WTN;
+  const unsigned lch_own = (unsigned)(nb + ge * 4), lch_pair = (unsigned)(nb + 8 * (ge >> 1) + 16 * (ge & 1));
+  f32x4_t bb[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) bb[i] = p.bias ? *(const f32x4_t*)(p.bias + nb + i * 16 + ge * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // (two copies of the tile loop, with and without the BatchNorm sums: their 2 x FN x 4 accumulators next to the gate
+  //  batch spilled the three-workgroups-per-CU instance)
+  auto tile_out = [&](auto stats_c) {
+  constexpr bool STATS = decltype(stats_c)::value;
+  float s1[STATS ? FN : 1][4], s2[STATS ? FN : 1][4];
+#pragma unroll
+  for (int i = 0; i < (STATS ? FN : 1); ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[i][r] = 0.f; s2[i][r] = 0.f; }
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
-    const int m = m0 + wm * WTM + j * 16 + r16;
+    const int m = m0 + wm * WTM + j * 16 + r16e;
     const bool mv = m < p.M;
-    OutPos op; op.base = p.out; op.opix = 0; op.gpix = 0; op.g_ok = true;
-    if (mv && p.splitk == 1) {         // (a split launch stores slab rows indexed by m: no output position needed)
-      if (p.dense_out) {               // position index == m: no decomposition
-        op.opix = (size_t)m * p.ops; op.gpix = (size_t)m * p.gps;
-      } else {
-        int b, oy, ox;
-        if (p.howo_shift >= 0) { b = m >> p.howo_shift; const int r = m & (HoWo - 1); oy = r >> p.wo_shift; ox = r & (p.Wo - 1); }
-        else { b = m / HoWo; const int r = m - b * HoWo; oy = r / p.Wo; ox = r - oy * p.Wo; }
-        op = gconv_out_pos(p, b, oy * p.osy + ooy, ox * p.osx + oox);
+    unsigned fpix = (unsigned)m, opix = (unsigned)m;
+    bool inside = true;
+    if (!p.dense_out) {
+      int b, oy, ox;
+      if (p.howo_shift >= 0) { b = m >> p.howo_shift; const int r = m & (HoWo - 1); oy = r >> p.wo_shift; ox = r & (p.Wo - 1); }
+      else { b = m / HoWo; const int r = m - b * HoWo; oy = r / p.Wo; ox = r - oy * p.Wo; }
+      const int ty_ = oy * p.osy + ooy, tx_ = ox * p.osx + oox;
+      fpix = (unsigned)((b * p.Hout_t + ty_) * p.Wout_t + tx_); opix = fpix;
+      if (p.out2) {
+        const int cy = ty_ - p.win_y0, cx = tx_ - p.win_x0;
+        inside = (unsigned)cy < (unsigned)p.win_h && (unsigned)cx < (unsigned)p.win_w;
+        opix = (unsigned)((b * p.win_h + cy) * p.win_w + cx);
       }
     }
+    const unsigned offo = (mv && inside) ? opix * (unsigned)(p.ops * es) : OOB;
+    const unsigned offh = (mv && !inside) ? fpix * (unsigned)(p.o2ps * es) : OOB;
+    f32x4_t gt[FN];
+    if (!STATS && has_gate) {
+      const unsigned offg = (mv && inside) ? opix * (unsigned)(p.gps * ges) : OOB;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const unsigned go = offg + (lch_own + i * 16) * ges;
+        if (p.gdt == CSMRI_F32) gt[i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_gate, (int)go, 0, 0));
+        else {
+          const u32x2_t u = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs_gate, (int)go, 0, 0));
+          gt[i] = (f32x4_t){__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u),
+                            __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
+        }
+      }
+    }
+    f32x4_t vv[FN];
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
-      const int n = n0 + wn * WTN + i * 16 + g * 4;
-      f32x4_t v = acc[i][j];
-      if (p.splitk > 1) {
-        if (mv) *(f32x4_t*)(p.slab + (((size_t)cls * p.splitk + ks) * p.M + m) * p.Cout + n) = v;
-        continue;
-      }
-      if (!mv) continue;
-      if (p.bias) { f32x4_t bb = *(const f32x4_t*)(p.bias + n); v += bb; }
-      if (p.stats) {
+      f32x4_t v = acc[i][j] + bb[i];
+      if constexpr (STATS) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
+        for (int r = 0; r < 4; ++r) { const float q = mv ? v[r] : 0.f; s1[i][r] += q; s2[i][r] += q * q; }
       }
-      if (p.slope != 1.f) {
+      if (has_act) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * p.slope : v[r];
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], v[r] * p.slope);            // 0 <= slope <= 1 (gconv_glds_eligible)
       }
-      if (p.gsrc && op.g_ok) {
-        f32x4_t gs = load4(p.gsrc, op.gpix + n, p.gdt);
+      if (!STATS && has_gate) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gs[r] > 0.f ? v[r] : v[r] * p.gslope;
+        for (int r = 0; r < 4; ++r) v[r] = gt[i][r] > 0.f ? v[r] : v[r] * p.gslope;
       }
-      store4(op.base, op.opix + n, p.out_dt, v);
+      vv[i] = v;
     }
+    if (bf_out) {
+#pragma unroll
+      for (int i = 0; i < FN; i += 2) {
+        const u32x2_t a = pack4_bf16(vv[i]), c = pack4_bf16(vv[i + 1]);
+        const auto x0_ = __builtin_amdgcn_permlane16_swap(a[0], c[0], false, false);
+        const auto x1_ = __builtin_amdgcn_permlane16_swap(a[1], c[1], false, false);
+        const u32x4_t d = (u32x4_t){x0_[0], x1_[0], x0_[1], x1_[1]};
+        const unsigned ch = (lch_pair + i * 16) * 2u;
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs_out, (int)(offo == OOB ? OOB : offo + ch), 0, 0);
+        if (p.out2) __builtin_amdgcn_raw_buffer_store_b128(d, rs_halo, (int)(offh == OOB ? OOB : offh + ch), 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const unsigned ch = (lch_own + i * 16) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vv[i]), rs_out, (int)(offo == OOB ? OOB : offo + ch), 0, 0);
+        if (p.out2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vv[i]), rs_halo, (int)(offh == OOB ? OOB : offh + ch), 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // (one fragment row at a time: hoisted, the four rows' offsets and gates spill)
   }
-  if (p.stats && p.splitk == 1) {
+  if constexpr (STATS) {
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -313,14 +385,16 @@ __global__ __launch_bounds__(64 * NW, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gc
         float a = s1[i][r], b = s2[i][r];
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-        const int n = n0 + wn * WTN + i * 16 + g * 4 + r;
-        if (r16 == 0) {
+        const int n = nb + i * 16 + ge * 4 + r;
+        if (r16e == 0) {
           // partial sums are channel-major: [2][Cout][rows], rows = mtiles * WM (finalize reads coalesced)
           const size_t R = (size_t)p.mtiles * WM, r = (size_t)mt * WM + wm;
           p.stats[(size_t)n * R + r] = a; p.stats[((size_t)p.Cout + n) * R + r] = b;
         }
       }
   }
+  };
+  if (has_stats) tile_out(std::true_type{}); else tile_out(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,6 +406,12 @@ int gconv_glds_eligible(const csmri_gconv_desc* d) {
   if (d->in1 && d->c0 % 64) return 0;
   if (d->in0_pix_stride % 8 || (d->in1 && d->in1_pix_stride % 8)) return 0;
   if (d->TH * d->TW > 16) return 0;                     // rows of the source-pixel table
+  // epilogue: max(v, slope v); 32-bit byte offsets into the output / halo / gate tensors (buffer descriptors)
+  if (!(d->act_slope >= 0.f && d->act_slope <= 1.f)) return 0;
+  const long long out_px = (long long)d->B * d->Hout_t * d->Wout_t;
+  const long long widest = std::max((long long)d->out_pix_stride, std::max((long long)(d->out_halo ? d->halo_pix_stride : 0),
+                                                                           (long long)(d->g_src ? d->g_pix_stride : 0)));
+  if (out_px * widest * 4 >= (1ll << 31)) return 0;
   return 1;
 }
 

@@ -83,8 +83,13 @@ __device__ __forceinline__ void u_lgkm(u32x4_t& f) { asm volatile("s_waitcnt lgk
 #ifdef CSMRI_DBG_STAMPS
 #define U_NOW(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define U_STAMP(i) do { unsigned long long t_; U_NOW(t_); stp[i] += t_ - last_t; last_t = t_; } while (0)
-#define U_STAMP_DECL unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_t; U_NOW(last_t)
-#define U_STAMP_DUMP do { if (lane == 0 && p.slab) { unsigned long long* dbg_ = (unsigned long long*)p.slab + ((size_t)blockIdx.x * 8 + wv) * 8; \
+// (slots 6, 7: the wave's whole life in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime): their ratio is
+//  the clock the chip held, MI355X_MICROARCH.md 'DVFS give-back' item 6)
+#define U_STAMP_DECL unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_t, c0_, r0_; U_NOW(last_t); c0_ = last_t; \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0_) :: "memory")
+#define U_STAMP_DUMP do { unsigned long long c1_, r1_; U_NOW(c1_); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1_) :: "memory"); \
+    stp[6] = c1_ - c0_; stp[7] = r1_ - r0_; \
+    if (lane == 0 && p.slab) { unsigned long long* dbg_ = (unsigned long long*)p.slab + ((size_t)blockIdx.x * 8 + wv) * 8; \
     for (int i_ = 0; i_ < 8; ++i_) dbg_[i_] = stp[i_]; } } while (0)
 #else
 #define U_STAMP(i) do {} while (0)

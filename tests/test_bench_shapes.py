@@ -177,7 +177,9 @@ def test_bench_layer_vs_oracle_bf16(hip, case):
       gyd = to_dev_nhwc(gy, layer.cout_p)
       if 'd' in checks:
         n0 = len(log)
-        if vgg:          # gated by the producer's ReLU (its output is this layer's input): models/vgg.py:35 backward
+        # VGG conv*_2 (.._3, .._4): gated by the producer's ReLU, whose output is this layer's input (models/vgg.py:35
+        # backward); conv*_1 follow a max-pool (the pool's backward applies the ReLU derivative) or the image: plain
+        if vgg and not name.split('_')[1] == '1':
           gx = ops.conv_dgrad(layer, gyd, (h, w), g_src=x0, g_slope=0.0)
           gref = xr.grad * (x > 0).float()
         else:

@@ -41,6 +41,16 @@ CASES = {
     'unet_first': (2, 32, 4, 1, 'reflection', False, 256, 256, 8),
     'd1cat': (128, 64, 4, 1, 'reflection', False, 128, 128, 8),
     'd1up': (128, 64, 4, 1, 'reflection', True, 64, 64, 8),
+    # discriminator layers 2-6 at the 16-image (D-phase backward), 8-image (generator-phase data gradient) and 24-image (forward) batches
+    'dl2b16': (64, 128, 4, 2, 'reflection', False, 128, 128, 16), 'dl3b16': (128, 256, 4, 2, 'reflection', False, 64, 64, 16),
+    'dl4b16': (256, 512, 4, 2, 'reflection', False, 32, 32, 16), 'dl5b16': (512, 1024, 4, 2, 'reflection', False, 16, 16, 16),
+    'dl6b16': (1024, 1024, 4, 1, 'reflection', False, 8, 8, 16),
+    'dl2b8': (64, 128, 4, 2, 'reflection', False, 128, 128, 8), 'dl3b8': (128, 256, 4, 2, 'reflection', False, 64, 64, 8),
+    'dl4b8': (256, 512, 4, 2, 'reflection', False, 32, 32, 8), 'dl5b8': (512, 1024, 4, 2, 'reflection', False, 16, 16, 8),
+    'dl6b8': (1024, 1024, 4, 1, 'reflection', False, 8, 8, 8),
+    'dl2b24': (64, 128, 4, 2, 'reflection', False, 128, 128, 24), 'dl3b24': (128, 256, 4, 2, 'reflection', False, 64, 64, 24),
+    'dl4b24': (256, 512, 4, 2, 'reflection', False, 32, 32, 24), 'dl5b24': (512, 1024, 4, 2, 'reflection', False, 16, 16, 24),
+    'dl6b24': (1024, 1024, 4, 1, 'reflection', False, 8, 8, 24),
 }
 
 

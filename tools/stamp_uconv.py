@@ -31,7 +31,8 @@ pads = (t // 2, t - t // 2, t // 2, t - t // 2)
 wt = torch.nn.Parameter((torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)).cuda())
 layer = ops.ConvLayer(wt, None, 1, pads, border, torch.bfloat16)
 x = torch.randn(b, h, h, cin, device='cuda').bfloat16()
-for _ in range(5):
+# UCONV_STAMP_WARM launches before the stamped one (default 5; a few thousand = the clock the chip holds under the sustained load)
+for _ in range(int(os.environ.get('UCONV_STAMP_WARM', '5'))):
   ops.conv_forward(layer, x, None, False, want_stats=want_stats)
 torch.cuda.synchronize()
 dbg.zero_()
@@ -41,7 +42,10 @@ v = dbg.view(-1, 8, 8).double().cpu()
 used = (v.sum((1, 2)) > 0)
 v = v[used]
 print(patched.name, 'workgroups', v.shape[0], 'launch %.1f us' % (e0.elapsed_time(e1) * 1e3))
-comp, load = v[:, :4, :], v[:, 4:, :]
+comp, load = v[:, :4, :6], v[:, 4:, :6]
+clk = (v[:, :4, 6] / v[:, :4, 7].clamp(min=1)).median() * 100.0           # MHz: shader cycles per 100 MHz tick
+life = v[:, :4, 7].median() / 100.0
+print('  in-kernel clock %.0f MHz (s_memtime / s_memrealtime, median over compute waves); a compute wave lives %.1f us' % (float(clk), float(life)))
 for i, n in enumerate(['wait for first patch + stage', 'multiplying (between barriers)', 'at the barrier', 'pass tail: MFMAs + epilogue']):
   print('  compute  %-34s %9.0f cycles (mean over waves; max %9.0f)' % (n, float(comp[:, :, i].mean()), float(comp[:, :, i].max())))
 print('  compute  total %9.0f' % float(comp.sum(2).mean()))
