@@ -27,6 +27,12 @@ _lib = C.CDLL(LIB_PATH)
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
+ABI = 102           # csmri_version() of the library these structures mirror (102: csmri_gconv_desc.out_q .. out_amax)
+_lib.csmri_version.restype = C.c_int
+if _lib.csmri_version() != ABI:
+  raise RuntimeError('%s reports ABI %d, this binding is for %d: rebuild the library (python __graft_entry__.py)'
+                     % (LIB_PATH, _lib.csmri_version(), ABI))
+
 
 class GConvDesc(C.Structure):
   _fields_ = [
@@ -50,6 +56,7 @@ class GConvDesc(C.Structure):
       ('win_w', i32),
       ('in_dequant', vp), ('w_dequant', vp),
       ('cin_real', i32), ('cout_real', i32),
+      ('out_q', vp), ('out_q_pix_stride', i32), ('out_q_scale', vp), ('out_amax', vp),
   ]
 
 
@@ -173,6 +180,8 @@ _SIGS = {
                                  vp, vp, i32, vp]),
     'csmri_act_bwd': (i32, [i32, vp, i32, vp, i32, vp, i32, i64, i32, f32, vp, i32, vp]),
     'csmri_maxpool2': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    'csmri_maxpool2_q': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
+    'csmri_fp8_scales_update': (i32, [vp, vp, i32, i32, vp]),
     'csmri_maxpool2_bwd': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     'csmri_maxpool2_bwd_act': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i32, f32, vp, i32, vp]),
     'csmri_complex_abs': (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),

@@ -1342,12 +1342,18 @@ class ConvBnActReplay(torch.autograd.Function):
     return ConvBnAct.backward(ctx, gz, gz2)[:5] + (None,) * 10
 
 
-def maxpool2_fwd(x):
-  """MaxPool2d(2,2) on NHWC; returns (y, argmax uint8)."""
+def maxpool2_fwd(x, q_scale_ptr=0, amax_ptr=0, want_q=False):
+  """MaxPool2d(2,2) on NHWC; returns (y, argmax uint8), or (y, argmax, y_q) when an fp8 copy of y (csmri_maxpool2_q:
+  scale at device address ``q_scale_ptr``) and / or the running |y| maximum (``amax_ptr``) is asked for."""
   x = as_nhwc(x)
   b, h, w, c = x.shape
   y = torch.empty(b, h // 2, w // 2, c, dtype=x.dtype, device=x.device)
   arg = torch.empty(b, h // 2, w // 2, c, dtype=torch.uint8, device=x.device)
+  if want_q or amax_ptr:
+    yq = torch.empty(b, h // 2, w // 2, c, dtype=torch.uint8, device=x.device) if want_q else None
+    lib.call('csmri_maxpool2_q', dt_of(x), x.data_ptr(), x.stride(2), y.data_ptr(), y.stride(2),
+             arg.data_ptr(), b, h, w, c, ptr(yq), c, q_scale_ptr if want_q else 0, amax_ptr, stream())
+    return y, arg, yq
   lib.call('csmri_maxpool2', dt_of(x), x.data_ptr(), x.stride(2), y.data_ptr(), y.stride(2),
            arg.data_ptr(), b, h, w, c, stream())
   return y, arg
@@ -1410,6 +1416,96 @@ class MaxPool2Skip(torch.autograd.Function):
     return maxpool2_bwd(gy, arg, ctx.shape, g_add=gskip)
 
 
+class Fp8Chain(object):
+  """fp8 (e4m3fn) forward of a frozen conv / ReLU / max-pool stack with DELAYED scaling (BASELINE config 5: the VGG19
+  perceptual loss is half the step's FLOPs and its weights never change).  Every 3 x 3 layer with a multiple of 128 input
+  channels reads an fp8 copy of its input that the PRODUCING kernel's epilogue wrote (csmri_gconv_desc.out_q /
+  csmri_maxpool2_q: no quantisation pass) and fp8 weights quantised once; outputs, saved activations and the whole
+  backward stay bf16.  The scale of tensor j at step t is derived from the |x| maximum the producers accumulated at step
+  t - 1 (csmri_fp8_scales_update, one tiny launch per forward); the first forward runs in bf16 and only collects the
+  maxima.  ``margin``: bits of headroom kept above last step's maximum."""
+
+  def __init__(self, plan, device, margin=1):
+    self.slots = {}                       # plan index of the producer -> slot of its output tensor
+    convs = [i for i, it in enumerate(plan) if it[0] == 'conv']
+    for i in convs:
+      if self.layer_ok(plan[i][1]) and i > 0:
+        self.slots[i - 1] = len(self.slots)        # the item in front of an fp8 layer produces its input
+    n = max(1, len(self.slots))
+    self.amax = torch.zeros(n, dtype=torch.float32, device=device)
+    self.scales = torch.ones(n, 2, dtype=torch.float32, device=device)
+    self.margin = int(margin)
+    self.ready = False                    # True once a forward has left scales behind
+    self.disabled = not self.slots
+    self.steps = 0
+
+  @staticmethod
+  def layer_ok(layer):
+    return (layer.frozen and layer.dtype == torch.bfloat16 and layer.kh == 3 and layer.kw == 3 and layer.stride == 1 and
+            not layer.upsample and layer.border == BORDER_ZERO and layer.cin_p % 128 == 0 and layer.cout_p % 128 == 0)
+
+  def q_scale_ptr(self, slot):
+    return self.scales.data_ptr() + 8 * slot
+
+  def dq_scale_ptr(self, slot):
+    return self.scales.data_ptr() + 8 * slot + 4
+
+  def amax_ptr(self, slot):
+    return self.amax.data_ptr() + 4 * slot
+
+  def finish(self):
+    """End of a forward: this pass's maxima become the next pass's scales."""
+    lib.call('csmri_fp8_scales_update', self.amax.data_ptr(), self.scales.data_ptr(), len(self.slots), self.margin,
+             stream())
+    self.ready = True
+    self.steps += 1
+
+
+def frozen_conv_forward(layer, x, slope, xq=None, dq_ptr=0, out_slot=None, chain=None):
+  """Bias + ReLU forward of one layer of a frozen stack: conv_forward, plus (chain given) fp8 operands when ``xq`` (the
+  fp8 copy of x, dequantisation scale at ``dq_ptr``) is given, and an fp8 copy / the |y| maximum of the output for slot
+  ``out_slot``.  Returns (y, y_q or None)."""
+  if chain is None or (xq is None and out_slot is None):
+    return conv_forward(layer, x, None, True, slope, False, None)[0], None
+  _need_gpu(x)
+  b, h, w, _ = x.shape
+  ho, wo = layer.out_hw(h, w)
+  y = torch.empty(b, ho, wo, layer.cout_p, dtype=layer.dtype, device=x.device)
+  pl, pr, pt, pb = layer.pads
+  d = lib.GConvDesc()
+  keep = None
+  if xq is not None:
+    wq, kp, wsc = layer._pack_fp8()
+    keep = (wq, wsc)
+    d.dtype, d.in0, d.in0_pix_stride = FP8, xq.data_ptr(), xq.stride(2)
+    d.in_dequant, d.w_dequant = dq_ptr, wsc.data_ptr() + 8
+    wp = wq
+  else:
+    wp, kp, _, _ = layer._pack(0)
+    d.dtype, d.in0, d.in0_pix_stride = dt_of(x), x.data_ptr(), x.stride(2)
+  d.out_dtype = dt_of(y)
+  d.B, d.Hin, d.Win, d.Cin = b, h, w, layer.cin_p
+  d.upsample, d.border = 0, layer.border
+  d.TH, d.TW, d.in_s = layer.kh, layer.kw, layer.stride
+  d.dy0, d.dy_step, d.dx0, d.dx_step = -pt, 1, -pl, 1
+  d.w, d.Kp, d.nclass, d.w_class_stride = wp.data_ptr(), kp, 1, 0
+  d.out, d.out_pix_stride, d.Hout_t, d.Wout_t = y.data_ptr(), y.stride(2), ho, wo
+  d.Ho, d.Wo, d.out_sy, d.out_sx, d.out_oy, d.out_ox = ho, wo, 1, 1, 0, 0
+  d.Cout = layer.cout_p
+  d.cin_real, d.cout_real = layer.cin, layer.cout
+  bias = layer.bias_padded()
+  d.bias = ptr(bias)
+  d.act_slope = float(slope)
+  yq = None
+  if out_slot is not None:
+    d.out_amax = chain.amax_ptr(out_slot)
+    if chain.ready:
+      yq = torch.empty(b, ho, wo, layer.cout_p, dtype=torch.uint8, device=x.device)
+      d.out_q, d.out_q_pix_stride, d.out_q_scale = yq.data_ptr(), layer.cout_p, chain.q_scale_ptr(out_slot)
+  _gconv_run(d, False, 2.0 * b * ho * wo * layer.cout * layer.cin * layer.kh * layer.kw)
+  return y, yq
+
+
 class FrozenConvStackPair(torch.autograd.Function):
   """A frozen conv/ReLU/max-pool stack (VGG19 features) applied to a (prediction, target)
   pair as ONE batched forward: the stack has no batch-coupled op, so concatenating the two
@@ -1422,7 +1518,7 @@ class FrozenConvStackPair(torch.autograd.Function):
   prediction features then target features."""
 
   @staticmethod
-  def forward(ctx, p_in, t_in, plan, taps, cabs=None):
+  def forward(ctx, p_in, t_in, plan, taps, cabs=None, chain=None):
     # cabs = (dtype, mode): p_in / t_in are interleaved complex fp32 images [B,H,W,2]; their magnitudes (ComplexAbs
     # of that mode) are written straight into the two halves of the batched input (no torch.cat), and the backward
     # ends with the magnitude's derivative
@@ -1437,18 +1533,37 @@ class FrozenConvStackPair(torch.autograd.Function):
     else:
       x = torch.cat((p_in, t_in), 0)
     saved, shapes, feats = [], [], []
+    if chain is not None and chain.disabled:
+      chain = None
+    xq, xq_slot = None, None              # fp8 copy of x and its slot in the chain (Fp8Chain)
     for i, (kind, layer, slope) in enumerate(plan):
+      out_slot = chain.slots.get(i) if chain is not None else None
       if kind == 'conv':
-        y, _ = conv_forward(layer, x, None, True, slope, False, None)
+        try:
+          y, yq = frozen_conv_forward(layer, x, slope, xq if (chain is not None and Fp8Chain.layer_ok(layer)) else None,
+                                      chain.dq_scale_ptr(xq_slot) if xq is not None else 0, out_slot, chain)
+        except RuntimeError:
+          if chain is None or chain.ready:
+            raise
+          # a layer of this stack is outside the fp8-capable kernel's shapes (tiny feature maps): the whole stack stays bf16
+          chain.disabled, chain, xq, out_slot = True, None, None, None
+          y, yq = frozen_conv_forward(layer, x, slope)
         saved.append(y)
         shapes.append((x.shape[1], x.shape[2]))
-        x = y
+        x, xq, xq_slot = y, yq, out_slot
       else:
         shapes.append((b,) + tuple(x.shape[1:]))
-        x, arg = maxpool2_fwd(x)
+        if out_slot is not None:
+          x, arg, xq = maxpool2_fwd(x, chain.q_scale_ptr(out_slot), chain.amax_ptr(out_slot), want_q=chain.ready)
+          xq_slot = out_slot
+        else:
+          x, arg = maxpool2_fwd(x)
+          xq, xq_slot = None, None
         saved.append(arg)
       if i in taps:
         feats.append(x)
+    if chain is not None:
+      chain.finish()
     ctx.plan, ctx.taps, ctx.b, ctx.shapes = plan, taps, b, shapes
     ctx.save_for_backward(*saved)
     outs = [f[:b] for f in feats] + [f[b:] for f in feats]
@@ -1480,7 +1595,7 @@ class FrozenConvStackPair(torch.autograd.Function):
         gp = g if (act_done or slope == 1.0) else act_bwd(g, y, slope)
         act_done = False
         if i == 0 and not ctx.needs_input_grad[0]:
-          return None, None, None, None, None
+          return None, None, None, None, None, None
         # fuse the producer's activation derivative into this dgrad's epilogue when the
         # producer is the previous conv of the stack (its output IS this layer's input)
         prev = plan[i - 1] if i > 0 else None
@@ -1507,7 +1622,7 @@ class FrozenConvStackPair(torch.autograd.Function):
       lib.call('csmri_complex_abs_bwd', xc.data_ptr(), xc.shape[0] * xc.shape[1] * xc.shape[2], g.data_ptr(),
                dt_of(g), g.stride(2), 3 if ctx.cabs[1] == 3 else 1, ctx.cabs[1], dx.data_ptr(), 0, stream())
       g = dx
-    return g, None, None, None, None
+    return g, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------

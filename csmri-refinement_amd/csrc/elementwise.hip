@@ -358,9 +358,14 @@ extern "C" int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const
 }
 
 // --------------------------------------------------------------- max pool ----
+// yq / qs / amax (csmri_maxpool2_q): an fp8 (e4m3fn) copy of the pooled bf16 output, value * *qs rounded by
+// v_cvt_pk_fp8_f32 (bit for bit csmri_quantize_fp8 of y), and atomicMax of the bit patterns |y| (csmri_absmax of y)
 __global__ void maxpool2_kernel(int dt, const void* x, int xps, void* y, int yps, uint8_t* arg, int B,
-                                int H, int W, int C) {
+                                int H, int W, int C, uint8_t* yq = nullptr, int yqps = 0, const float* qs = nullptr,
+                                unsigned* amax = nullptr) {
   const int nv = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const float qscale = qs ? *qs : 1.f;
+  unsigned am = 0;
   GRID_STRIDE32(i, (long long)B * Ho * Wo * nv) {
     const int c = (int)(i % nv) * 4;
     const unsigned p = i / nv;
@@ -377,6 +382,28 @@ __global__ void maxpool2_kernel(int dt, const void* x, int xps, void* y, int yps
     }
     store4(y, (long long)p * yps + c, dt, best);
     if (arg) *(uint32_t*)(arg + (long long)p * C + c) = idx[0] | (idx[1] << 8) | (idx[2] << 16) | (idx[3] << 24);
+    if (yq || amax) {
+      // (the pooled values are elements of x: bf16-exact already when dt is bf16)
+      if (amax) {
+        for (int q = 0; q < 4; ++q) {
+          const unsigned ab = __float_as_uint(best[q]) & 0x7fffffffu;
+          am = (ab <= 0x7f800000u && ab > am) ? ab : am;
+        }
+      }
+      if (yq) {
+        int r = 0;
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(best[0] * qscale, best[1] * qscale, r, false);
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(best[2] * qscale, best[3] * qscale, r, true);
+        *(uint32_t*)(yq + (long long)p * yqps + c) = (uint32_t)r;
+      }
+    }
+  }
+  if (amax) {
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t_ = __shfl_xor(am, o); am = t_ > am ? t_ : am; }
+    if ((threadIdx.x & 63) == 0 && am) {       // (read first: the maximum only grows, most waves cannot raise it)
+      const unsigned cur = __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (am > cur) atomicMax(amax, am);
+    }
   }
 }
 // gadd != null: a second gradient of the pooled tensor's source (skip connection) is added in the same pass.
@@ -414,6 +441,18 @@ extern "C" int csmri_maxpool2(int dtype, const void* x, int x_pix_stride, void* 
   CSMRI_CHECK_I32((long long)B * H * W * C);
   hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dtype, x,
                      x_pix_stride, y, y_pix_stride, argmax, B, H, W, C);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+extern "C" int csmri_maxpool2_q(int dtype, const void* x, int x_pix_stride, void* y, int y_pix_stride,
+                                uint8_t* argmax, int B, int H, int W, int C, void* y_q, int y_q_pix_stride,
+                                const float* q_scale, float* amax, void* stream) {
+  CSMRI_CHECK_ARG(x && y && H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && dtype == CSMRI_BF16);
+  CSMRI_CHECK_ARG((!y_q || (q_scale && y_q_pix_stride % 4 == 0 && !((uintptr_t)y_q & 3))));
+  long long n = (long long)B * (H / 2) * (W / 2) * (C / 4);
+  CSMRI_CHECK_I32((long long)B * H * W * C);
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dtype, x,
+                     x_pix_stride, y, y_pix_stride, argmax, B, H, W, C, (uint8_t*)y_q, y_q_pix_stride, q_scale, (unsigned*)amax);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
@@ -576,7 +615,7 @@ extern "C" int csmri_copy_channels(const void* src, int src_dtype, int src_pix_s
   return CSMRI_OK;
 }
 
-extern "C" int csmri_version(void) { return 101; }   // 101: csmri_dc_in_bf16 takes x_dtype; csmri_dropout2d_mask state is uint64[3]
+extern "C" int csmri_version(void) { return 102; }   // 101: csmri_dc_in_bf16 takes x_dtype; csmri_dropout2d_mask state is uint64[3]
 extern "C" const char* csmri_error_string(int code) {
   switch (code) {
     case CSMRI_OK: return "ok";

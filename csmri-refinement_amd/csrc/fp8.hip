@@ -113,3 +113,25 @@ extern "C" int csmri_quantize_fp8(int dtype, const void* x, void* q, long long n
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }
+
+// Delayed scaling for a chain of fp8 tensors (the frozen VGG stack): n tensors, amax[j] = the |x| maximum the producers of
+// tensor j accumulated during THIS step (atomicMax of bit patterns; csmri_gconv_desc.out_amax, csmri_maxpool2_q), scales[2j],
+// scales[2j+1] = the quantisation / dequantisation scale pair the NEXT step uses: 2^(7 - floor(log2(amax)) - margin), so
+// that values up to 2^margin x 1.75 times this step's maximum still fit e4m3fn's finite range.  amax[j] is cleared; a
+// tensor that saw no data (amax 0) keeps its scales.
+__global__ void fp8_scales_update_kernel(float* amax, float* scales, int n, int margin) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const float am = amax[j];
+  if (am > 0.f) {
+    const int se = fp8_scale_exp(am) - margin;
+    scales[2 * j] = pow2f(se); scales[2 * j + 1] = pow2f(-se);
+  }
+  amax[j] = 0.f;
+}
+extern "C" int csmri_fp8_scales_update(float* amax, float* scales, int n, int margin, void* stream) {
+  CSMRI_CHECK_ARG(amax && scales && n > 0 && margin >= 0 && margin <= 4);
+  hipLaunchKernelGGL(fp8_scales_update_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, amax, scales, n, margin);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}

@@ -372,6 +372,8 @@ static int build_params(const csmri_gconv_desc* d, GParams& p, GConfig& c) {
   p.wo_shift = lg2(d->Wo); p.howo_shift = lg2((long long)d->Ho * d->Wo);
   if (p.wo_shift < 0 || p.howo_shift < 0) p.wo_shift = p.howo_shift = -1;
   p.dq0 = d->dtype == CSMRI_FP8 ? d->in_dequant : nullptr; p.dq1 = d->dtype == CSMRI_FP8 ? d->w_dequant : nullptr;
+  p.outq = (char*)d->out_q; p.oqps = d->out_q_pix_stride; p.oqs = d->out_q_scale; p.oamax = (unsigned*)d->out_amax;
+  if (d->out_q) CSMRI_CHECK_ARG(d->out_q_scale && d->out_q_pix_stride % 8 == 0 && !((uintptr_t)d->out_q & 7));
   p.dense_out = !d->out_halo && nclass == 1 && d->out_sy == 1 && d->out_sx == 1 && d->out_oy == 0 && d->out_ox == 0 &&
                 d->Hout_t == d->Ho && d->Wout_t == d->Wo;
   const long long in_px = (long long)d->B * d->Hin * d->Win, out_px = (long long)d->B * d->Hout_t * d->Wout_t;
@@ -396,10 +398,11 @@ static int launch_reduce(const GParams& p, hipStream_t st) {
 // template instance csmri_gconv dispatches to for this problem, spelled as rocprofv3 prints it
 extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n) {
   CSMRI_CHECK_ARG(d && buf && n > 0);
+  if (d->dtype == CSMRI_FP8 && pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3, %d, true>", pconv2_bn(d)); return CSMRI_OK; }
   if (d->dtype == CSMRI_FP8) { gconv_fp8_kernel_name(d, buf, n); return CSMRI_OK; }
   if (thin_out1_eligible(d)) { thin_kernel_name(d, buf, n); return CSMRI_OK; }
   if (UCONV_BEFORE_PCONV2 && uconv_eligible(d)) { uconv_kernel_name(d, buf, n); return CSMRI_OK; }
-  if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3, %d>", pconv2_bn(d)); return CSMRI_OK; }
+  if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3, %d, false>", pconv2_bn(d)); return CSMRI_OK; }
   if (uconv_eligible(d)) { uconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (gconv_glds_eligible(d)) { gconv_glds_kernel_name(d, buf, n); return CSMRI_OK; }
@@ -424,6 +427,8 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
   int rc = build_params(d, p, c);
   if (rc != CSMRI_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if ((d->out_q || d->out_amax) && !pconv2_eligible(d)) return CSMRI_E_UNSUPPORTED;
+  if (d->dtype == CSMRI_FP8 && pconv2_eligible(d)) return pconv2_launch(p, d, st);
   if (d->dtype == CSMRI_FP8) {
     rc = gconv_fp8_launch(p, d, st);
     if (rc != CSMRI_OK) return rc;

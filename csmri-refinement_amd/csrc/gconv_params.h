@@ -20,6 +20,7 @@ struct GParams {
   int off32;                  // every input / output byte offset fits 32 bits
   const float* dq0; const float* dq1;   // fp8 operands: device scalars whose product dequantises the accumulators
   int us_n, us_x, us_y;                 // uconv: strips in all, strips per row of strips, rows of strips per image
+  char* outq; int oqps; const float* oqs; unsigned* oamax;   // pconv2: fp8 copy of the output, its scale, |out| maximum (bits)
 };
 
 // where output position (b, ty, tx) of the tensor goes: window -> dense `out`, else halo buffer

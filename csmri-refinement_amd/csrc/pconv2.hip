@@ -53,8 +53,15 @@ __device__ __forceinline__ void p2_unroll(std::integer_sequence<int, I...>, F&& 
 #define P2_STAMP_DUMP do {} while (0)
 #endif
 
-template <int TH, int TW, int BN>
+// F8: operands are fp8 (OCP e4m3fn) -- a 128-byte row of either LDS image then holds 128 K elements instead of 64 and ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) consumes what two bf16 MFMAs did: the same bytes, the same LDS reads,
+// the same MFMA cycles per step for twice the K (the instruction contracts the 32 bytes lane group g holds of A with the 32
+// bytes it holds of B: the two 16-byte slots (g, 4 + g) a lane read for the bf16 half-steps, concatenated -- gconv_fp8.hip).
+// The accumulators are multiplied by *dq0 * *dq1 (the operands' dequantisation scales) before the epilogue.
+typedef __attribute__((ext_vector_type(8))) int p2_i32x8_t;
+template <int TH, int TW, int BN, bool F8>
 __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
+  constexpr int ES = F8 ? 1 : 2;                               // bytes per operand element
   constexpr int NT = TH * TW, TPW = 16 + TW - 1, TPH = 16 + TH - 1, NPIX = TPH * TPW;
   constexpr int PLANE = (NPIX * 16 + 255) & ~255, PBUF = 8 * PLANE, WST = BN * 128, NG = 6;
   constexpr int BOFF = 2 * PBUF + 4 * WST;                     // bias of the workgroup's channel block (BN floats)
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_x = (p.Wo + 15) >> 4, tiles_y = (p.Ho + 15) >> 4, tiles_img = tiles_x * tiles_y;
   const int ntile = p.mtiles, NB = p.ntiles;
-  const int ncc = p.Cin >> 6;
+  const int ncc = p.Cin >> (F8 ? 7 : 6);                         // 128-byte channel chunks
 
   // which output-channel block, which spatial worker: an XCD (workgroup id % 8) keeps ONE channel block's weights in its L2
   int nblk, worker, workers;
@@ -90,12 +97,12 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
     // weights: piece k of a stage = rows 8 (L + 4 k) .. + 7 (8 rows x 128 B), 16-B slots XOR-swizzled at the source
     const int lrow = lane >> 3;
     const int wchunk = (lane & 7) ^ ((4 * (L & 1) + (lane >> 4)) & 7);
-    const char* wbase = p.w + (size_t)n0 * p.Kp * 2;
-    const size_t wstep = (size_t)32 * p.Kp * 2;
+    const char* wbase = p.w + (size_t)n0 * p.Kp * ES;
+    const size_t wstep = (size_t)32 * p.Kp * ES;
     const char* w0p = wbase; const char* w1p = wbase + wstep; const char* w2p = wbase + 2 * wstep; const char* w3p = wbase + 3 * wstep;
     (void)w2p; (void)w3p;
-    const unsigned wvoff = (unsigned)(((L * 8 + lrow) * p.Kp + wchunk * 8) * 2);
-    unsigned cin2 = (unsigned)p.Cin * 2u;
+    const unsigned wvoff = (unsigned)((L * 8 + lrow) * p.Kp * ES + wchunk * 16);
+    unsigned cin2 = (unsigned)p.Cin * (unsigned)ES;
     asm volatile("" : "+s"(w0p), "+s"(w1p), "+s"(w2p), "+s"(w3p), "+s"(cin2));
     int w_s = 0, w_tap = 0, w_cc = 0;
     unsigned w_koff = 0, w_ring = 0;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
     patch_pixels(p_tile);
     // (kept in registers: the compiler would re-load kernel arguments it finds no SGPR for inside the step loop)
     const char* in0 = p.in0 + L * 16;
-    unsigned ps0b = (unsigned)p.ps0 * 2u;
+    unsigned ps0b = (unsigned)p.ps0 * (unsigned)ES;
     const char* zero_page = p2_zero_page;
     asm volatile("" : "+s"(in0), "+s"(ps0b), "+s"(zero_page));
     auto patch_piece = [&](auto kc_) {                 // piece k of chunk p_cc of tile p_tile
@@ -218,6 +225,14 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
       (int)(p.gsrc ? (unsigned)p.B * p.Hout_t * p.Wout_t * (unsigned)p.gps * 2u : 0u), 0x00020000);
   const bool has_bias = p.bias != nullptr, has_gate = p.gsrc != nullptr, has_act = p.slope != 1.f;
   const float e_slope = p.slope, e_gslope = p.gslope;
+  const float e_dq = F8 ? (p.dq0 ? *p.dq0 : 1.f) * (p.dq1 ? *p.dq1 : 1.f) : 1.f;
+  // fp8 copy of the output (csmri_gconv_desc.out_q): the stored bf16 value times *out_q_scale, rounded to e4m3 by
+  // v_cvt_pk_fp8_f32 -- bit for bit what csmri_quantize_fp8 makes of the bf16 tensor -- 8 channels = 8 bytes per lane
+  const bool has_q = p.outq != nullptr, has_amax = p.oamax != nullptr;
+  const float e_qs = has_q ? *p.oqs : 1.f;
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(has_q ? (void*)p.outq : (void*)p.out, 0,
+      (int)(has_q ? (unsigned)p.B * p.Hout_t * p.Wout_t * (unsigned)p.oqps : 0u), 0x00020000);
+  unsigned amax_bits = 0;
   constexpr unsigned OOB = 0x80000000u;
   const unsigned nown = (unsigned)(n0 + wn * (BN / 2));
   const unsigned lch_st = (nown + 8 * (g >> 1) + 16 * (g & 1)) * 2u;     // store: 8 consecutive channels after the exchange
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
       u32x2_t pk[FN];
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
-        f32x4_t v = acc[i][f] + bb[i];
+        f32x4_t v = F8 ? acc[i][f] * e_dq + bb[i] : acc[i][f] + bb[i];
         acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         if (has_act) {
 #pragma unroll
@@ -269,7 +284,29 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
       for (int i = 0; i < FN; i += 2) {
         const auto s0 = __builtin_amdgcn_permlane16_swap(pk[i][0], pk[i + 1][0], false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(pk[i][1], pk[i + 1][1], false, false);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){s0[0], s1[0], s0[1], s1[1]}, rs_out, (int)(off + i * 32), 0, 0);
+        const u32x4_t d = (u32x4_t){s0[0], s1[0], s0[1], s1[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs_out, (int)(off + i * 32), 0, 0);
+        if (has_q | has_amax) {
+          float e[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { e[2 * k] = __uint_as_float(d[k] << 16); e[2 * k + 1] = __uint_as_float(d[k] & 0xffff0000u); }
+          if (has_amax && mvv[f]) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                   // NaNs are skipped, as csmri_absmax does
+              const unsigned ab = __float_as_uint(e[k]) & 0x7fffffffu;
+              amax_bits = (ab <= 0x7f800000u && ab > amax_bits) ? ab : amax_bits;
+            }
+          }
+          if (has_q) {
+            int q0 = 0, q1 = 0;
+            q0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0] * e_qs, e[1] * e_qs, q0, false);
+            q0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2] * e_qs, e[3] * e_qs, q0, true);
+            q1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4] * e_qs, e[5] * e_qs, q1, false);
+            q1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6] * e_qs, e[7] * e_qs, q1, true);
+            const unsigned qoff = mvv[f] ? opix[f] * (unsigned)p.oqps + (lch_st >> 1) + i * 16 : OOB;
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){(unsigned)q0, (unsigned)q1}, rs_q, (int)qoff, 0, 0);
+          }
+        }
       }
     }
   };
@@ -312,6 +349,22 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
       P2_STAMP(1);
       // ======== multiply half ========
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (F8) {
+        p2_i32x8_t a8[4], b8[FN];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          a8[f] = (p2_i32x8_t){(int)a[0][f][0], (int)a[0][f][1], (int)a[0][f][2], (int)a[0][f][3],
+                               (int)a[1][f][0], (int)a[1][f][1], (int)a[1][f][2], (int)a[1][f][3]};
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+          b8[i] = (p2_i32x8_t){(int)b[0][i][0], (int)b[0][i][1], (int)b[0][i][2], (int)b[0][i][3],
+                               (int)b[1][i][0], (int)b[1][i][1], (int)b[1][i][2], (int)b[1][i][3]};
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int f = 0; f < 4; ++f)   // cbsz = blgp = 0: both operands e4m3; block scales 2^0 (E8M0 127)
+            acc[i][f] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8[i], a8[f], acc[i][f], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      } else {
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
@@ -320,6 +373,7 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
           for (int f = 0; f < 4; ++f)
             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[kc][i]),
                                                                 __builtin_bit_cast(bf16x8_t, a[kc][f]), acc[i][f], 0, 0, 0);
+      }
       __builtin_amdgcn_s_setprio(0);
       P2_STAMP(2);
       if constexpr (t == NT - 1) {
@@ -332,6 +386,17 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
     });
   }
   if (!wn) __builtin_amdgcn_s_barrier();
+  if (has_amax) {
+    // One atomic per WAVE on one word was 2,048 same-address atomics per launch: ~11 ns each, 20-40 us on a 60 us kernel.
+    // The maximum only grows: a wave first reads the word and skips the atomic when it cannot raise it (a stale read
+    // costs an unnecessary atomic, never a wrong result).
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t_ = __shfl_xor(amax_bits, o); amax_bits = t_ > amax_bits ? t_ : amax_bits; }
+    if (lane == 0 && amax_bits) {
+      const unsigned cur = __hip_atomic_load(p.oamax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (amax_bits > cur) atomicMax(p.oamax, amax_bits);
+    }
+  }
   P2_STAMP_DUMP;
 }
 
@@ -368,7 +433,10 @@ static void p2_grid(const csmri_gconv_desc* d, int* ntile, int* nb, int* workers
 #endif
 int pconv2_bn(const csmri_gconv_desc* d) { return p2_bn(d); }
 int pconv2_eligible(const csmri_gconv_desc* d) {
-  if (d->dtype != CSMRI_BF16 || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
+  if ((d->dtype != CSMRI_BF16 && d->dtype != CSMRI_FP8) || d->in_s != 1 || d->dy_step != 1 || d->dx_step != 1) return 0;
+  const bool f8 = d->dtype == CSMRI_FP8;
+  if (f8 && (d->Cin % 128 || d->in0_pix_stride % 16 || d->border != CSMRI_BORDER_ZERO)) return 0;
+  if (d->out_q && (long long)d->B * d->Hout_t * d->Wout_t * d->out_q_pix_stride >= (1ll << 31)) return 0;
   if (d->nclass > 1 || d->splitk > 1 || d->upsample || d->in1 || d->stats_partial || d->out_halo) return 0;
   // epilogue: bf16 tensors addressed with 32-bit byte offsets, leaky slope applied as max(v, slope v)
   if (d->out_dtype != CSMRI_BF16 || (d->g_src && d->g_dtype != CSMRI_BF16)) return 0;
@@ -383,10 +451,12 @@ int pconv2_eligible(const csmri_gconv_desc* d) {
   // (64-channel output blocks -- VGG conv1_2 -- were built and measured too: 117 vs tconv's 122 us alone, the step 0.1 ms
   // SLOWER: a wave's 64 x 32 tile reads 12 fragments per 16 MFMAs)
   if (d->Cin % 64 || d->Cout % 128) return 0;
-  if ((long long)d->B * d->Hin * d->Win * d->in0_pix_stride * 2 >= (1ll << 32)) return 0;
-  if ((long long)d->Cout * d->TH * d->TW * d->Cin * 2 >= (1ll << 31)) return 0;
+  if ((long long)d->B * d->Hin * d->Win * d->in0_pix_stride * (f8 ? 1 : 2) >= (1ll << 32)) return 0;
+  if ((long long)d->Cout * d->TH * d->TW * d->Cin * (f8 ? 1 : 2) >= (1ll << 31)) return 0;
   int ntile, nb, workers;
   p2_grid(d, &ntile, &nb, &workers);
+  // (the fp8 form and the fp8-copy / maximum outputs exist in this kernel only: no minimum grid for them)
+  if (f8 || d->out_q || d->out_amax) return 1;
   return (long long)ntile * nb >= P2_MIN_BLOCKS;
 }
 
@@ -397,13 +467,11 @@ int pconv2_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) 
   p.mtiles = ntile; p.ntiles = nb;
   const int bn = p2_bn(d);
   const int lds = 2 * 8 * p2_plane(d) + 4 * bn * 128 + bn * 4;
-  if (bn == 64) {
-    CSMRI_SET_MAX_LDS((pconv2_kernel<3, 3, 64>), 160 * 1024);
-    hipLaunchKernelGGL((pconv2_kernel<3, 3, 64>), dim3(workers * nb), dim3(768), lds, st, p);
-  } else {
-    CSMRI_SET_MAX_LDS((pconv2_kernel<3, 3, 128>), 160 * 1024);
-    hipLaunchKernelGGL((pconv2_kernel<3, 3, 128>), dim3(workers * nb), dim3(768), lds, st, p);
-  }
+#define P2_GO(BN_, F8_) do { CSMRI_SET_MAX_LDS((pconv2_kernel<3, 3, BN_, F8_>), 160 * 1024); \
+    hipLaunchKernelGGL((pconv2_kernel<3, 3, BN_, F8_>), dim3(workers * nb), dim3(768), lds, st, p); } while (0)
+  if (d->dtype == CSMRI_FP8) { if (bn == 64) P2_GO(64, true); else P2_GO(128, true); }
+  else { if (bn == 64) P2_GO(64, false); else P2_GO(128, false); }
+#undef P2_GO
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -5,6 +5,7 @@ The reference materialises padding with nn.ZeroPad2d / nn.ReflectionPad2d
 bottom) amounts and the border mode -- the gather-conv kernel applies them in
 its address computation."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -12,12 +13,17 @@ import torch.nn as nn
 import csmri_hip
 from csmri_hip import ops
 
-# 'fp8' (BASELINE config 5): bf16 activations / backward, forward products of the trainable convolutions on
-# e4m3fn operands wherever the shape allows (ops.ConvLayer.fp8_ok); everything else exactly the bf16 path
+# 'fp8' (BASELINE config 5): bf16 activations / backward; the FROZEN VGG19 of the perceptual loss multiplies e4m3fn
+# operands from conv2_2 on (ops.Fp8Chain: weights quantised once, activations quantised by the producing kernel's
+# epilogue with delayed scaling) and the data-consistency layers keep their images in bf16; everything else exactly the
+# bf16 path.  FP8_TRAINABLE (or CSMRI_FP8_TRAINABLE=1) additionally moves the forward products of the TRAINABLE
+# convolutions to fp8 wherever the shape allows (ops.ConvLayer.fp8_ok): quantisation passes per launch, measured 12 %
+# slower than bf16 end to end -- kept as an opt-in, not part of 'fp8'.
 COMPUTE_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32,
                   'bfloat16': torch.bfloat16, 'float32': torch.float32, 'fp8': torch.bfloat16}
 _DEFAULT_DTYPE = [torch.bfloat16]
 _FP8_FORWARD = [False]
+FP8_TRAINABLE = os.environ.get('CSMRI_FP8_TRAINABLE', '0') == '1'
 
 
 def set_default_compute_dtype(name_or_dtype):
@@ -85,7 +91,7 @@ class ConvParams(nn.Module):
     self.layer = ops.ConvLayer(self.weight, self.bias, stride, pads, border, dtype,
                                upsample=upsample, frozen=frozen)
     self._layer_args = (stride, pads, border, dtype, upsample, frozen)
-    self.layer.fp8 = bool(getattr(self, 'fp8', _FP8_FORWARD[0])) and not frozen
+    self.layer.fp8 = bool(getattr(self, 'fp8', _FP8_FORWARD[0] and FP8_TRAINABLE)) and not frozen
     return self.layer
 
   def _apply(self, fn, *a, **k):

@@ -30,6 +30,8 @@ class VGG19(nn.Module):
     assert last <= 5, 'VGG19 has at most 6 blocks'
     dtype = dtype or default_compute_dtype()
     self.dtype = dtype
+    from models.utils import default_fp8_forward
+    self.fp8 = bool(default_fp8_forward()) and not requires_grad     # compute_dtype 'fp8': ops.Fp8Chain in features_pair
     gen = torch.Generator().manual_seed(seed)
     blocks, plan = [dict()], []
     cin, idx, block = 3, 0, 0
@@ -110,8 +112,14 @@ class VGG19(nn.Module):
     interleaved complex images [B,H,W,2] fp32 and the normalised magnitude (ComplexAbs mode 3) is part of the op."""
     plan = [('conv', conv.layer, 0.0) if kind == 'conv' else ('pool', None, None)
             for kind, conv, _ in self._plan]
+    chain = None
+    if getattr(self, 'fp8', False) and self.dtype == torch.bfloat16:
+      # compute_dtype 'fp8' (BASELINE config 5): the 3 x 3 layers from conv2_2 on multiply fp8 operands, delayed scaling
+      chain = getattr(self, '_fp8_chain', None)
+      if chain is None or chain.amax.device != p_in.device:
+        chain = self._fp8_chain = ops.Fp8Chain(plan, p_in.device)
     outs = ops.FrozenConvStackPair.apply(p_in, t_in, plan, tuple(self._taps),
-                                         (self.dtype, 3) if complex_input else None)
+                                         (self.dtype, 3) if complex_input else None, chain)
     n = len(self._taps)
     return list(outs[:n]), list(outs[n:])
 

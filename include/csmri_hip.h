@@ -120,6 +120,13 @@ typedef struct csmri_gconv_desc {
    * (discriminator first layer and its data gradient, U-Net head, discriminator final conv): same result, the
    * seven pad channels are simply not multiplied. */
   int cin_real, cout_real;
+  /* ABI 102.  Optional fp8 (OCP e4m3fn) copy of the output for a following fp8 convolution -- the frozen VGG stack
+   * (reference models/vgg.py:35) chains its 3 x 3 layers this way --: out_q[pos * out_q_pix_stride + c] =
+   * fp8_rne(out[pos][c] * *out_q_scale), i.e. exactly what csmri_quantize_fp8 makes of the stored bf16 output with that
+   * scale, written by the producing kernel's epilogue instead of by a pass of its own; *out_amax (device word, optional)
+   * receives atomicMax of the bit patterns |out| (what csmri_absmax returns), from which the caller derives the NEXT
+   * step's scale (delayed scaling).  Only the 3 x 3 patch kernel takes these (else CSMRI_E_UNSUPPORTED). */
+  void* out_q; int out_q_pix_stride; const float* out_q_scale; float* out_amax;
 } csmri_gconv_desc;
 #define CSMRI_GCONV_DEFER_REDUCE 1
 
@@ -235,6 +242,11 @@ int csmri_convblock_fused_bwd_splits(int B, int H, int W);
 int csmri_absmax(int dtype, const void* x, long long n, float* amax, void* stream);
 int csmri_quantize_fp8(int dtype, const void* x, void* q, long long n, const float* amax, float* scales,
                        void* stream);
+/* Delayed scaling for a chain of fp8 tensors (ABI 102; the frozen VGG stack): amax[j] = the |x| maximum of tensor j its
+ * producers accumulated this step (csmri_gconv_desc.out_amax, csmri_maxpool2_q); scales[2j], scales[2j+1] become the
+ * quantisation / dequantisation pair of the NEXT step, 2^(7 - floor(log2 amax) - margin) and its inverse; amax[j] is cleared
+ * (a tensor that saw no data keeps its scales).  0 <= margin <= 4. */
+int csmri_fp8_scales_update(float* amax, float* scales, int n, int margin, void* stream);
 
 /* ------------------------------------------------------------------------
  * Weight gradient of a convolution (nn.Conv2d backward w.r.t. weight):
@@ -433,6 +445,11 @@ int csmri_act_bwd(int dtype, const void* dz, int dz_pix_stride, const void* z, i
 /* MaxPool2d(2,2) NHWC (models/unet.py:58, torchvision VGG19) */
 int csmri_maxpool2(int dtype, const void* x, int x_pix_stride, void* y, int y_pix_stride,
                    uint8_t* argmax, int B, int H, int W, int C, void* stream);
+/* the same (bf16) with an fp8 (e4m3fn) copy of the pooled output for a following fp8 convolution: y_q = what
+ * csmri_quantize_fp8 makes of y with scale *q_scale; *amax (optional) = atomicMax of the bit patterns |y| (ABI 102) */
+int csmri_maxpool2_q(int dtype, const void* x, int x_pix_stride, void* y, int y_pix_stride,
+                     uint8_t* argmax, int B, int H, int W, int C, void* y_q, int y_q_pix_stride,
+                     const float* q_scale, float* amax, void* stream);
 int csmri_maxpool2_bwd(int dtype, const void* dy, int dy_pix_stride, const uint8_t* argmax,
                        void* dx, int dx_pix_stride, int B, int H, int W, int C, void* stream);
 /* same with the neighbouring elementwise steps of the backward folded into the one pass over the

@@ -218,3 +218,184 @@ def test_fp8_layer_backward_is_the_bf16_path(hip):
   assert 5e-3 < rel_l2(y8, y16) < 6e-2
   # no activation on this layer, so nothing of the forward's output enters the backward: identical launches
   assert torch.equal(gx8, gx16) and torch.equal(gw8, gw16)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The frozen VGG stack in fp8 (ops.Fp8Chain): the patch-structured 3 x 3 kernel with e4m3fn operands, the fp8 copy of an
+# output written by the producing kernel's epilogue, delayed scaling.  The perceptual loss of the reference
+# (models/vgg_loss.py:43-65, models/vgg.py:35) has no fp8 form: the oracle is the reference's conv / ReLU / max-pool on
+# operands rounded as fp8.hip rounds them.
+# ---------------------------------------------------------------------------------------------------
+def _frozen_layer(ops, cin, cout, gen, integer=False, density=1.0):
+  if integer:
+    wt = torch.randint(-4, 5, (cout, cin, 3, 3), generator=gen).float()
+    if density < 1.0:
+      wt = wt * (torch.rand(wt.shape, generator=gen) < density)
+    bias = torch.randint(-3, 4, (cout,), generator=gen).float()
+  else:
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (cin * 9))
+    bias = torch.randn(cout, generator=gen) * 0.1
+  layer = ops.ConvLayer(torch.nn.Parameter(wt.clone().cuda()), torch.nn.Parameter(bias.clone().cuda()), 1, (1, 1, 1, 1), 'zero',
+                        torch.bfloat16, frozen=True)
+  return layer, wt, bias
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(64, 128, 128, 40, 24, 3), (128, 256, 256, 16, 16, 5), (256, 128, 128, 32, 48, 2)],
+                         ids=['64-128-128', '128-256-256', '256-128-128'])
+def test_fp8_patch_conv_chain_exact_on_integer_operands(hip, shape):
+  """Two frozen 3 x 3 layers chained through the fp8 copy: layer A (bf16 operands) writes y_A and, from the same epilogue,
+  its fp8 copy (scale 1) and the running maximum; layer B multiplies that copy with fp8 weights.  With small integers
+  every product and every fp32 partial sum is exact, so
+    * the fp8 copy equals y_A element for element (e4m3 holds the integers 0..16 exactly; larger ones are rounded by
+      the restated rule), the maximum is max |y_A|;
+    * y_B equals the integer convolution of the ROUNDED copy with B's weights, rounded once to bf16 -- bit for bit: this
+      pins the operand lane map of v_mfma_scale_f32_16x16x128_f8f6f4 in the patch kernel and the K order of its LDS
+      images for every tap and channel chunk (ragged tiles: the map is not a multiple of 16)."""
+  ops = hip.ops
+  c0, c1, c2, h, w, b = shape
+  g = torch.Generator().manual_seed(c0 + c1 + h)
+  la, wa, ba = _frozen_layer(ops, c0, c1, g, integer=True, density=0.1)
+  lb, wb, bb = _frozen_layer(ops, c1, c2, g, integer=True)
+  # sparse small-integer input and first-layer weights: y_A stays within a few tens
+  x = (torch.randint(-2, 3, (b, c0, h, w), generator=g) * (torch.rand(b, c0, h, w, generator=g) < 0.05)).float()
+  plan = [('conv', la, 0.0), ('conv', lb, 0.0)]
+  chain = ops.Fp8Chain(plan, torch.device('cuda'))
+  assert chain.slots == {0: 0}
+  chain.ready = True                                   # scales given: 1.0 (integers)
+  xd = to_dev_nhwc(x)
+  log = ops.LAUNCH_LOG = []
+  try:
+    ya, yq = ops.frozen_conv_forward(la, xd, 0.0, None, 0, 0, chain)
+    yb, _ = ops.frozen_conv_forward(lb, ya, 0.0, yq, chain.dq_scale_ptr(0), None, chain)
+    torch.cuda.synchronize()
+  finally:
+    ops.LAUNCH_LOG = None
+  names = [e[1] for e in log]
+  assert names[0].startswith('pconv2_kernel<3, 3,') and names[0].endswith('false>'), names
+  assert names[1].startswith('pconv2_kernel<3, 3,') and names[1].endswith('true>'), names
+  ra = torch.relu(F.conv2d(x, wa, ba, padding=1))
+  assert torch.equal(from_dev_nhwc(ya, c1), ra.bfloat16().float())
+  ya_host = from_dev_nhwc(ya, c1)
+  q_ref = L.e4m3_round(ya_host)                          # scale 1
+  assert torch.equal(yq.cpu()[..., :c1].permute(0, 3, 1, 2), L.e4m3_bits(q_ref))
+  assert float(chain.amax[0].cpu()) == float(ya_host.abs().max())
+  wq, sw = L.quantize_fp8(wb)
+  assert torch.equal(wq / sw, wb)                        # small integers: exact in e4m3
+  rb = torch.relu(F.conv2d(q_ref, wb, bb, padding=1))
+  assert torch.equal(from_dev_nhwc(yb, c2), rb.bfloat16().float())
+
+
+@pytest.mark.gpu
+def test_fp8_patch_conv_vs_oracle_and_copy_is_quantize_of_output(hip):
+  """Random operands at a VGG shape (conv3_x: 256 -> 256, 64 x 64, 4 images): the fp8 copy a layer's epilogue writes is
+  bit for bit csmri_quantize_fp8's rounding of its stored bf16 output with the chain's scale; the consuming fp8 layer agrees
+  with the reference convolution on the SAME rounded operands within bf16 output rounding (relative L2 <= 3e-3), and its
+  distance to the un-quantised convolution is the format's (< 6e-2)."""
+  ops = hip.ops
+  g = torch.Generator().manual_seed(31)
+  la, wa, ba = _frozen_layer(ops, 128, 256, g)
+  lb, wb, bb = _frozen_layer(ops, 256, 256, g)
+  x = torch.relu(torch.randn(4, 128, 64, 64, generator=g)).bfloat16().float()
+  chain = ops.Fp8Chain([('conv', la, 0.0), ('conv', lb, 0.0)], torch.device('cuda'))
+  xd = to_dev_nhwc(x)
+  # pass 1 (bf16, collects the maximum), scales for pass 2 with one bit of headroom
+  ya1, yq1 = ops.frozen_conv_forward(la, xd, 0.0, None, 0, 0, chain)
+  assert yq1 is None
+  chain.finish()
+  torch.cuda.synchronize()
+  ya_host = from_dev_nhwc(ya1, 256)
+  amax = float(ya_host.abs().max())
+  s = L.fp8_scale(amax) / 2.0
+  assert chain.scales.cpu().tolist() == [[s, 1.0 / s]] and float(chain.amax[0].cpu()) == 0.0
+  ya, yq = ops.frozen_conv_forward(la, xd, 0.0, None, 0, 0, chain)
+  yb, _ = ops.frozen_conv_forward(lb, ya, 0.0, yq, chain.dq_scale_ptr(0), None, chain)
+  torch.cuda.synchronize()
+  assert torch.equal(ya, ya1) and float(chain.amax[0].cpu()) == amax
+  qa = L.e4m3_round(ya_host * s)
+  assert torch.equal(yq.cpu().permute(0, 3, 1, 2), L.e4m3_bits(qa))
+  wq, sw = L.quantize_fp8(wb)
+  ref8 = torch.relu(F.conv2d(qa, wq, None, padding=1) / (s * sw) + bb.view(1, -1, 1, 1))
+  ref32 = torch.relu(F.conv2d(ya_host, wb, bb, padding=1))
+  e8, fmt = rel_l2(from_dev_nhwc(yb, 256), ref8), rel_l2(ref8, ref32)
+  print('fp8 patch conv vs oracle on the same fp8 operands %.2e | format error vs the bf16-operand convolution %.2e' % (e8, fmt))
+  assert e8 < 3e-3 and fmt < 6e-2, (e8, fmt)
+
+
+@pytest.mark.gpu
+def test_maxpool_fp8_copy_is_quantize_of_output(hip):
+  ops = hip.ops
+  g = torch.Generator().manual_seed(8)
+  x = torch.relu(torch.randn(3, 128, 24, 40, generator=g) * 3.0).bfloat16().float()
+  sc = torch.tensor([4.0, 0.25], device='cuda')
+  am = torch.zeros(1, device='cuda')
+  y, arg, yq = ops.maxpool2_fwd(to_dev_nhwc(x), sc.data_ptr(), am.data_ptr(), want_q=True)
+  torch.cuda.synchronize()
+  ref = F.max_pool2d(x, 2, 2)
+  assert torch.equal(from_dev_nhwc(y, 128), ref)
+  assert torch.equal(yq.cpu().permute(0, 3, 1, 2), L.e4m3_bits(L.e4m3_round(ref * 4.0)))
+  assert float(am.cpu()) == float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_vgg19_fp8_chain_features_and_gradient(hip):
+  """models.vgg.VGG19 with compute_dtype 'fp8' (frozen stack, ops.Fp8Chain), 128 x 128, 2 + 2 images: the first call
+  runs bf16 and leaves scales behind (delayed scaling), the second multiplies fp8 operands in conv2_2 .. conv5_4 (13
+  launches of the fp8 patch kernel).  relu5_4 of the fp8 pass against the fp32 CPU oracle (O.vgg_features, reference
+  models/vgg.py:58-80) within the format's error (relative L2 < 0.15, 13 layers of ~3.8 % each; the bf16 pass: < 0.02);
+  the gradient of the MSE feature loss w.r.t. the prediction (bf16 backward on the saved activations): see below."""
+  import sys
+  from conftest import PKG
+  if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+  from models.utils import set_default_compute_dtype
+  from models.vgg import VGG19
+  ops = hip.ops
+  set_default_compute_dtype('fp8')
+  try:
+    vgg = VGG19(seed=3).cuda()
+  finally:
+    set_default_compute_dtype('bf16')
+  assert vgg.fp8
+  PV = {k: v.detach().cpu().float() for k, v in vgg.state_dict().items() if k.startswith('blocks.')}
+  g = torch.Generator().manual_seed(17)
+  p = torch.rand(2, 3, 128, 128, generator=g)
+  t = torch.rand(2, 3, 128, 128, generator=g)
+  mean, std = torch.tensor(O.VGG_MEAN).view(1, 3, 1, 1), torch.tensor(O.VGG_STD).view(1, 3, 1, 1)
+
+  res = []
+  for it in range(2):
+    pd = ops.ToNHWC.apply(((p - mean) / std).cuda().requires_grad_(True), torch.bfloat16, 8)
+    pd.retain_grad()
+    td = ops.ToNHWC.apply(((t - mean) / std).cuda(), torch.bfloat16, 8)
+    log = ops.LAUNCH_LOG = []
+    try:
+      fp, ft = vgg.features_pair(pd, td)
+      loss = ((fp[0].float() - ft[0].float()) ** 2).mean()
+      loss.backward()
+      torch.cuda.synchronize()
+    finally:
+      ops.LAUNCH_LOG = None
+    n8 = sum(1 for e in log if e[1].startswith('pconv2_kernel') and e[1].endswith('true>'))
+    res.append((fp[0].detach().float().cpu(), ft[0].detach().float().cpu(), pd.grad.float().cpu()[..., :3], float(loss), n8))
+  assert res[0][4] == 0 and res[1][4] == 13, (res[0][4], res[1][4])
+  assert vgg._fp8_chain.ready and not vgg._fp8_chain.disabled and len(vgg._fp8_chain.slots) == 13
+  pr = ((p - mean) / std).requires_grad_(True)
+  fo_p, fo_t = O.vgg_features(PV, pr * std + mean), O.vgg_features(PV, t)
+  lo = F.mse_loss(fo_p, fo_t.detach())
+  lo.backward()
+  go = pr.grad.permute(0, 2, 3, 1)
+  for name, (fp, ft, gp, loss, n8) in zip(('bf16 pass', 'fp8 pass'), res):
+    ef = rel_l2(fp.permute(0, 3, 1, 2)[:, :512], fo_p.detach())
+    cos = float((gp * go).sum() / (gp.norm() * go.norm() + 1e-30))
+    print('VGG19 %-9s relu5_4 rel_l2 vs fp32 oracle %.3e | loss %.5e (oracle %.5e) | grad cos %.4f | %d fp8 launches' %
+          (name, ef, loss, float(lo), cos, n8))
+    assert ef < (0.02 if name == 'bf16 pass' else 0.15), (name, ef)
+    # the gradient: bf16 is the established path; for fp8 only the sign of the correlation is asserted -- the MSE of two
+    # feature maps whose difference is of the size of the fp8 noise has no direction left (0.39 here, 0.6 / 0.25 for a
+    # prediction 30 / 40 dB from its target: DESIGN.md 3.5), which is the measured reason the variant stays opt-in
+    assert cos >= (0.90 if name == 'bf16 pass' else 0.2), (name, cos)
+    assert abs(loss - float(lo)) <= (0.05 if name == 'bf16 pass' else 1.0) * float(lo)
+  g16, g8 = res[0][2], res[1][2]
+  cos88 = float((g16 * g8).sum() / (g16.norm() * g8.norm() + 1e-30))
+  print('VGG19 fp8 pass against the bf16 pass: relu5_4 rel_l2 %.3e, grad cos %.4f' % (rel_l2(res[1][0], res[0][0]), cos88))

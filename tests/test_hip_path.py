@@ -1385,6 +1385,10 @@ def test_fp8_config_key_step_fp8_convs_and_bf16_dc(env, monkeypatch):
   Configuration, set_dtype = env
   import csmri_hip
   from csmri_hip import lib
+  import models.utils
+  # (since round 5 'fp8' by itself moves the frozen VGG stack to fp8, tests/test_fp8.py; the trainable layers' forward
+  #  products -- what this test is about -- are behind models.utils.FP8_TRAINABLE)
+  monkeypatch.setattr(models.utils, 'FP8_TRAINABLE', True)
   B = 2
   batch = O.synth_batch(B, 256, 256, acc=4, seed=77)
   res = {}
@@ -1423,6 +1427,58 @@ def test_fp8_config_key_step_fp8_convs_and_bf16_dc(env, monkeypatch):
   d = abs(res['fp8'][1]['gen_psnr'].value - res['bf16'][1]['gen_psnr'].value)
   print('fp8 config key gen_psnr fp8 %.5f bf16 %.5f' % (res['fp8'][1]['gen_psnr'].value, res['bf16'][1]['gen_psnr'].value))
   assert d < 0.1
+
+
+def test_fp8_compute_dtype_runs_the_frozen_vgg_stack_in_fp8(env):
+  """`compute_dtype: "fp8"` (BASELINE config 5) since round 5: the frozen VGG19 of the perceptual loss (reference
+  models/vgg_loss.py:43-65) multiplies e4m3fn operands from conv2_2 on (ops.Fp8Chain; tests/test_fp8.py pins the kernel,
+  the fp8 copies and the scales), the trainable networks stay bf16.  Two full-width 256^2 GAN steps next to the bf16
+  runner from the same initial weights and dropout masks: step 1 runs the stack in bf16 and collects the maxima (0 fp8
+  launches), step 2 launches the fp8 patch kernel 13 times; every loss of step 2 except the perceptual one within 10 % of
+  the bf16 runner's, the perceptual loss within a factor 2 (its value is a difference of two nearly equal feature maps:
+  at 30 dB the fp8 features' noise is of the size of the signal -- DESIGN.md 3.5 has the measured gradient cosines),
+  PSNR within 0.05 dB."""
+  Configuration, set_dtype = env
+  import csmri_hip
+  B = 2
+  batch = O.synth_batch(B, 256, 256, acc=4, seed=78)
+  res = {}
+  for dtype in ('bf16', 'fp8'):
+    runner, conf = _full_width_runner(Configuration, set_dtype, dtype, batch_size=B)
+    vgg = runner.gen_criteria['VGG19'].criterion.vgg
+    assert vgg.fp8 == (dtype == 'fp8')
+    g = torch.Generator().manual_seed(9)
+    chans = [f for _, bn, drop, f in runner.disc._layers if bn is not None and drop]
+    masks = [(torch.rand(B, c, 1, 1, generator=g) < 0.5).float() * 2.0 for _ in range(3) for c in chans]
+    steps = []
+    for it in range(2):
+      log = csmri_hip.ops.LAUNCH_LOG = []
+      try:
+        hip = _hip_step(runner, batch, masks)
+      finally:
+        csmri_hip.ops.LAUNCH_LOG = None
+      n8 = sum(1 for e in log if e[1].startswith('pconv2_kernel') and e[1].endswith('true>'))
+      n8t = sum(1 for e in log if e[1].startswith('gconv_fp8_kernel'))
+      steps.append((hip, n8, n8t))
+    print('%s: fp8 patch-kernel launches per step %s, fp8 launches of trainable layers %s' %
+          (dtype, [s_[1] for s_ in steps], [s_[2] for s_ in steps]))
+    if dtype == 'fp8':
+      assert [s_[1] for s_ in steps] == [0, 13] and all(s_[2] == 0 for s_ in steps)
+      assert vgg._fp8_chain.ready and not vgg._fp8_chain.disabled
+    else:
+      assert all(s_[1] == 0 and s_[2] == 0 for s_ in steps)
+    res[dtype] = steps[1][0]
+    set_dtype('bf16')
+  for k in sorted(res['bf16'][0]):
+    a, b = res['fp8'][0][k], res['bf16'][0][k]
+    rel = abs(a - b) / max(1e-12, abs(b))
+    print('fp8 VGG stack, step 2 %-26s fp8 %.6e bf16 %.6e rel %.3e' % (k, a, b, rel))
+    if k == 'gen_loss_VGG19':
+      assert 0.5 * b <= a <= 2.0 * b, (k, a, b)
+    else:
+      assert rel < 0.1, (k, a, b)          # (step 2: the two runners' weights already differ by one update; measured <= 6 %)
+  d = abs(res['fp8'][1]['gen_psnr'].value - res['bf16'][1]['gen_psnr'].value)
+  assert d < 0.05, d
 
 
 def test_recnet_runner_graph_replay_equals_eager(env):

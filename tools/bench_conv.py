@@ -24,6 +24,7 @@ CASES = {
     'u32x64': (32, 64, 4, 1, 'reflection', False, 256, 256, 8),
     'u32x64z': (32, 64, 4, 1, 'zero', False, 259, 259, 8),
     'vgg5_2b16': (512, 512, 3, 1, 'zero', False, 16, 16, 16),
+    'vgg3_2c5': (256, 256, 3, 1, 'zero', False, 128, 128, 4), 'vgg4_2c5': (512, 512, 3, 1, 'zero', False, 64, 64, 4),
     'vgg4_2b16': (512, 512, 3, 1, 'zero', False, 32, 32, 16),
     'vgg3_2b16': (256, 256, 3, 1, 'zero', False, 64, 64, 16),
     'vgg4_1b16': (256, 512, 3, 1, 'zero', False, 32, 32, 16),
@@ -67,7 +68,22 @@ def run(name, mode='fwd', iters=20):
   x = torch.randn(b, h, w, ops.pad8(cin), device='cuda').bfloat16()
   y, _ = ops.conv_forward(layer, x, None, False)
   gy = torch.randn_like(y)
-  fn = {'fwd': lambda: ops.conv_forward(layer, x, None, False),
+  if mode in ('fwdb8', 'fwdbq'):
+    # frozen-stack forms (ops.Fp8Chain): fwdbq = bf16 operands, bias + ReLU, fp8 copy + maximum of the output from the epilogue;
+    # fwdb8 = the same with fp8 operands (needs cin == cout: the layer is chained behind itself)
+    fl = ops.ConvLayer(wt, torch.nn.Parameter(torch.randn(cout).cuda() * 0.1), s, pads_for(k, s), border, torch.bfloat16, frozen=True)
+    chain = ops.Fp8Chain([('conv', fl, 0.0), ('conv', fl, 0.0)], x.device)
+    xr = torch.relu(x)
+    ops.frozen_conv_forward(fl, xr, 0.0, None, 0, 0, chain); chain.finish()
+    y1, yq1 = ops.frozen_conv_forward(fl, xr, 0.0, None, 0, 0, chain)
+    slot = None if os.environ.get('F8_NOOUT') else 0      # F8_NOOUT=1: without the fp8 copy / maximum of the output
+    if mode == 'fwdbq':
+      fn8 = lambda: ops.frozen_conv_forward(fl, xr, 0.0, None, 0, slot, chain)
+    else:
+      assert cin == cout
+      fn8 = lambda: ops.frozen_conv_forward(fl, y1, 0.0, yq1, chain.dq_scale_ptr(0), slot, chain)
+  fn = {'fwdb8': lambda: fn8(), 'fwdbq': lambda: fn8(),
+        'fwd': lambda: ops.conv_forward(layer, x, None, False),
         'fwdb': lambda: ops.conv_forward(layer, x, None, True, 0.0),          # bias + ReLU (the VGG forward)
         'fwds': lambda: ops.conv_forward(layer, x, None, False, 1.0, True),   # BatchNorm partial sums (the U-Net forward)
         'dgrad': lambda: ops.conv_dgrad(layer, gy, (h, w)),
@@ -89,7 +105,7 @@ def run(name, mode='fwd', iters=20):
 
 if __name__ == '__main__':
   names = [a for a in sys.argv[1:] if a in CASES] or list(CASES)
-  modes = [a for a in sys.argv[1:] if a in ('fwd', 'fwdb', 'fwds', 'dgrad', 'dgradg', 'wgrad')] or ['fwd']
+  modes = [a for a in sys.argv[1:] if a in ('fwd', 'fwdb', 'fwdb8', 'fwdbq', 'fwds', 'dgrad', 'dgradg', 'wgrad')] or ['fwd']
   for n in names:
     for m in modes:
       run(n, m)
