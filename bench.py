@@ -22,7 +22,7 @@ batches resident in HBM (--device-resident makes that the only leg) and both rat
 {host, resident}, so the PCIe cost is on the line.  After the W warm-up steps the replay settles for --settle-s
 seconds (untimed; the step count is reported as `settle_steps` and included in `warmup_total_steps`), then EXACTLY
 K steps are timed.  Rank 0 prints ONE JSON line; on the default invocation (c3, bf16, one GPU) it also carries
-`other_configs`: short legs of C2 and C5.
+`other_configs`: short legs of C2, C5 and C5 with compute_dtype fp8.
 
 Extra legs (rank 0, outside the timed region):
   roofline      HIP-event brackets around every conv-library launch over instrumented eager steps of the
@@ -652,16 +652,23 @@ def main():
     # attached to the ONE JSON line.  Their CPU-oracle legs are cut to the PSNR probe (+ one timed step for C2).
     args.other_cpu_fast = True
     others = []
-    for cfg in ('c2', 'c5'):
+    # (third leg: config 5's fp8 variant -- the frozen VGG stack on e4m3fn operands + bf16-storage DC -- timed right behind
+    #  its bf16 leg on the same box; no roofline / CPU passes of its own)
+    for cfg, dt in (('c2', 'bf16'), ('c5', 'bf16'), ('c5', 'fp8')):
       try:
-        o = run_leg(args, cfg, 'bf16', DEFAULT_BATCH[cfg], 20, 5, 1, 0, want_roofline=not args.no_roofline,
-                    want_cpu=not args.no_cpu_baseline, min_timed_s=0.5)
+        f8 = dt == 'fp8'
+        o = run_leg(args, cfg, dt, DEFAULT_BATCH[cfg], 20, 5, 1, 0, want_roofline=not args.no_roofline and not f8,
+                    want_cpu=not args.no_cpu_baseline and not f8, min_timed_s=0.5)
         keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'settle_steps', 'ms_per_step', 'dtype', 'config',
                 'algorithmic_tflops', 'launch_mode', 'input', 'input_ab', 'roofline', 'roofline_hbm', 'psnr_delta_db',
                 'psnr_hip_db', 'psnr_cpu_db', 'cpu_baseline', 'final_losses')
         others.append({k: o[k] for k in keep if k in o})
+        if f8:
+          ref = [x for x in others if x.get('dtype') == 'bf16' and x.get('metric') == o.get('metric')]
+          if ref:
+            others[-1]['vs_bf16_leg_same_run'] = round(o['value'] / ref[0]['value'], 4)
       except Exception as e:                      # the headline must survive a failing side leg
-        others.append({'config': {'workload': cfg}, 'error': repr(e)})
+        others.append({'config': {'workload': cfg, 'dtype': dt}, 'error': repr(e)})
     line['other_configs'] = others
   print(json.dumps(line))
 
