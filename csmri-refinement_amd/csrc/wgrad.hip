@@ -397,8 +397,15 @@ __device__ __attribute__((aligned(16))) char w_zero_page[16];
 // map).  The step's (b, oy, ox) origin is then wave-uniform (scalar unit) and a lane's pixel is
 // origin + a per-lane constant, which cuts the address arithmetic from ~100 to ~15 vector
 // instructions per 16-byte piece; the general kernel below is vector-ALU bound on exactly that.
-template <int BP, int BQ, int WP, int WQ, bool REFLECT, bool UPS>
+// DIRECT (16-tap layers without split-K: the discriminator's 512 / 1024-channel layers): the tile's 128 columns are ONE
+// block of 8 input channels x all 16 taps instead of 128 consecutive (tap, channel) indices -- the LDS-DMA source address
+// is per lane and per 16-byte chunk anyway, so the order of the chunks is free -- arranged so that the four column
+// fragments of a wave hold four CONSECUTIVE taps of the same channels: a lane then owns 16 contiguous bytes of the
+// reference-layout gradient [Cout][Cin][4][4] and the kernel writes dW itself.  No fp32 slab (64 MB written and read
+// back for the 1024 -> 1024 layer) and no transposing scatter launch behind it (47 + 28 us per step on the chain).
+template <int BP, int BQ, int WP, int WQ, bool REFLECT, bool UPS, bool DIRECT = false>
 __global__ __launch_bounds__(64 * WP * WQ, WP * WQ == 8 ? 2 : (((BP == 128 && BQ == 128) || (BP == 256 && BQ == 64)) ? 3 : 4)) void wgrad_glds_row_kernel(const WParams p) {
+  static_assert(!DIRECT || (BP == 128 && WP == 2), "DIRECT: 16 chunks of 8 channels, four column fragments per wave");
   constexpr int PS = 64;
   constexpr int NW = WP * WQ;                         // waves: every wave issues 1/NW of a step's LDS-DMA instructions
   constexpr int CP = BP / 8, CQ = BQ / 8;
@@ -427,7 +434,12 @@ __global__ __launch_bounds__(64 * WP * WQ, WP * WQ == 8 ? 2 : (((BP == 128 && BQ
     const int ry = p.Wo >= 64 ? 0 : row / p.Wo, rx = p.Wo >= 64 ? row : row - ry * p.Wo;
     xsrc[j] = w_zero_page; xps[j] = 0; cu[j] = 0; cw[j] = 0;      // columns past NK read zeros
     if (col < p.NK) {
-      const int tap = col / p.Cin, ci = col - tap * p.Cin;
+      int tap = col / p.Cin, ci = col - tap * p.Cin;
+      if constexpr (DIRECT) {
+        // chunk = 8 wp + 2 i + h (wave half wp, fragment i, lane-row pair h) holds tap 8 wp + 4 h + i of channels 8 ptile ..
+        tap = 8 * (chunk >> 3) + 4 * (chunk & 1) + ((chunk >> 1) & 3);
+        ci = ptile * 8;
+      }
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
       cu[j] = ry * p.S + ky - p.pt; cw[j] = rx * p.S + kx - p.pl;
       xsrc[j] = (ci < p.c0) ? p.in0 + (size_t)ci * 2 : p.in1 + (size_t)(ci - p.c0) * 2;
@@ -512,6 +524,23 @@ __global__ __launch_bounds__(64 * WP * WQ, WP * WQ == 8 ? 2 : (((BP == 128 && BQ
     __syncthreads();
   }
   const int r16 = lane & 15;
+  if constexpr (DIRECT) {
+    // lane (r16, g): output channel co, input channels 8 ptile + 4 (g & 1) + r, taps 8 wp + 4 (g >> 1) + i (i = fragment)
+#pragma unroll
+    for (int j = 0; j < FQ; ++j) {
+      const int co = q0 + wq * WTQ + j * 16 + r16;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = ptile * 8 + (g & 1) * 4 + r;
+        float* o = p.dwd + ((size_t)co * p.Cin + ci) * 16 + 8 * wp + 4 * (g >> 1);
+        f32x4_t v = (f32x4_t){acc[0][j][r], acc[1][j][r], acc[2][j][r], acc[3][j][r]};
+        if (p.dw_acc) v += *(const f32x4_t*)o;
+        *(f32x4_t*)o = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < FQ; ++j) {
     const int co = q0 + wq * WTQ + j * 16 + r16;
@@ -1149,6 +1178,16 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
   if (row_aligned) {
     const dim3 grid(p.ptiles * p.qtiles, 1, p.splitk);
     const bool refl = p.border == CSMRI_BORDER_REFLECT;
+    if constexpr (BP == 128 && BQ == 128 && WP == 2 && WQ == 2) {
+      if (p.dwd) {                                     // (wgrad_direct_ok: no split, 16 taps, no upsampling, real == padded channels)
+        CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<128, 128, 2, 2, true, false, true>), lds);
+        CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<128, 128, 2, 2, false, false, true>), lds);
+        if (refl) hipLaunchKernelGGL((wgrad_glds_row_kernel<128, 128, 2, 2, true, false, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((wgrad_glds_row_kernel<128, 128, 2, 2, false, false, true>), grid, dim3(256), lds, st, p);
+        CSMRI_LAUNCH_CHECK();
+        return CSMRI_OK;
+      }
+    }
     CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, true>), lds);
     CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<BP, BQ, WP, WQ, true, false>), lds);
     CSMRI_SET_MAX_LDS((wgrad_glds_row_kernel<BP, BQ, WP, WQ, false, true>), lds);
@@ -1165,6 +1204,22 @@ static int launch_wgrad_glds(const WParams& p, hipStream_t st) {
   }
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
+}
+
+// the geometry conditions of the row-aligned kernel (launch_wgrad_glds)
+static bool wgrad_row_launchable(const csmri_wgrad_desc* d) {
+  return wgrad_row_aligned(d) && (long long)d->B * d->Hin * d->Win < (1 << 24) &&
+         d->in0_pix_stride < (1 << 22) && d->in1_pix_stride < (1 << 22) &&
+         (long long)d->B * d->Hin * d->Win * (d->in0_pix_stride > d->in1_pix_stride ? d->in0_pix_stride : d->in1_pix_stride) * 2 < (1ll << 32);
+}
+#ifndef WGRAD_DIRECT
+#define WGRAD_DIRECT 1
+#endif
+// wgrad_glds_row_kernel<128,128,2,2,..,DIRECT>: writes the reference-layout gradient itself
+static bool wgrad_direct_ok(const csmri_wgrad_desc* d, int BP, int BQ, bool row) {
+  return WGRAD_DIRECT && row && d->dtype == CSMRI_BF16 && BP == 128 && BQ == 128 && (d->splitk <= 1) && !d->defer_finish &&
+         d->KH * d->KW == 16 && !d->upsample && d->Cin_real == d->Cin && d->Cout_real == d->Cout && d->Cout % 128 == 0 &&
+         !((uintptr_t)d->dw & 15);
 }
 
 // template instance csmri_wgrad dispatches to for this problem, spelled as rocprofv3 prints it
@@ -1184,8 +1239,9 @@ extern "C" int csmri_wgrad_kernel_name(const csmri_wgrad_desc* d, char* buf, int
   const bool row = wgrad_row_aligned(d) && (long long)d->B * d->Hin * d->Win < (1 << 24) &&
                    d->in0_pix_stride < (1 << 22) && d->in1_pix_stride < (1 << 22) &&
                    (long long)d->B * d->Hin * d->Win * (d->in0_pix_stride > d->in1_pix_stride ? d->in0_pix_stride : d->in1_pix_stride) * 2 < (1ll << 32);
-  if (row) snprintf(buf, n, "wgrad_glds_row_kernel<%d, %d, %d, %d, %s, %s>", c.BP, c.BQ, wp, wq,
-                    d->border == CSMRI_BORDER_REFLECT ? "true" : "false", d->upsample ? "true" : "false");
+  if (row) snprintf(buf, n, "wgrad_glds_row_kernel<%d, %d, %d, %d, %s, %s, %s>", c.BP, c.BQ, wp, wq,
+                    d->border == CSMRI_BORDER_REFLECT ? "true" : "false", d->upsample ? "true" : "false",
+                    wgrad_direct_ok(d, c.BP, c.BQ, row) ? "true" : "false");
   else snprintf(buf, n, "wgrad_glds_kernel<%d, %d, %d, %d>", c.BP, c.BQ, wp, wq);
   return CSMRI_OK;
 }
@@ -1220,6 +1276,8 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
     if (e != hipSuccess) return (int)e;
   }
   int rc;
+  bool direct = false;
+  p.dwd = nullptr; p.dw_acc = 0;
 #define WG(DT_, BP_, BQ_, WP_, WQ_) rc = launch_wgrad<DT_, BP_, BQ_, WP_, WQ_>(p, st)
   const bool patch = thin || wpatch_eligible(d) || wrow_eligible(d);   // (all leave their bias-gradient partial rows behind the slabs)
   if (thin) {
@@ -1229,6 +1287,8 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
     q.nsteps = d->db ? 1 : 0;                      // wpatch / wrow reuse the field: also produce the bias-gradient partials
     rc = wrow_eligible(d) ? wrow_launch(q, d, st) : wpatch_launch(q, d, st);
   } else if (d->dtype == CSMRI_BF16) {
+    direct = wgrad_direct_ok(d, c.BP, c.BQ, wgrad_row_launchable(d));
+    if (direct) { p.dwd = d->dw; p.dw_acc = d->accumulate; }
     if (c.BQ == 128) rc = launch_wgrad_glds<128, 128, 2, 2>(p, st);
     else if (c.BQ == 64 && c.BP == 256) rc = launch_wgrad_glds<256, 64, 4, 1>(p, st);
     else if (c.BQ == 64) rc = launch_wgrad_glds<128, 64, 2, 2>(p, st);
@@ -1257,7 +1317,9 @@ extern "C" int csmri_wgrad(const csmri_wgrad_desc* d, void* stream) {
     }
     return CSMRI_OK;
   }
-  if (p.splitk <= 8) {        // big layers: bandwidth-bound transposing copy
+  if (direct) {
+    // (the kernel wrote the reference-layout gradient itself)
+  } else if (p.splitk <= 8) {        // big layers: bandwidth-bound transposing copy
     if (d->KH * d->KW <= 16 && (long long)d->Cout_real * ((d->Cin_real + 63) / 64) >= 4096)
       hipLaunchKernelGGL((wgrad_scatter_t_rows_kernel<4>), dim3((d->Cout_real + 3) / 4, (d->Cin_real + 63) / 64), dim3(256), 0, st,
                          d->slab, p.splitk, d->Cout, p.NK, d->Cin, d->KH * d->KW, d->Cin_real, d->Cout_real, d->dw,

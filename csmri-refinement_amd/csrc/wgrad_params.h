@@ -10,6 +10,7 @@ struct WParams {
   float* slab; int splitk; int M, NK, nsteps, steps_per_split, ptiles, qtiles;
   int wr_items, wr_seg, wr_xs, wr_segs;   // wrow: work items, rows per item, column strips per image, segments per strip
   int stages;   // wpatch: 2 = the next tile's images stream in under this tile's MFMAs (LDS permitting), 1 = in place
+  float* dwd; int dw_acc;   // wgrad_glds_row DIRECT: the reference-layout gradient itself (no slab, no scatter launch), accumulate flag
 };
 
 typedef __attribute__((address_space(1))) const void* wgptr_t;

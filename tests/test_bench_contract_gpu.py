@@ -42,16 +42,19 @@ def _check_headline(d, steps, warmup):
 
 
 def test_bench_json_line_schema_with_other_configs():
-  """The default invocation: the C3 headline plus short C2 and C5 legs (`other_configs`)."""
+  """The default invocation: the C3 headline plus short C2, C5 and C5-with-compute_dtype-fp8 legs (`other_configs`)."""
   out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2',
                         '--no-cpu-baseline', '--settle-s', '0.2'], capture_output=True, text=True, timeout=1200,
                        cwd=ROOT)
   d = _one_line(out)
   _check_headline(d, 3, 2)
   others = d['other_configs']
-  assert len(others) == 2 and not any('error' in o for o in others), others
-  c2, c5 = others
-  assert 'C2' in c2['config']['workload'] and 'C5' in c5['config']['workload']
+  assert len(others) == 3 and not any('error' in o for o in others), others
+  c2, c5, c5f8 = others
+  assert 'C2' in c2['config']['workload'] and 'C5' in c5['config']['workload'] and 'C5' in c5f8['config']['workload']
+  # BASELINE config 5's fp8 variant right behind its bf16 leg: frozen VGG stack on e4m3fn operands + bf16-storage FFT
+  assert c5f8['dtype'] == 'fp8' and c5f8['value'] > 0 and 0.8 < c5f8['vs_bf16_leg_same_run'] < 1.3, c5f8
+  others = [c2, c5]
   # the C2 leg's roofline describes the kernel the timed step runs (the fused conv-block backward), not the per-layer
   # backward it replaces
   assert c2['roofline']['kernel'] == 'convblock_bwd_kernel', c2['roofline']

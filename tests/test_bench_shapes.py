@@ -198,6 +198,12 @@ def test_bench_layer_vs_oracle_bf16(hip, case):
         print('%-16s wgrad rel_l2 %.3e  bias %.3e  %s' % (name, ew, eb, [e[1:] for e in log[n0:]]))
         assert ew < 2e-5, (name, 'wgrad', ew)
         assert eb < 2e-5, (name, 'bgrad', eb)
+        # the accumulating form (a second backward pass into the same .grad): twice the gradient
+        ops.conv_wgrad(layer, x0, x1, gyd, accumulate=True)
+        ops.join_wgrad_stream()
+        torch.cuda.synchronize()
+        ew2, eb2 = rel_l2(wd.grad.cpu(), 2.0 * wr.grad), rel_l2(bd.grad.cpu(), 2.0 * br.grad)
+        assert ew2 < 2e-5 and eb2 < 2e-5, (name, 'wgrad accumulate', ew2, eb2)
   finally:
     ops.LAUNCH_LOG = None
   SEEN[name] = list(log)
