@@ -49,10 +49,13 @@ def test_bench_json_line_schema_with_other_configs():
   d = _one_line(out)
   _check_headline(d, 3, 2)
   others = d['other_configs']
-  assert len(others) == 3 and not any('error' in o for o in others), others
+  assert len(others) == 3 and not any('error' in o for o in others[:2]), others
   c2, c5, c5f8 = others
-  assert 'C2' in c2['config']['workload'] and 'C5' in c5['config']['workload'] and 'C5' in c5f8['config']['workload']
-  # BASELINE config 5's fp8 variant right behind its bf16 leg: frozen VGG stack on e4m3fn operands + bf16-storage FFT
+  assert 'C2' in c2['config']['workload'] and 'C5' in c5['config']['workload']
+  # BASELINE config 5's fp8 variant right behind its bf16 leg (a child process of bench.py): frozen VGG stack on e4m3fn
+  # operands + bf16-storage FFT
+  assert 'error' not in c5f8, c5f8
+  assert 'C5' in c5f8['config']['workload']
   assert c5f8['dtype'] == 'fp8' and c5f8['value'] > 0 and 0.8 < c5f8['vs_bf16_leg_same_run'] < 1.3, c5f8
   others = [c2, c5]
   # the C2 leg's roofline describes the kernel the timed step runs (the fused conv-block backward), not the per-layer
