@@ -180,6 +180,7 @@ _SIGS = {
                                  vp, vp, i32, vp]),
     'csmri_act_bwd': (i32, [i32, vp, i32, vp, i32, vp, i32, i64, i32, f32, vp, i32, vp]),
     'csmri_maxpool2': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    'csmri_maxpool2_bwd_pooled_gate': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i32, f32, vp]),
     'csmri_maxpool2_q': (i32, [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
     'csmri_fp8_scales_update': (i32, [vp, vp, i32, i32, vp]),
     'csmri_maxpool2_bwd': (i32, [i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),

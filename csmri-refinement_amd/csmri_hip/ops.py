@@ -1359,13 +1359,19 @@ def maxpool2_fwd(x, q_scale_ptr=0, amax_ptr=0, want_q=False):
   return y, arg
 
 
-def maxpool2_bwd(gy, arg, shape, g_src=None, g_slope=1.0, g_add=None):
+def maxpool2_bwd(gy, arg, shape, g_src=None, g_slope=1.0, g_add=None, g_pooled=None):
   """Gradient of MaxPool2d(2,2).  ``g_add``: a second gradient of the pool's input, added in the same pass;
   ``g_src`` (the output of the activation layer that fed the pool): the result also carries that activation's
-  derivative (csmri_maxpool2_bwd_act)."""
+  derivative (csmri_maxpool2_bwd_act); ``g_pooled``: the same with the pool's OUTPUT as the gate (same result, a
+  quarter of the gate's bytes: csmri_maxpool2_bwd_pooled_gate)."""
   b, h, w, c = shape
   gy = as_nhwc(gy)
   gx = torch.empty(b, h, w, c, dtype=gy.dtype, device=gy.device)
+  if g_pooled is not None:
+    assert g_src is None and g_add is None and g_pooled.dtype == gy.dtype and tuple(g_pooled.shape) == (b, h // 2, w // 2, c)
+    lib.call('csmri_maxpool2_bwd_pooled_gate', dt_of(gy), gy.data_ptr(), gy.stride(2), arg.data_ptr(), gx.data_ptr(),
+             gx.stride(2), b, h, w, c, g_pooled.data_ptr(), g_pooled.stride(2), float(g_slope), stream())
+    return gx
   if g_src is not None or g_add is not None:
     for t in (g_src, g_add):
       assert t is None or (t.dtype == gy.dtype and tuple(t.shape) == (b, h, w, c) and t.stride(3) == 1)
@@ -1506,6 +1512,9 @@ def frozen_conv_forward(layer, x, slope, xq=None, dq_ptr=0, out_slot=None, chain
   return y, yq
 
 
+POOLED_GATE = True     # frozen stack: a pool's backward gates with the pooled tensor (tests turn it off for A/B)
+
+
 class FrozenConvStackPair(torch.autograd.Function):
   """A frozen conv/ReLU/max-pool stack (VGG19 features) applied to a (prediction, target)
   pair as ONE batched forward: the stack has no batch-coupled op, so concatenating the two
@@ -1533,6 +1542,7 @@ class FrozenConvStackPair(torch.autograd.Function):
     else:
       x = torch.cat((p_in, t_in), 0)
     saved, shapes, feats = [], [], []
+    pooled = {}
     if chain is not None and chain.disabled:
       chain = None
     xq, xq_slot = None, None              # fp8 copy of x and its slot in the chain (Fp8Chain)
@@ -1560,12 +1570,14 @@ class FrozenConvStackPair(torch.autograd.Function):
           x, arg = maxpool2_fwd(x)
           xq, xq_slot = None, None
         saved.append(arg)
+        pooled[i] = x                      # the gate of this pool's backward (the producer's ReLU at the routed position)
       if i in taps:
         feats.append(x)
     if chain is not None:
       chain.finish()
     ctx.plan, ctx.taps, ctx.b, ctx.shapes = plan, taps, b, shapes
-    ctx.save_for_backward(*saved)
+    ctx.pool_keys = sorted(pooled) if POOLED_GATE else []
+    ctx.save_for_backward(*(saved + [pooled[k] for k in ctx.pool_keys]))
     outs = [f[:b] for f in feats] + [f[b:] for f in feats]
     ctx.set_materialize_grads(False)        # no zero fills for the target half / unused feature maps
     ctx.mark_non_differentiable(*outs[len(feats):])
@@ -1575,6 +1587,8 @@ class FrozenConvStackPair(torch.autograd.Function):
   def backward(ctx, *gouts):
     plan, taps, b = ctx.plan, sorted(ctx.taps), ctx.b
     saved = ctx.saved_tensors
+    npk = len(ctx.pool_keys)
+    pooled = dict(zip(ctx.pool_keys, saved[len(saved) - npk:])) if npk else {}
     gmap = {t: gouts[j] for j, t in enumerate(taps)}
     g = None
     act_done = False       # True when g already carries the activation derivative of plan[i]
@@ -1610,7 +1624,10 @@ class FrozenConvStackPair(torch.autograd.Function):
         if prev is not None and prev[0] == 'conv' and prev[2] != 1.0 and \
             saved[i - 1].dtype == g.dtype:
           # the pool's producer is an activated conv: its derivative rides on the un-pooling pass
-          g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i], g_src=saved[i - 1][:b], g_slope=prev[2])
+          if i in pooled and pooled[i].dtype == g.dtype:
+            g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i], g_pooled=pooled[i][:b], g_slope=prev[2])
+          else:
+            g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i], g_src=saved[i - 1][:b], g_slope=prev[2])
           act_done = True
         else:
           g = maxpool2_bwd(g, saved[i][:b], ctx.shapes[i])

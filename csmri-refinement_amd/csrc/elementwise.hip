@@ -409,9 +409,12 @@ __global__ void maxpool2_kernel(int dt, const void* x, int xps, void* y, int yps
 // gadd != null: a second gradient of the pooled tensor's source (skip connection) is added in the same pass.
 // gsrc != null: dx additionally carries the activation derivative of the layer that produced the pooled
 // tensor (gsrc = its output): one pass instead of maxpool2_bwd + act_bwd over the full-resolution gradient
+// gpooled: gsrc is the POOLED tensor (the pool's output): at the position the gradient is routed to, the producer's output
+// IS the pooled value, everywhere else the result is zero whatever the gate says -- same bits as gating with the
+// full-resolution tensor, a quarter of its bytes (csmri_maxpool2_bwd_pooled_gate)
 __global__ void maxpool2_bwd_kernel(int dt, const void* dy, int dyps, const uint8_t* arg, void* dx,
                                     int dxps, int B, int H, int W, int C, const void* gsrc, int gps,
-                                    float gslope, const void* gadd, int gaps) {
+                                    float gslope, const void* gadd, int gaps, int gpooled = 0) {
   const int nv = C >> 2, Ho = H >> 1, Wo = W >> 1;
   GRID_STRIDE32(i, (long long)B * Ho * Wo * nv) {
     const int c = (int)(i % nv) * 4;
@@ -427,7 +430,7 @@ __global__ void maxpool2_bwd_kernel(int dt, const void* dy, int dyps, const uint
       for (int q = 0; q < 4; ++q) o[q] = ((a >> (8 * q)) & 0xff) == (unsigned)k ? g[q] : 0.f;
       if (gadd) o += load4(gadd, (base + (k >> 1) * W + (k & 1)) * gaps + c, dt);
       if (gsrc) {
-        const f32x4_t s = load4(gsrc, (base + (k >> 1) * W + (k & 1)) * gps + c, dt);
+        const f32x4_t s = load4(gsrc, (gpooled ? (long long)p : base + (k >> 1) * W + (k & 1)) * gps + c, dt);
         for (int q = 0; q < 4; ++q) o[q] = s[q] > 0.f ? o[q] : o[q] * gslope;
       }
       store4(dx, (base + (k >> 1) * W + (k & 1)) * dxps + c, dt, o);
@@ -466,6 +469,18 @@ extern "C" int csmri_maxpool2_bwd_act(int dtype, const void* dy, int dy_pix_stri
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dtype,
                      dy, dy_pix_stride, argmax, dx, dx_pix_stride, B, H, W, C, g_src, g_pix_stride, g_slope, g_add,
                      g_add_pix_stride);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+extern "C" int csmri_maxpool2_bwd_pooled_gate(int dtype, const void* dy, int dy_pix_stride, const uint8_t* argmax,
+                                              void* dx, int dx_pix_stride, int B, int H, int W, int C,
+                                              const void* g_pooled, int g_pix_stride, float g_slope, void* stream) {
+  CSMRI_CHECK_ARG(dy && dx && argmax && g_pooled && H % 2 == 0 && W % 2 == 0 && C % 4 == 0);
+  long long n = (long long)B * (H / 2) * (W / 2) * (C / 4);
+  CSMRI_CHECK_I32((long long)B * H * W * C);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dtype,
+                     dy, dy_pix_stride, argmax, dx, dx_pix_stride, B, H, W, C, g_pooled, g_pix_stride, g_slope,
+                     (const void*)nullptr, 0, 1);
   CSMRI_LAUNCH_CHECK();
   return CSMRI_OK;
 }

@@ -463,6 +463,13 @@ int csmri_maxpool2_bwd_act(int dtype, const void* dy, int dy_pix_stride, const u
                            int g_pix_stride, float g_slope, const void* g_add, int g_add_pix_stride,
                            void* stream);
 
+/* The activated-producer form with the POOLED tensor as the gate (g_pooled = the pool's output [B,H/2,W/2,C]): where the
+ * gradient is routed the producer's output is the pooled value itself, elsewhere dx is zero either way -- the same bits
+ * as csmri_maxpool2_bwd_act with the full-resolution g_src, for a quarter of its bytes. */
+int csmri_maxpool2_bwd_pooled_gate(int dtype, const void* dy, int dy_pix_stride, const uint8_t* argmax,
+                                   void* dx, int dx_pix_stride, int B, int H, int W, int C,
+                                   const void* g_pooled, int g_pix_stride, float g_slope, void* stream);
+
 /* ------------------------------------------------------------------------
  * small fused ops of the refinement wrapper / losses / optimizer
  * ---------------------------------------------------------------------- */

@@ -493,10 +493,12 @@ def test_maxpool_skip_and_act_fused_backward(hip, dtype):
     if dtype == torch.bfloat16:
       z = z.bfloat16().float()
     zd = to_dev_nhwc(z, dtype)
-    _, arg = ops.maxpool2_fwd(zd)
+    pooled, arg = ops.maxpool2_fwd(zd)
     got = ops.maxpool2_bwd(to_dev_nhwc(g, dtype), arg, tuple(zd.shape), g_src=zd, g_slope=slope)
     two = ops.act_bwd(ops.maxpool2_bwd(to_dev_nhwc(g, dtype), arg, tuple(zd.shape)), zd, slope)
     assert torch.equal(got, two)
+    # the same with the POOLED tensor as the gate (csmri_maxpool2_bwd_pooled_gate: what the frozen VGG stack's backward uses)
+    assert torch.equal(ops.maxpool2_bwd(to_dev_nhwc(g, dtype), arg, tuple(zd.shape), g_pooled=pooled, g_slope=slope), got)
     zr = z.clone().requires_grad_(True)
     F.max_pool2d(zr, 2, 2).backward(g)
     ref = zr.grad * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
@@ -1314,3 +1316,4 @@ def test_dropout2d_mask_matches_the_philox_oracle_bit_for_bit(hip, n, p):
     assert torch.equal(out[:n].cpu(), want), (n, p, call)
     assert bool((out[n:] == -3.0).all())
   assert hip.lib.raw('csmri_dropout2d_mask')(out.data_ptr(), n, 1.0, st.data_ptr(), None) == -1     # p < 1
+
