@@ -83,6 +83,8 @@ def parse():
                  help='A/B: launch the look-ahead graph (frozen RecNet of batch t+1) AFTER the step graph instead of before')
   p.add_argument('--finish-multi', default='auto', choices=['auto', '1', '0'],
                  help='A/B: one slab-reduction launch per backward pass (csmri_wgrad_finish_multi) instead of per layer')
+  p.add_argument('--inprocess-legs', action='store_true',
+                 help='diagnostic: run the fp8 side leg in this process too (tools/segv_hunt.sh)')
   p.add_argument('--no-other-configs', action='store_true',
                  help='skip the short C2 and C5 legs attached to the default (c3, bf16, N=1) line')
   a = p.parse_args()
@@ -167,22 +169,33 @@ class PinnedHostLoader(object):
     import torch
     self.n, self.batch_size = n, host_batches[0]['inp'].shape[0]
     self.resident = resident
+    # keyed by id() -- and the entry KEEPS the list alive (first element of the tuple), so the id cannot be handed to the
+    # next leg's list while the entry exists.  Round 5 keyed by the bare id of a list that died with its leg: a later
+    # leg whose list landed on the same address got the earlier leg's batches.
     key = id(host_batches)
     if resident:
       if key not in PinnedHostLoader._resident:
-        PinnedHostLoader._resident[key] = [{k: v.to(device) for k, v in b.items()} for b in host_batches]
-      self.dev = PinnedHostLoader._resident[key]
+        PinnedHostLoader._resident[key] = (host_batches, [{k: v.to(device) for k, v in b.items()} for b in host_batches])
+      assert PinnedHostLoader._resident[key][0] is host_batches
+      self.dev = PinnedHostLoader._resident[key][1]
       return
     if key not in PinnedHostLoader._pinned:
       with _near_gpu(device):        # page-lock on the GPU's own NUMA node (2-socket hosts: H2D from the far node is slower)
-        PinnedHostLoader._pinned[key] = [{k: v.pin_memory() for k, v in b.items()} for b in host_batches]
-    self.host = PinnedHostLoader._pinned[key]
+        PinnedHostLoader._pinned[key] = (host_batches, [{k: v.pin_memory() for k, v in b.items()} for b in host_batches])
+    assert PinnedHostLoader._pinned[key][0] is host_batches
+    self.host = PinnedHostLoader._pinned[key][1]
     # the tensors of a batch are copied on COPY_STREAMS streams in turn: one hipMemcpyAsync stream is served by one
     # SDMA engine (17-28 GB/s on the boxes measured), two move a 134 MB C2 batch in parallel
     self.copy_streams = [torch.cuda.Stream() for _ in range(max(1, PinnedHostLoader.COPY_STREAMS))]
     self.dev = [{k: torch.empty_like(v, device=device) for k, v in host_batches[0].items()} for _ in range(4)]
     self.ready = [[torch.cuda.Event() for _ in self.copy_streams] for _ in self.dev]
     self.primed = False
+
+  @staticmethod
+  def forget(host_batches):
+    """End of a leg: release its pinned pages and resident copies (and with them the key)."""
+    PinnedHostLoader._pinned.pop(id(host_batches), None)
+    PinnedHostLoader._resident.pop(id(host_batches), None)
 
   def prime(self):
     """Steady state of the copy pipeline at the moment the clock starts: in a running epoch the copy of batch 0 was issued
@@ -429,6 +442,11 @@ def roofline(runner, loader_factory, dtype, steps=2, config='c3'):
   return rl, table, conv_ms, hbm
 
 
+def dist_forced():
+  from training import distributed as dist_utils
+  return dist_utils.exchange_active()
+
+
 def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=True, want_cpu=True, min_timed_s=0.0):
   """One measured leg: build the runner of `config`, W warm-up steps, settle, EXACTLY `steps` timed steps between
   barrier + synchronize pairs, then (outside the timed region) the roofline brackets and the CPU-oracle legs.
@@ -528,7 +546,16 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
       dt_ = float(t.item())
     return dt_, res
 
+  from training.distributed import GradBucket
+  GradBucket.TIMING = [] if ws > 1 or dist_forced() else None
   dt, (losses, metrics) = timed(resident)
+  exposed_comm, grad_payload = None, None
+  if GradBucket.TIMING is not None:
+    # event pairs around every wait for a gradient exchange (GradBucket.wait): the time the step's stream STOOD there
+    pairs, GradBucket.TIMING = GradBucket.TIMING, None
+    exposed_comm = round(sum(a.elapsed_time(b) for a, b in pairs) / max(1, steps), 4)
+    grad_payload = os.environ.get('CSMRI_GRAD_PAYLOAD', 'bf16')
+  part = getattr(args, 'participation', None) or {}
   dt_resident = None
   if not resident and not args.no_input_ab:
     # the A/B leg: the same K steps with the batches already in HBM (its rate is reported, never `value`)
@@ -567,6 +594,9 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
   line = {
       'metric': metric, 'value': round(value, 2), 'unit': 'slices/s',
       'n_gpus': ws, 'steps': steps, 'warmup': warmup, 'warmup_total_steps': warmup + settle_steps,
+      'backend': part.get('backend'), 'collective_ranks': part.get('collective_ranks'),
+      'rccl_ranks': part.get('rccl_ranks'), 'distinct_gpus': part.get('distinct_gpus'),
+      'grad_payload': grad_payload, 'exposed_comm_ms_per_step': exposed_comm,
       'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
       'input': 'batches resident in HBM when the timed region starts (%d distinct batches cycled)' % N_HOST_BATCHES
@@ -601,7 +631,7 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
     ref_runner, _ = build_runner(config, dtype, batch)
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     if gan:
-      if config == 'c3' or not args.other_cpu_fast:
+      if not args.other_cpu_fast:        # (side legs of the default line: PSNR probes only)
         line['cpu_baseline'] = cpu_baseline_c3(ref_runner, host_batches[0], all_threads=args.cpu_all_threads)
       # the 0.01 dB criterion where the U-Net contributes (scale preset; the reference starts at scale = 0
       # where pred == pretrained, reported beside it)
@@ -628,21 +658,66 @@ def run_leg(args, config, dtype, batch, steps, warmup, ws, rank, want_roofline=T
       line['gpu_over_cpu'] = round(value / line['cpu_baseline']['value'], 1)
     del ref_runner
   del runner
+  torch.cuda.synchronize()
+  PinnedHostLoader.forget(host_batches)
   import gc
   gc.collect()
   torch.cuda.empty_cache()
   return line
 
 
+def spawn_ranks(args, argv):
+  """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (one per GPU, RCCL), as a
+  CHILD process and BEFORE this process has imported torch or touched the GPU, and exit with its code.  A bare
+  `--gpus 8` must never quietly measure one GPU."""
+  import subprocess
+  port = os.environ.get('MASTER_PORT') or str(29500 + os.getpid() % 2000)
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + list(argv)
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL needs it on this host driver
+  return subprocess.call(cmd, env=env)
+
+
+def participation(ws, rank, dev):
+  """Who really took part: every rank adds a one-hot row over the job's process group (the backend that also carries
+  the gradient exchange) -- `collective_ranks` counts the ranks whose contribution arrived; `distinct_gpus` counts the
+  different (host, PCI bus id) pairs behind them (2 ranks on one GPU over gloo, the functional-test mode, says 1)."""
+  import socket
+  import torch
+  import torch.distributed as dist
+  props = torch.cuda.get_device_properties(dev)
+  me = '%s/%04x:%02x:%02x' % (socket.gethostname(), props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+  if ws == 1:
+    return {'backend': None, 'collective_ranks': 1, 'rccl_ranks': 0, 'distinct_gpus': 1, 'gpus': [me]}
+  hot = torch.zeros(ws, device=dev)
+  hot[rank] = 1.0
+  dist.all_reduce(hot, op=dist.ReduceOp.SUM)
+  names = [None] * ws
+  dist.all_gather_object(names, me)
+  backend = dist.get_backend()
+  n = int((hot > 0.5).sum().item())
+  assert float(hot.max().item()) == 1.0, 'a rank id was used twice: %r' % hot.tolist()
+  return {'backend': backend, 'collective_ranks': n, 'rccl_ranks': n if backend == 'nccl' else 0,
+          'distinct_gpus': len(set(names)), 'gpus': names}
+
+
 def main():
   args = parse()
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(spawn_ranks(args, sys.argv[1:]))
   import torch
   from training import distributed as dist_utils
   ws = dist_utils.init_from_env()
   rank = dist_utils.rank()
   local = int(os.environ.get('LOCAL_RANK', '0'))
   torch.cuda.set_device(local if torch.cuda.device_count() > local else 0)
-  assert ws == max(1, args.gpus) or ws == 1, (ws, args.gpus)
+  if ws != max(1, args.gpus):
+    raise SystemExit('bench.py: --gpus %d but the process group has %d rank(s) (WORLD_SIZE=%s): refusing to report a '
+                     'number for a job that is not the one asked for' % (args.gpus, ws, os.environ.get('WORLD_SIZE')))
+  args.participation = participation(ws, rank, torch.device('cuda', torch.cuda.current_device()))
+  if ws > 1 and args.participation['collective_ranks'] != ws:
+    raise SystemExit('bench.py: %d of %d ranks answered the collective' % (args.participation['collective_ranks'], ws))
   line = run_leg(args, args.config, args.dtype, args.batch, args.steps, args.warmup, ws, rank,
                  want_roofline=not args.no_roofline, want_cpu=not args.no_cpu_baseline)
   if rank != 0:
@@ -654,15 +729,20 @@ def main():
     others = []
     # (third leg: config 5's fp8 variant -- the frozen VGG stack on e4m3fn operands + bf16-storage DC -- timed right behind
     #  its bf16 leg on the same box; no roofline / CPU passes of its own)
-    for cfg, dt in (('c2', 'bf16'), ('c5', 'bf16'), ('c5', 'fp8')):
+    # ('c3', 'fp32'): the headline workload in the REFERENCE's arithmetic (fp32 operands on the fp32-matrix MFMA path,
+    #  same kernels' exact mode), driver-timed on the same box; its roofline is priced against the 157.3 TFLOP/s fp32 peak
+    for cfg, dt in (('c3', 'fp32'), ('c2', 'bf16'), ('c5', 'bf16'), ('c5', 'fp8')):
       try:
         f8 = dt == 'fp8'
-        if f8:
+        if f8 and not args.inprocess_legs:
           # the fp8 variant runs as a CHILD process (same interpreter, same file): the newest code path of the tree
           # cannot take the headline down with it, whatever it does
           import subprocess
-          r = subprocess.run([sys.executable, os.path.abspath(__file__), '--config', cfg, '--dtype', dt, '--steps', '80',
-                              '--warmup', '5', '--no-other-configs', '--no-cpu-baseline', '--no-roofline'],
+          ref = [x for x in others if x.get('dtype') == 'bf16' and 'radial' in x.get('metric', '')]
+          r = subprocess.run([sys.executable, os.path.abspath(__file__), '--config', cfg, '--dtype', dt,
+                              '--steps', str(ref[0]['steps'] if ref else 80),     # the bf16 leg's K, W and settling
+                              '--warmup', '5', '--settle-s', str(args.settle_s),
+                              '--no-other-configs', '--no-cpu-baseline', '--no-roofline'],
                              capture_output=True, text=True, timeout=600)
           lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
           if r.returncode != 0 or not lines:
@@ -679,6 +759,8 @@ def main():
           ref = [x for x in others if x.get('dtype') == 'bf16' and x.get('metric') == o.get('metric')]
           if ref:
             others[-1]['vs_bf16_leg_same_run'] = round(o['value'] / ref[0]['value'], 4)
+            others[-1]['vs_bf16_note'] = ('same box, same K / W / settling; the fp8 leg is a child process with its own '
+                                          'graph capture: indicative, +-1 %')
       except Exception as e:                      # the headline must survive a failing side leg
         others.append({'config': {'workload': cfg, 'dtype': dt}, 'error': repr(e)})
     line['other_configs'] = others

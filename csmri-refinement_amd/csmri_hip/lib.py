@@ -266,8 +266,19 @@ HBM_BYTES = {
 }
 
 
+class CsmriError(RuntimeError):
+  """A non-zero status of a C-ABI entry point; ``code`` is the status (CSMRI_E_* or a HIP error code)."""
+
+  def __init__(self, name, code):
+    super(CsmriError, self).__init__('%s failed: %s (%d)' % (name, error_string(code), code))
+    self.entry, self.code = name, int(code)
+
+
+E_UNSUPPORTED = -2      # CSMRI_E_UNSUPPORTED (include/csmri_hip.h)
+
+
 def call(name, *args):
-  """Call a status-returning entry point; raise RuntimeError on failure."""
+  """Call a status-returning entry point; raise CsmriError (a RuntimeError) on failure."""
   if HBM_PROFILE is not None and name in HBM_BYTES:
     import torch
     label, fn = HBM_BYTES[name]
@@ -279,7 +290,7 @@ def call(name, *args):
   else:
     rc = getattr(_lib, name)(*args)
   if rc != 0:
-    raise RuntimeError('%s failed: %s (%d)' % (name, error_string(rc), rc))
+    raise CsmriError(name, rc)
 
 
 def raw(name):

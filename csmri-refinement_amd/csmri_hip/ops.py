@@ -1552,10 +1552,15 @@ class FrozenConvStackPair(torch.autograd.Function):
         try:
           y, yq = frozen_conv_forward(layer, x, slope, xq if (chain is not None and Fp8Chain.layer_ok(layer)) else None,
                                       chain.dq_scale_ptr(xq_slot) if xq is not None else 0, out_slot, chain)
-        except RuntimeError:
-          if chain is None or chain.ready:
+        except lib.CsmriError as e:
+          # ONLY "this shape is outside the fp8-capable kernel" (tiny feature maps) turns the chain off -- for good, and
+          # said aloud: the stack then runs bf16.  Anything else (a launch failure, out of memory) is an error.
+          if chain is None or e.code != lib.E_UNSUPPORTED:
             raise
-          # a layer of this stack is outside the fp8-capable kernel's shapes (tiny feature maps): the whole stack stays bf16
+          import logging
+          logging.getLogger(__name__).warning(
+              'fp8 chain disabled: layer %d (%d -> %d channels at %d x %d) is outside the fp8 patch kernel; the frozen '
+              'stack runs bf16', i, layer.cin, layer.cout, x.shape[1], x.shape[2])
           chain.disabled, chain, xq, out_slot = True, None, None, None
           y, yq = frozen_conv_forward(layer, x, slope)
         saved.append(y)

@@ -129,3 +129,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
 }
+
+// Saturation in front of v_cvt_pk_fp8_f32: with DELAYED scaling (the scale of step t comes from the maximum seen at
+// step t - 1, one bit of headroom) a tensor that grows more than ~3.5x between two forwards would leave the e4m3fn range
+// (448), and the unclamped convert does not saturate.  Inside the range the clamp is the identity, so the bytes stay
+// bit for bit csmri_quantize_fp8's.
+__device__ __forceinline__ float sat_e4m3(float x) { return __builtin_amdgcn_fmed3f(x, -448.f, 448.f); }

@@ -392,8 +392,8 @@ __global__ void maxpool2_kernel(int dt, const void* x, int xps, void* y, int yps
       }
       if (yq) {
         int r = 0;
-        r = __builtin_amdgcn_cvt_pk_fp8_f32(best[0] * qscale, best[1] * qscale, r, false);
-        r = __builtin_amdgcn_cvt_pk_fp8_f32(best[2] * qscale, best[3] * qscale, r, true);
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(sat_e4m3(best[0] * qscale), sat_e4m3(best[1] * qscale), r, false);
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(sat_e4m3(best[2] * qscale), sat_e4m3(best[3] * qscale), r, true);
         *(uint32_t*)(yq + (long long)p * yqps + c) = (uint32_t)r;
       }
     }

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * NW, NST == 1 ? 3 : (NST == 2 ? 2 : 1)) void gc
       }
       if (!STATS && has_gate) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gt[i][r] > 0.f ? v[r] : v[r] * p.gslope;
+        for (int r = 0; r < 4; ++r) v[r] = (gt[i][r] > 0.f || !inside) ? v[r] : v[r] * p.gslope;   // halo leaves ungated
       }
       vv[i] = v;
     }
@@ -406,6 +406,7 @@ int gconv_glds_eligible(const csmri_gconv_desc* d) {
   if (d->in1 && d->c0 % 64) return 0;
   if (d->in0_pix_stride % 8 || (d->in1 && d->in1_pix_stride % 8)) return 0;
   if (d->TH * d->TW > 16) return 0;                     // rows of the source-pixel table
+  if (d->stats_partial && d->g_src) return 0;           // the BatchNorm-sums instance of the epilogue carries no gate
   // epilogue: max(v, slope v); 32-bit byte offsets into the output / halo / gate tensors (buffer descriptors)
   if (!(d->act_slope >= 0.f && d->act_slope <= 1.f)) return 0;
   const long long out_px = (long long)d->B * d->Hout_t * d->Wout_t;

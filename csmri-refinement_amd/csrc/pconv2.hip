@@ -299,10 +299,10 @@ __global__ __launch_bounds__(768, 1) void pconv2_kernel(const GParams p) {
           }
           if (has_q) {
             int q0 = 0, q1 = 0;
-            q0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0] * e_qs, e[1] * e_qs, q0, false);
-            q0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2] * e_qs, e[3] * e_qs, q0, true);
-            q1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4] * e_qs, e[5] * e_qs, q1, false);
-            q1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6] * e_qs, e[7] * e_qs, q1, true);
+            q0 = __builtin_amdgcn_cvt_pk_fp8_f32(sat_e4m3(e[0] * e_qs), sat_e4m3(e[1] * e_qs), q0, false);
+            q0 = __builtin_amdgcn_cvt_pk_fp8_f32(sat_e4m3(e[2] * e_qs), sat_e4m3(e[3] * e_qs), q0, true);
+            q1 = __builtin_amdgcn_cvt_pk_fp8_f32(sat_e4m3(e[4] * e_qs), sat_e4m3(e[5] * e_qs), q1, false);
+            q1 = __builtin_amdgcn_cvt_pk_fp8_f32(sat_e4m3(e[6] * e_qs), sat_e4m3(e[7] * e_qs), q1, true);
             const unsigned qoff = mvv[f] ? opix[f] * (unsigned)p.oqps + (lch_st >> 1) + i * 16 : OOB;
             __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){(unsigned)q0, (unsigned)q1}, rs_q, (int)qoff, 0, 0);
           }

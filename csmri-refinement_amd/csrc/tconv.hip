@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, (CIN <= 32 && FN < 4) ? 4 : 2) void tconv_kern
   for (int i = 0; i < FN; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[i][r] = 0.f; s2[i][r] = 0.f; }
-  unsigned offo[4], offh[4], offg[4]; bool mvv[4];
+  unsigned offo[4], offh[4], offg[4]; bool mvv[4], gated[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const int oy = y0 + 4 * wv + f, ox = x0 + r16;
@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, (CIN <= 32 && FN < 4) ? 4 : 2) void tconv_kern
     offo[f] = (mv && inside) ? opix * (unsigned)(p.ops * es) : OOB;
     offh[f] = (mv && !inside) ? fpix * (unsigned)(p.o2ps * es) : OOB;
     offg[f] = (mv && inside) ? opix * (unsigned)(p.gps * ges) : OOB;
+    gated[f] = inside;            // halo positions leave ungated (csmri_fold_halo gates them where they land)
   }
   f32x4_t gt[4][FN];
   if (has_gate) {
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256, (CIN <= 32 && FN < 4) ? 4 : 2) void tconv_kern
       }
       if (has_gate) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gt[f][i][r] > 0.f ? v[r] : v[r] * p.gslope;
+        for (int r = 0; r < 4; ++r) v[r] = (gt[f][i][r] > 0.f || !gated[f]) ? v[r] : v[r] * p.gslope;
       }
       vv[i] = v;
     }

@@ -100,21 +100,33 @@ def synth_sample(h, w, acc, seed, sample_n=8):
   return _pack(x_u), _pack(k_u), _pack(mask * (1 + 1j)), _pack(img.astype(np.complex128))
 
 
-def synth_batch(b, h, w, acc=4, seed=0, sample_n=8):
-  parts = [synth_sample(h, w, acc, seed + 1000 + i, sample_n) for i in range(b)]
+def synth_batch(b, h, w, acc=4, seed=0, sample_n=8, first=0):
+  """Samples first .. first + b - 1 of the batch seeded ``seed`` (a sample depends on its index only: rank r of a
+  data-parallel job synthesises rows r * b .. of the global batch and nothing else)."""
+  parts = [synth_sample(h, w, acc, seed + 1000 + first + i, sample_n) for i in range(b)]
   return {k: torch.from_numpy(np.stack([p[j] for p in parts]))
           for j, k in enumerate(('inp', 'kspace', 'mask', 'target'))}
 
 
 class SyntheticLoader(object):
   """Minimal DataLoader stand-in: ``len``, ``iter``, ``batch_size``.  Batches are
-  generated once (``distinct`` of them, pinned) and cycled."""
+  generated once (``distinct`` of them, pinned) and cycled.  ``shard = (rank, world)``: ``batch_size`` is the GLOBAL
+  batch and this loader holds only rank's contiguous share of it (``presharded``: the runner's _request_data does not
+  cut it again) -- the same rows dist_utils.shard_batch would cut out of the global batch, without every rank
+  synthesising all of it."""
 
-  def __init__(self, batch_size, h, w, num_batches, acc=4, seed=0, distinct=2, pin=True):
+  def __init__(self, batch_size, h, w, num_batches, acc=4, seed=0, distinct=2, pin=True, shard=None):
     self.batch_size, self.num_batches = batch_size, num_batches
+    self.presharded = shard is not None and shard[1] > 1
+    first, rows = 0, batch_size
+    if self.presharded:
+      r, n = shard
+      assert batch_size % n == 0, 'global batch {} not divisible by {} ranks'.format(batch_size, n)
+      rows = batch_size // n
+      first = r * rows
     self.batches = []
     for i in range(max(1, min(distinct, num_batches))):
-      bt = synth_batch(batch_size, h, w, acc, seed + 100000 * i)
+      bt = synth_batch(rows, h, w, acc, seed + 100000 * i, first=first)
       if pin and torch.cuda.is_available():
         bt = {k: v.pin_memory() for k, v in bt.items()}
       self.batches.append(bt)

@@ -79,7 +79,8 @@ def main(argv=None):
   ws = dist_utils.world_size()
   loader = SyntheticLoader(conf.batch_size * ws, size, size,
                            conf.get_attr('steps_per_epoch', default=20),
-                           acc=conf.undersampling['acceleration_factor'], seed=conf.seed)
+                           acc=conf.undersampling['acceleration_factor'], seed=conf.seed,
+                           shard=(dist_utils.rank(), ws))      # each rank synthesises its own rows only
   for epoch in range(start_epoch, conf.num_epochs + 1):
     runner.epoch_beginning(epoch)
     t0 = time.time()

@@ -114,6 +114,20 @@ def _split_disc_output(out, b):
   return first, second
 
 
+def _epoch_window(spec):
+  """Half-open epoch window [first, end) of a pretraining phase from its config value: a count n means the first n
+  epochs (1-based), a pair is a window as given, None an empty window (semantics pinned by fixture F11 /
+  oracle.pretraining_flags; reference config keys pretrain_generator / pretrain_discriminator)."""
+  if spec is None:
+    return (-1, -1)
+  if isinstance(spec, int):
+    return (1, 1 + spec)
+  first, end = spec
+  if not first < end:
+    raise AssertionError('Starting epoch must be smaller than ending epoch')
+  return (first, end)
+
+
 class AdversarialRunner(BaseRunner):
   def __init__(self, gen_model, disc_model=None, gen_optimizer=None, disc_optimizer=None,
                gen_lr_scheduler=None, disc_lr_scheduler=None, gen_adv_criteria=None,
@@ -173,15 +187,8 @@ class AdversarialRunner(BaseRunner):
     self.generator_enabled = True
     self._host_weights = {}
 
-    def _get_pretraining_schedule(epochs):          # reference adversarial_runner.py:195-209
-      if epochs is None:
-        return (-1, -1)
-      elif isinstance(epochs, int):
-        return (1, epochs + 1)
-      assert epochs[0] < epochs[1], 'Starting epoch must be smaller than ending epoch'
-      return tuple(epochs)
-    self.generator_pretraining_schedule = _get_pretraining_schedule(pretrain_generator_epochs)
-    self.discriminator_pretraining_schedule = _get_pretraining_schedule(pretrain_discriminator_epochs)
+    self.generator_pretraining_schedule = _epoch_window(pretrain_generator_epochs)
+    self.discriminator_pretraining_schedule = _epoch_window(pretrain_discriminator_epochs)
     self.pool_decisions = None            # optional injected image-pool decisions (tests)
     self._graph = None
     self._last_metrics = None
@@ -740,50 +747,50 @@ class AdversarialRunner(BaseRunner):
     self._last_metrics = {name: MaxMetric(VecRef(shared, n + j)) for j, name in enumerate(st['metric_names'])}
     return 1, loss_metrics, (st['batch'], st['out_gen'], st['out_disc_fake'], st['out_disc_real'])
 
-  # -- epoch hooks: LR schedulers and pretraining schedules (reference adversarial_runner.py:267-305) --
+  # -- epoch hooks: learning-rate schedulers and the pretraining windows (behaviour pinned by fixture F11:
+  #    tests/test_hip_path.py::test_f11_*; the reference's hooks are adversarial_runner.py:267-305) --
+  def _learning_rates(self):
+    return [o.param_groups[0]['lr'] for o in (self.gen_optimizer, self.disc_optimizer) if o is not None]
+
+  def _step_schedulers(self, due):
+    for scheduler in (self.gen_lr_scheduler, self.disc_lr_scheduler):
+      if due(scheduler):
+        scheduler.step()
+
+  def _networks_enabled(self, epoch):
+    """(discriminator_enabled, generator_enabled) in ``epoch``: inside the discriminator's pretraining window only the
+    discriminator trains; else inside the generator's only the generator; else both.  (Where the two windows overlap
+    the discriminator's wins: oracle.pretraining_flags, F11.)"""
+    in_window = lambda w: w[0] <= epoch < w[1]
+    if in_window(self.discriminator_pretraining_schedule):
+      return True, False
+    if in_window(self.generator_pretraining_schedule):
+      return False, True
+    return True, True
+
   def epoch_beginning(self, epoch):
-    lrs = [o.param_groups[0]['lr'] for o in (self.gen_optimizer, self.disc_optimizer) if o is not None]
-    if is_pre_epoch_scheduler(self.gen_lr_scheduler):
-      self.gen_lr_scheduler.step()
-    if is_pre_epoch_scheduler(self.disc_lr_scheduler):
-      self.disc_lr_scheduler.step()
-    start, end = self.generator_pretraining_schedule
-    if start <= epoch < end:
-      logging.debug('Pretraining generator, discriminator disabled')
-      self.discriminator_enabled = False
-      self.generator_enabled = True
-    else:
-      self.discriminator_enabled = True
-    if start == epoch:
-      logging.info('Start pretraining generator in epoch {}'.format(epoch))
-    elif end == epoch:
-      logging.info('Stop pretraining generator before epoch {}'.format(epoch))
-    start, end = self.discriminator_pretraining_schedule
-    if start <= epoch < end:
-      logging.debug('Pretraining discriminator, generator disabled')
-      self.discriminator_enabled = True
-      self.generator_enabled = False
-    else:
-      self.generator_enabled = True
-    if start == epoch:
-      logging.info('Start pretraining discriminator in epoch {}'.format(epoch))
-    elif end == epoch:
-      logging.info('Stop pretraining discriminator before epoch {}'.format(epoch))
+    lrs = self._learning_rates()
+    self._step_schedulers(is_pre_epoch_scheduler)
+    self.discriminator_enabled, self.generator_enabled = self._networks_enabled(epoch)
+    for trained, frozen, (first, end) in (('generator', 'discriminator', self.generator_pretraining_schedule),
+                                          ('discriminator', 'generator', self.discriminator_pretraining_schedule)):
+      if epoch == first:
+        logging.info('Epoch %d: %s pretraining begins (%s frozen until epoch %d)', epoch, trained, frozen, end)
+      elif epoch == end:
+        logging.info('Epoch %d: %s pretraining is over', epoch, trained)
+      elif first < epoch < end:
+        logging.debug('Epoch %d: %s pretraining, %s frozen', epoch, trained, frozen)
     self._after_lr_change(lrs)
 
   def epoch_finished(self, epoch):
-    lrs = [o.param_groups[0]['lr'] for o in (self.gen_optimizer, self.disc_optimizer) if o is not None]
-    if is_post_epoch_scheduler(self.gen_lr_scheduler):
-      self.gen_lr_scheduler.step()
-    if is_post_epoch_scheduler(self.disc_lr_scheduler):
-      self.disc_lr_scheduler.step()
+    lrs = self._learning_rates()
+    self._step_schedulers(is_post_epoch_scheduler)
     self._after_lr_change(lrs)
 
   def _after_lr_change(self, old_lrs):
     """The learning rate is a launch argument of the fused Adam kernel, i.e. baked into a captured
     hipGraph: capture again (same static buffers' shapes) when a scheduler moved it."""
-    new = [o.param_groups[0]['lr'] for o in (self.gen_optimizer, self.disc_optimizer) if o is not None]
-    if new != old_lrs and getattr(self, '_graph', None) is not None:
+    if self._learning_rates() != old_lrs and getattr(self, '_graph', None) is not None:
       example = {k: v.clone() for k, v in self._graph['static'].items()}
       # drop the old graphs (incl. the look-ahead graph) and their pool BEFORE the new capture
       self.disable_graphs()
@@ -792,9 +799,11 @@ class AdversarialRunner(BaseRunner):
       torch.cuda.empty_cache()
       self.enable_graphs(example, warmup=0)
 
-  # -- the reference's control flow, literally: used whenever a network is disabled by a pretraining
-  #    schedule or several updates per step are configured (the fused 4-segment step above is the
-  #    both-enabled, one-update-each case) ---------------------------------------------------------------
+  # -- steps outside the fused one-update-each case: a network disabled by a pretraining window, or several updates
+  #    per step.  Semantics pinned by fixture F11 against oracle.gan_train_step / oracle.gan_train_multi_step
+  #    (tests/test_hip_path.py::test_f11_*); the reference's versions are adversarial_runner.py:322-525.  Built from
+  #    three pieces: a PHASE evaluates one network's named losses on a generator output, `_apply_phase` turns a phase
+  #    into an optimizer update and records its values, and a step is a short schedule of phases. ------------------
   def _disc_forward_pair(self, out_gen, gen_inp0, target):
     out_fake = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp0, out_gen, is_real_input=False, detach=True,
                                                  pool_decisions=self.pool_decisions))
@@ -807,111 +816,88 @@ class AdversarialRunner(BaseRunner):
         'losses are weighted but not computed while the discriminator is disabled)' % (len(losses), weights.numel())
     return self._update_step(optimizer, losses, weights)
 
+  @staticmethod
+  def _evaluate(prefix, criteria, *operands):
+    return [(prefix + name, criterion(*operands)) for name, criterion in criteria.items()]
+
+  def _disc_phase(self, batch, gen_inp0, out_gen):
+    """D(pool(fake).detach()), D(real) -> the discriminator's named losses."""
+    fake, real = self._disc_forward_pair(out_gen, gen_inp0, batch['target'])
+    return self._evaluate('disc_loss_', self.disc_adv_criteria, fake, real), fake, real
+
+  def _gen_phase(self, batch, gen_inp0, out_gen, real=None, fresh_real=False):
+    """The generator's named losses: adversarial ones through D(fake) with gradient (only while the discriminator
+    takes part; ``real`` = a D(real) output to match features against, recomputed when ``fresh_real``), then the
+    ordinary criteria on (out_gen, batch)."""
+    named, fake = [], None
+    if self.discriminator_enabled:
+      fake = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp0, out_gen, is_real_input=False, detach=False))
+      if fresh_real:
+        real = self.disc(nhwc=self.disc_input_fn(batch['target'], gen_inp0, out_gen, is_real_input=True, detach=True))
+      named += self._evaluate('gen_loss_', self.gen_adv_criteria, fake, real)
+    else:
+      real = None
+    return named + self._evaluate('gen_loss_', self.gen_criteria, out_gen, batch), fake, real
+
+  def _apply_phase(self, who, named, record):
+    optimizer, weights = ((self.disc_optimizer, self.disc_loss_weights) if who == 'disc' else
+                          (self.gen_optimizer, self.gen_loss_weights))
+    for name, loss in named:
+      record(name, get_loss_metric(loss.detach()))
+    record(who + '_loss', get_loss_metric(self._general_update(optimizer, [loss for _, loss in named], weights)))
+
   def _train_single_step_general(self, loader):
-    """reference adversarial_runner.py:322-389 with its enabled flags."""
+    """One batch, ONE generator forward shared by both phases; every loss is evaluated before either network moves,
+    then the discriminator is updated, then the generator (its backward runs through the updated discriminator:
+    ordering A, SURVEY A-4).  The D(real) pass of the discriminator phase also serves feature matching."""
     batch = self._request_data(loader)
     if batch is None:
       return 0, None, None
-    loss_metrics = {}
     gen_inp = self.train_model_input_fn(batch)
     out_gen = self.gen(*gen_inp)
-    out_disc_fake = out_disc_real = None
+    phases, fake, real = [], None, None
     if self.discriminator_enabled:
-      out_disc_fake, out_disc_real = self._disc_forward_pair(out_gen, gen_inp[0], batch['target'])
-      disc_losses = []
-      for name, criterion in self.disc_adv_criteria.items():
-        loss = criterion(out_disc_fake, out_disc_real)
-        disc_losses.append(loss)
-        loss_metrics['disc_loss_' + name] = get_loss_metric(loss.detach())
+      named, fake, real = self._disc_phase(batch, gen_inp[0], out_gen)
+      phases.append(('disc', named))
     if self.generator_enabled:
-      gen_losses = []
-      if self.discriminator_enabled:
-        out_disc_fake = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False,
-                                                          detach=False))
-        for name, criterion in self.gen_adv_criteria.items():
-          loss = criterion(out_disc_fake, out_disc_real)
-          gen_losses.append(loss)
-          loss_metrics['gen_loss_' + name] = get_loss_metric(loss.detach())
-      for name, criterion in self.gen_criteria.items():
-        loss = criterion(out_gen, batch)
-        gen_losses.append(loss)
-        loss_metrics['gen_loss_' + name] = get_loss_metric(loss.detach())
-    if self.discriminator_enabled:
-      total = self._general_update(self.disc_optimizer, disc_losses, self.disc_loss_weights)
-      loss_metrics['disc_loss'] = get_loss_metric(total)
-    if self.generator_enabled:
-      total = self._general_update(self.gen_optimizer, gen_losses, self.gen_loss_weights)
-      loss_metrics['gen_loss'] = get_loss_metric(total)
+      named, fake_g, real = self._gen_phase(batch, gen_inp[0], out_gen, real=real)
+      fake = fake_g if fake_g is not None else fake
+      phases.append(('gen', named))
+    loss_metrics = {}
+    for who, named in phases:
+      self._apply_phase(who, named, loss_metrics.__setitem__)
     if not self.discriminator_enabled:
-      out_disc_fake = out_disc_real = None
-    return 1, loss_metrics, (batch, out_gen, out_disc_fake, out_disc_real)
+      fake = real = None
+    return 1, loss_metrics, (batch, out_gen, fake, real)
 
   def _train_multiple_steps(self, loader):
-    """Several discriminator / generator updates per step (reference adversarial_runner.py:391-525):
-    max(updates) batches are drawn up front; the discriminator trains on the first
-    disc_updates_per_step of them, then the generator on the first gen_updates_per_step (fresh
-    forward passes through the already updated discriminator; the real pass is repeated only for
-    the feature-matching loss).  Loss metrics are averaged over the updates; the returned data is
-    that of the last update."""
+    """disc_updates_per_step / gen_updates_per_step > 1: as many batches as the larger count are drawn first; the
+    discriminator trains on the leading disc_updates_per_step of them, THEN the generator on the leading
+    gen_updates_per_step -- every update with forward passes of its own (the generator's through the discriminator
+    as updated so far; D(real) is run again only when feature matching needs it).  Returns the batches consumed, the
+    per-name mean of the recorded values, and the tensors of the last update."""
+    from itertools import islice
     from metrics import accumulate_metric
-    last_batch = None
-    max_updates = max(self.disc_updates_per_step, self.gen_updates_per_step)
-    batches = []
-    for _ in range(max_updates):
-      batch = self._request_data(loader)
-      if batch is None:
-        break
-      batches.append(batch)
-    gen_uses_feature_matching = 'FeatureMatching' in self.gen_adv_criteria
-    loss_metrics = {}
-    out_gen = out_disc_fake = out_disc_real = None
-    for idx, batch in enumerate(batches[:self.disc_updates_per_step]):
-      if not self.discriminator_enabled:
-        continue
-      last_batch = batch
+    wanted = max(self.disc_updates_per_step, self.gen_updates_per_step)
+    batches = list(islice(iter(lambda: self._request_data(loader), None), wanted))
+    if not batches:
+      return 0, None, None
+    schedule = [('disc', b) for b in batches[:self.disc_updates_per_step] if self.discriminator_enabled] + \
+               [('gen', b) for b in batches[:self.gen_updates_per_step] if self.generator_enabled]
+    matches_features = 'FeatureMatching' in self.gen_adv_criteria
+    totals, last = {}, (None, None, None, None)
+    for who, batch in schedule:
       gen_inp = self.train_model_input_fn(batch)
       out_gen = self.gen(*gen_inp)
-      out_disc_fake, out_disc_real = self._disc_forward_pair(out_gen, gen_inp[0], batch['target'])
-      disc_losses = []
-      for name, criterion in self.disc_adv_criteria.items():
-        loss = criterion(out_disc_fake, out_disc_real)
-        disc_losses.append(loss)
-        accumulate_metric(loss_metrics, 'disc_loss_' + name, get_loss_metric(loss.detach()))
-      total = self._general_update(self.disc_optimizer, disc_losses, self.disc_loss_weights)
-      accumulate_metric(loss_metrics, 'disc_loss', get_loss_metric(total))
-    for idx, batch in enumerate(batches[:self.gen_updates_per_step]):
-      if not self.generator_enabled:
-        continue
-      last_batch = batch
-      gen_losses = []
-      gen_inp = self.train_model_input_fn(batch)
-      out_gen = self.gen(*gen_inp)
-      if self.discriminator_enabled:
-        out_disc_fake = self.disc(nhwc=self.disc_input_fn(out_gen, gen_inp[0], out_gen, is_real_input=False,
-                                                          detach=False))
-        if gen_uses_feature_matching:
-          out_disc_real = self.disc(nhwc=self.disc_input_fn(batch['target'], gen_inp[0], out_gen,
-                                                            is_real_input=True, detach=True))
-        else:
-          out_disc_real = None
-        for name, criterion in self.gen_adv_criteria.items():
-          loss = criterion(out_disc_fake, out_disc_real)
-          gen_losses.append(loss)
-          accumulate_metric(loss_metrics, 'gen_loss_' + name, get_loss_metric(loss.detach()))
-      for name, criterion in self.gen_criteria.items():
-        loss = criterion(out_gen, batch)
-        gen_losses.append(loss)
-        accumulate_metric(loss_metrics, 'gen_loss_' + name, get_loss_metric(loss.detach()))
-      total = self._general_update(self.gen_optimizer, gen_losses, self.gen_loss_weights)
-      accumulate_metric(loss_metrics, 'gen_loss', get_loss_metric(total))
-    if len(batches) > 0:
-      avg = {name: m.average() for name, m in loss_metrics.items()}
-      if not self.discriminator_enabled:
-        out_disc_fake = out_disc_real = None
-      data = (last_batch, out_gen, out_disc_fake, out_disc_real)
-    else:
-      avg, data = None, None
-    return len(batches), avg, data
+      if who == 'disc':
+        named, fake, real = self._disc_phase(batch, gen_inp[0], out_gen)
+      else:
+        named, fake, real = self._gen_phase(batch, gen_inp[0], out_gen, fresh_real=matches_features)
+      self._apply_phase(who, named, lambda name, m: accumulate_metric(totals, name, m))
+      last = (batch, out_gen, fake, real)
+    if not self.discriminator_enabled:
+      last = last[:2] + (None, None)
+    return len(batches), {name: m.average() for name, m in totals.items()}, last
 
   def _val_step(self, loader, compute_metrics=True):
     batch = self._request_data(loader, volatile=True)

@@ -38,7 +38,8 @@ class BaseRunner(object):
     except StopIteration:
       self.data_iter = None
       return None
-    batch = dist_utils.shard_batch(batch)
+    if not getattr(loader, 'presharded', False):      # (a loader that holds only this rank's rows says so)
+      batch = dist_utils.shard_batch(batch)
     return {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
 
   def _get_model_input_fn(self, model, batch_transform=None):
@@ -51,69 +52,74 @@ class BaseRunner(object):
 
     return input_fn
 
-  def train_epoch(self, loader, epoch, summary_writer=None, steps_per_train_summary=1,
-                  verbose=False):
+  # -- the epoch passes ----------------------------------------------------------------------------------
+  # One pass = a loop of steps over the loader with two name -> Metric tables (losses, metrics) that absorb each
+  # step's values (metrics.accumulate_metric: device-side sums, one readback per report).  Contract of the reference
+  # (training/base_runner.py:65-147): train_epoch -> (losses, metrics) averaged over the epoch, a step may consume
+  # several batches (_train_step returns how many), a progress line every `steps_per_train_summary` batches and the
+  # same scalars to the summary writer under 'train/<name>'; validate -> (first n batches on the host, losses,
+  # metrics) under no_grad in eval mode; infer -> every batch on the host.
+
+  @staticmethod
+  def _absorb(table, named):
+    for name, m in named.items():
+      accumulate_metric(table, name, m)
+
+  @staticmethod
+  def _averaged(table):
+    return {name: m.average() for name, m in table.items()}
+
+  def _report(self, epoch, seen, total, losses, metrics, writer, verbose):
+    head = '===> Epoch[{}]({}/{}): '.format(epoch, seen, total)
+    logging.info(head + ', '.join('{}: {}'.format(*kv) for kv in losses.items()) +
+                 ''.join('\n     {}: {}'.format(*kv) for kv in (metrics.items() if verbose else ())))
+    if writer is not None:
+      at = total * (epoch - 1) + seen
+      for name, m in chain(losses.items(), metrics.items()):
+        writer.add_scalar('train/{}'.format(name), m.value, at)
+
+  def train_epoch(self, loader, epoch, summary_writer=None, steps_per_train_summary=1, verbose=False):
     self.epoch = epoch
-    n_batches = len(loader)
-    epoch_losses, epoch_metrics = {}, {}
     self._set_train()
     self.data_iter = iter(loader)
-    current = 0
-    while current < n_batches:
-      num, loss_metrics, data = self._train_step(loader)
-      if num == 0:
-        break
-      current += num
-      metrics = self._compute_train_metrics(data)
-      del data
-      for name, m in loss_metrics.items():
-        accumulate_metric(epoch_losses, name, m)
-      for name, m in metrics.items():
-        accumulate_metric(epoch_metrics, name, m)
-      if current % steps_per_train_summary == 0:
-        s = '===> Epoch[{}]({}/{}): '.format(epoch, current, n_batches)
-        s += ', '.join('{}: {}'.format(k, v) for k, v in loss_metrics.items())
-        if verbose:
-          s += '\n' + '\n'.join('     {}: {}'.format(k, v) for k, v in metrics.items())
-        logging.info(s)
-        if summary_writer is not None:
-          step = n_batches * (epoch - 1) + current
-          for name, m in chain(loss_metrics.items(), metrics.items()):
-            summary_writer.add_scalar('train/{}'.format(name), m.value, step)
-    return ({k: v.average() for k, v in epoch_losses.items()},
-            {k: v.average() for k, v in epoch_metrics.items()})
+    total, seen = len(loader), 0
+    sums = ({}, {})
+    while seen < total:
+      took, step_losses, data = self._train_step(loader)
+      if not took:
+        break                       # the loader ran dry inside the step
+      seen += took
+      step_metrics = self._compute_train_metrics(data)
+      data = None
+      self._absorb(sums[0], step_losses)
+      self._absorb(sums[1], step_metrics)
+      if seen % steps_per_train_summary == 0:
+        self._report(epoch, seen, total, step_losses, step_metrics, summary_writer, verbose)
+    return self._averaged(sums[0]), self._averaged(sums[1])
+
+  def _eval_batches(self, loader, compute_metrics):
+    """(loss_metrics, data) of every validation batch in eval mode (the caller holds torch.no_grad())."""
+    self._set_test()
+    self.data_iter = iter(loader)
+    for _ in range(len(loader)):
+      step_losses, data = self._val_step(loader, compute_metrics=compute_metrics)
+      if data is None:
+        return
+      yield step_losses, data
 
   def validate(self, loader, num_batches_to_return=0):
-    epoch_data, epoch_losses, epoch_metrics = [], {}, {}
-    self._set_test()
-    self.data_iter = iter(loader)
+    kept, sums = [], ({}, {})
     with torch.no_grad():
-      for _ in range(len(loader)):
-        loss_metrics, data = self._val_step(loader)
-        if data is None:
-          break
-        if len(epoch_data) < num_batches_to_return:
-          epoch_data.append(utils.cpuify(_strip_internal(data)))
-        metrics = self._compute_test_metrics(data)
-        del data
-        for name, m in loss_metrics.items():
-          accumulate_metric(epoch_losses, name, m)
-        for name, m in metrics.items():
-          accumulate_metric(epoch_metrics, name, m)
-    return (epoch_data, {k: v.average() for k, v in epoch_losses.items()},
-            {k: v.average() for k, v in epoch_metrics.items()})
+      for step_losses, data in self._eval_batches(loader, True):
+        if len(kept) < num_batches_to_return:
+          kept.append(utils.cpuify(_strip_internal(data)))
+        self._absorb(sums[0], step_losses)
+        self._absorb(sums[1], self._compute_test_metrics(data))
+    return kept, self._averaged(sums[0]), self._averaged(sums[1])
 
   def infer(self, loader):
-    epoch_data = []
-    self._set_test()
-    self.data_iter = iter(loader)
     with torch.no_grad():
-      for _ in range(len(loader)):
-        _, data = self._val_step(loader, compute_metrics=False)
-        if data is None:
-          break
-        epoch_data.append(utils.cpuify(_strip_internal(data)))
-    return epoch_data
+      return [utils.cpuify(_strip_internal(data)) for _, data in self._eval_batches(loader, False)]
 
   # -- subclass hooks ----------------------------------------------------------
   def get_named_outputs(self, data):

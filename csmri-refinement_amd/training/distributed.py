@@ -95,6 +95,8 @@ class GradBucket(object):
   When nothing has been started early (graph mode: the collectives sit between the captured segments), start()
   exchanges the whole buffer as ONE range: 2 collectives + 3 launches per model and step."""
 
+  TIMING = None          # bench.py: a list that collects (event, event) pairs around every wait() (exposed communication)
+
   def __init__(self, flat_grad, splits=None, payload=None):
     self.flat = flat_grad
     n = flat_grad.numel()
@@ -203,8 +205,18 @@ class GradBucket(object):
     must be scaled by (1/world)."""
     if exchange_active():
       self.start()                                        # anything nobody started early
+      timing = GradBucket.TIMING
+      timed = timing is not None and self.flat.is_cuda and not torch.cuda.is_current_stream_capturing()
+      if timed:
+        # EXPOSED communication: how long the consumer's stream stands at this wait (0 when the exchange ended under
+        # the compute issued before it); bench.py sums these event pairs over the timed steps
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
       for ev in self._done:
         torch.cuda.current_stream().wait_event(ev)
+      if timed:
+        e1.record()
+        timing.append((e0, e1))
       self._done = []
       self._started = [False] * len(self.splits)
     return 1.0 / world_size()

@@ -49,8 +49,13 @@ def test_bench_json_line_schema_with_other_configs():
   d = _one_line(out)
   _check_headline(d, 3, 2)
   others = d['other_configs']
-  assert len(others) == 3 and not any('error' in o for o in others[:2]), others
-  c2, c5, c5f8 = others
+  assert len(others) == 4 and not any('error' in o for o in others[:3]), others
+  c3f32, c2, c5, c5f8 = others
+  # the headline workload in the reference's arithmetic (fp32), driver-timed beside the bf16 line; its roofline is
+  # priced against the fp32-matrix peak
+  assert c3f32['dtype'] == 'fp32' and 'C3' in c3f32['config']['workload'] and c3f32['value'] > 0
+  assert c3f32['roofline']['peak'] == 157.3 and 0.0 < c3f32['roofline']['frac'] < 1.0
+  assert c3f32['value'] < d['value'] and c3f32['psnr_delta_db'] <= 0.01, c3f32
   assert 'C2' in c2['config']['workload'] and 'C5' in c5['config']['workload']
   # BASELINE config 5's fp8 variant right behind its bf16 leg (a child process of bench.py): frozen VGG stack on e4m3fn
   # operands + bf16-storage FFT
@@ -81,6 +86,7 @@ def test_bench_under_torch_distributed_run_single_rank():
   d = _one_line(out)
   _check_headline(d, 3, 2)
   assert d['config']['parallelism'] == 'dp1' and 'one graph per step' in d['launch_mode']
+  assert d['collective_ranks'] == 1 and d['distinct_gpus'] == 1 and d['exposed_comm_ms_per_step'] is None
 
 
 def _two_rank_bench(extra):
@@ -106,6 +112,40 @@ def test_bench_under_torch_distributed_run_two_ranks():
   # whole-job aggregate: both ranks' slices over the max-over-ranks time
   assert abs(d['value'] - 16 / (d['ms_per_step'] * 1e-3)) < 0.02 * d['value']
   assert d['warmup_total_steps'] == d['warmup'] + d['settle_steps']
+  _check_two_rank_fields(d)
+
+
+def _check_two_rank_fields(d):
+  # who took part, proven by a collective over the job's process group: two ranks answered; the functional-test mode
+  # (both ranks on the box's one GPU, gloo) is visible as such -- backend gloo, 0 RCCL ranks, ONE distinct GPU
+  assert d['n_gpus'] == d['collective_ranks'] == 2, d
+  assert d['backend'] == 'gloo' and d['rccl_ranks'] == 0 and d['distinct_gpus'] == 1
+  assert d['grad_payload'] in ('bf16', 'fp32') and d['exposed_comm_ms_per_step'] >= 0.0
+
+
+def test_bare_gpus_2_spawns_two_ranks():
+  """`python bench.py --gpus 2` WITHOUT torch.distributed.run starts its own two ranks (before it imports torch) and the
+  line says so; it can no longer run one rank and report n_gpus = 1 under a --gpus 2 command line."""
+  env = dict(os.environ, CSMRI_DIST_BACKEND='gloo', MASTER_PORT=str(29700 + os.getpid() % 100))
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+                        '--no-cpu-baseline', '--no-other-configs', '--no-roofline', '--settle-s', '0.2'],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+  d = _one_line(out)
+  _check_two_rank_fields(d)
+  assert d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 16
+
+
+def test_world_size_mismatch_is_refused():
+  """--gpus 2 inside a ONE-rank torch.distributed.run job: no line, non-zero exit (round 5 accepted it and reported one GPU)."""
+  port = 29800 + os.getpid() % 100
+  out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+  assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert 'refusing' in out.stderr
 
 
 def test_bench_c2_under_torch_distributed_run_two_ranks():

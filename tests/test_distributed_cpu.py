@@ -78,3 +78,25 @@ def test_single_process_is_world_one():
   bucket = D.GradBucket(torch.ones(4))
   bucket.start()
   assert bucket.wait() == 1.0
+
+
+def test_presharded_synthetic_loader_holds_exactly_the_ranks_rows():
+  """train.py gives every rank a loader that synthesises ONLY its contiguous share of the global batch
+  (SyntheticLoader(shard=(rank, world))): the rows are bit for bit the ones shard_batch would cut out of the global
+  batch (reference base_runner.py:29-41 hands the whole batch to DataParallel, which scatters it the same way), and
+  the runner does not cut a presharded batch again."""
+  sys.path.insert(0, PKG)
+  from data.synthetic import SyntheticLoader
+  from training import distributed as D
+  whole = SyntheticLoader(4, 32, 32, 3, acc=4, seed=5, distinct=2, pin=False)
+  assert not whole.presharded
+  for r in range(2):
+    mine = SyntheticLoader(4, 32, 32, 3, acc=4, seed=5, distinct=2, pin=False, shard=(r, 2))
+    assert mine.presharded and mine.batch_size == 4 and len(mine) == 3
+    for bw, bm in zip(whole, mine):
+      want = D.shard_batch(bw, r, 2)
+      assert set(bm) == set(want)
+      for k in want:
+        assert bm[k].shape[0] == 2 and torch.equal(bm[k], want[k]), (r, k)
+  one = SyntheticLoader(4, 32, 32, 1, pin=False, shard=(0, 1))
+  assert not one.presharded and next(iter(one))['inp'].shape[0] == 4

@@ -323,6 +323,45 @@ def test_fp8_patch_conv_vs_oracle_and_copy_is_quantize_of_output(hip):
 
 
 @pytest.mark.gpu
+def test_fp8_copies_saturate_when_activations_outgrow_the_delayed_scale(hip):
+  """Delayed scaling takes step t's scale from step t - 1's maximum with one bit of headroom, so max * scale lies in
+  [64, 128): a tensor that grows 8x between two forwards (train -> validation switch, a differently scaled slice) lands
+  at 512 ... 1024, outside e4m3fn (448).  The producing epilogues (patch-conv copy, max-pool copy) clamp before
+  v_cvt_pk_fp8_f32: the copy is the SATURATED rounding of y * scale (no NaN byte 0x7f / 0xff), the consuming fp8 layer's
+  output is finite, and the maximum collected in this pass repairs the next pass's scale."""
+  ops = hip.ops
+  g = torch.Generator().manual_seed(77)
+  la, wa, ba = _frozen_layer(ops, 128, 128, g)
+  lb, wb, bb = _frozen_layer(ops, 128, 128, g)
+  x = torch.relu(torch.randn(2, 128, 32, 32, generator=g)).bfloat16().float()
+  plan = [('conv', la, 0.0), ('pool', None, None), ('conv', lb, 0.0)]
+  chain = ops.Fp8Chain([('conv', la, 0.0), ('conv', lb, 0.0)], torch.device('cuda'))
+  xd = to_dev_nhwc(x)
+  ops.frozen_conv_forward(la, xd, 0.0, None, 0, 0, chain)          # pass 1: bf16, collects the maximum
+  chain.finish()
+  torch.cuda.synchronize()
+  s = float(chain.scales[0, 0].cpu())
+  xd8 = to_dev_nhwc(x * 8.0)                                       # pass 2: 8x larger activations, last pass's scale
+  ya, yq = ops.frozen_conv_forward(la, xd8, 0.0, None, 0, 0, chain)
+  yb, _ = ops.frozen_conv_forward(lb, ya, 0.0, yq, chain.dq_scale_ptr(0), None, chain)
+  # the max-pool's copy with the same stale scale
+  yp, _, ypq = ops.maxpool2_fwd(ya, chain.q_scale_ptr(0), chain.amax_ptr(0), want_q=True)
+  torch.cuda.synchronize()
+  ya_host = from_dev_nhwc(ya, 128)
+  assert float(ya_host.max()) * s > 448.0, 'the case must overflow the stale scale'
+  for name, q, src in (('conv copy', yq, ya_host), ('pool copy', ypq, F.max_pool2d(ya_host, 2, 2))):
+    bits = q.cpu().permute(0, 3, 1, 2)
+    assert int(((bits & 0x7f) == 0x7f).sum()) == 0, name + ': NaN bytes in the fp8 copy'
+    want = L.e4m3_bits(L.e4m3_round(torch.clamp(src * s, -448.0, 448.0)))
+    assert torch.equal(bits, want), name
+    assert int((bits == 0x7e).sum()) > 0, name + ': nothing saturated (0x7e = 448)'
+  assert bool(torch.isfinite(yb.float()).all())
+  chain.finish()
+  torch.cuda.synchronize()
+  assert float(chain.scales[0, 0].cpu()) <= s / 4.0                # the next pass's scale follows the new maximum
+
+
+@pytest.mark.gpu
 def test_maxpool_fp8_copy_is_quantize_of_output(hip):
   ops = hip.ops
   g = torch.Generator().manual_seed(8)

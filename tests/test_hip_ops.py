@@ -131,6 +131,49 @@ def test_conv_fwd_bwd(hip, case, dtype):
   check(name + ' bgrad', layer.bias.grad.cpu(), br.grad, dtype)
 
 
+@pytest.mark.parametrize('g_slope', [0.0, 0.2], ids=['relu', 'leaky'])
+@pytest.mark.parametrize('case', [('refl_k3_c32', 32, 32, 3, 40, 36, 2), ('refl_k4_c128', 128, 128, 4, 16, 16, 4),
+                                  ('refl_k4_c64_big', 64, 64, 4, 64, 64, 2)], ids=lambda c: c[0])
+def test_reflection_dgrad_gated_window_vs_oracle(hip, case, g_slope):
+  """Data gradient of a reflection-padded stride-1 layer WITH the producer's activation derivative fused
+  (conv_dgrad(g_src=, g_slope=): models/recnet.py:40-48 with padding='reflection', models/unet.py:48): the kernel
+  writes the un-padded centre gated and the halo positions UNGATED (include/csmri_hip.h, out_halo); csmri_fold_halo
+  mirrors the halo back and gates it where it lands.  A halo lane that was gated twice loses the mirrored
+  contribution (ReLU) or scales it by the slope (leaky): round-5 advisor finding.  Checked against CPU autograd and
+  against the FOLD_WINDOW = False path (full padded gradient + fold kernel)."""
+  ops = hip.ops
+  name, cin, cout, k, h, w, b = case
+  dtype = torch.bfloat16
+  layer, wt, bias, x, pads, mode = make_layer(hip, (name, cin, cout, k, 1, 'reflection', False, h, w, b), dtype)
+  gen = torch.Generator().manual_seed(11)
+  gy = torch.randn(b, cout, h, w, generator=gen).bfloat16().float()
+  gs = torch.randn(b, cin, h, w, generator=gen).bfloat16().float()
+  xr = x.clone().requires_grad_(True)
+  F.conv2d(O.pad2d(xr, pads, mode), wt, None).backward(gy)
+  ref = xr.grad * torch.where(gs > 0, torch.ones_like(gs), torch.full_like(gs, g_slope))
+  gyd, gsd = to_dev_nhwc(gy, dtype), to_dev_nhwc(gs, dtype)
+  log = ops.LAUNCH_LOG = []
+  try:
+    got = ops.conv_dgrad(layer, gyd, (h, w), g_src=gsd, g_slope=g_slope)
+  finally:
+    ops.LAUNCH_LOG = None
+  old = ops.FOLD_WINDOW
+  ops.FOLD_WINDOW = False
+  try:
+    plain = ops.conv_dgrad(layer, gyd, (h, w), g_src=gsd, g_slope=g_slope)
+  finally:
+    ops.FOLD_WINDOW = old
+  torch.cuda.synchronize()
+  print(name, [e[1] for e in log])
+  check(name + ' gated window dgrad', from_dev_nhwc(got, cin), ref, dtype)
+  check(name + ' gated full-pad dgrad', from_dev_nhwc(plain, cin), ref, dtype)
+  # the border rows / columns are where the halo lands: they alone must agree as well
+  gb, rb = from_dev_nhwc(got, cin), ref
+  for sl in ((slice(None), slice(None), slice(0, 2)), (slice(None), slice(None), slice(h - 3, h)),
+             (slice(None), slice(None), slice(None), slice(0, 2)), (slice(None), slice(None), slice(None), slice(w - 3, w))):
+    assert rel_l2(gb[sl], rb[sl]) < 1e-2, (name, sl)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 def test_conv_two_source_concat(hip, dtype):
   ops = hip.ops

@@ -800,6 +800,101 @@ def test_f6_vgg_loss_and_input_gradient_vs_reference_golden(env, dtype):
   assert err < max(1.5 * err_f, 3e-2), (err, err_f)
 
 
+def _torchvision_keyed_vgg19(seed, bias_std=0.05):
+  """A state_dict with torchvision's vgg19 key space (features.{i}.weight / .bias for the 16 convs + classifier
+  entries the loader must ignore) filled from a seeded generator, and the same tensors under the oracle's /
+  reference module's keys blocks.{b}.{i}.* (models/vgg.py:36-44)."""
+  gen = torch.Generator().manual_seed(seed)
+  PV = O.init_vgg(gen=gen)
+  for k in list(PV):
+    if k.endswith('.bias'):
+      PV[k] = torch.randn(PV[k].shape, generator=gen) * bias_std      # non-zero: the bias path must matter
+  tv = {'features.%s.%s' % tuple(k.split('.')[2:]): v.clone() for k, v in PV.items()}
+  tv['classifier.0.weight'] = torch.zeros(8, 8)
+  tv['classifier.0.bias'] = torch.zeros(8)
+  return tv, PV
+
+
+def test_pretrained_vgg19_weights_route_vs_oracle(env, tmp_path):
+  """The ONLY route to the reference's real perceptual loss (`models.vgg19(pretrained=True)`, reference
+  models/vgg.py:35, models/vgg_loss.py:44-65) is config key vgg_loss.weights_path -> VGG19.load_pretrained.  A
+  torchvision-keyed state_dict of seeded tensors (seed differs from the module's own init, biases non-zero) is
+  written to disk and loaded through the criterion factory; with the same tensors the oracle gives
+  (a) relu5_4 through VGG19.forward -- the reference API incl. its ImageNet mean/std normalisation (models/vgg.py:58-80),
+  (b) the perceptual loss and dL/dpred through the fused complex-magnitude route (fp32: 1e-4 relative each),
+  (c) the same through a checkpoint with this module's own keys; files with a missing / mis-shaped conv are refused."""
+  Configuration, set_dtype = env
+  from models.criteria import get_criterion
+  set_dtype('fp32')
+  tv, PV = _torchvision_keyed_vgg19(seed=4242)
+  path = str(tmp_path / 'vgg19_tv.pth')
+  torch.save(tv, path)
+  conf = gan_conf(Configuration, 'fp32')
+  conf.vgg_loss = {'seed': 19, 'weights_path': path, 'allow_random': False}
+  import warnings
+  with warnings.catch_warnings():
+    warnings.simplefilter('error')              # with a weights file the "seeded random weights" warning must not fire
+    crit = get_criterion(conf, 'VGG19', '0', target_key='target')
+  vgg = crit.criterion.vgg.cuda()
+  # the loaded tensors are the file's, not the seed-19 init
+  sd = vgg.state_dict()
+  for k, v in PV.items():
+    assert torch.equal(sd[k].cpu(), v), k
+  # (a) reference API: [B,3,H,W] in (0,1) -> relu5_4, mean/std inside forward
+  g = torch.Generator().manual_seed(7)
+  img = torch.rand(2, 3, 128, 128, generator=g)
+  with torch.no_grad():
+    feat = vgg(img.cuda())[0].float().cpu()
+  want = O.vgg_features(PV, img)
+  cos, err = _cos_err(feat, want)
+  print('pretrained route relu5_4: rel_l2 %.3e cos %.6f' % (err, cos))
+  assert feat.shape == want.shape and err < 1e-4
+  # (b) the loss as the step computes it
+  batch = O.synth_batch(2, 128, 128, acc=4, seed=77)
+  pred_h = (batch['target'] + 0.05 * torch.randn(batch['target'].shape, generator=g)).requires_grad_(True)
+  lw = O.vgg_loss(PV, pred_h, batch['target'])
+  lw.backward()
+  pred = pred_h.detach().clone().cuda().requires_grad_(True)
+  loss = crit({'pred': pred}, {'target': batch['target'].cuda()})
+  loss.backward()
+  torch.cuda.synchronize()
+  cos, err = _cos_err(pred.grad.cpu(), pred_h.grad)
+  print('pretrained route loss hip %.8e oracle %.8e   grad rel_l2 %.3e cos %.6f' % (float(loss), float(lw), err, cos))
+  assert abs(float(loss) - float(lw)) < 1e-4 * abs(float(lw)) and err < 1e-4
+  # the seeded-init module gives a DIFFERENT loss (the test would pass vacuously if loading were a no-op)
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    conf.vgg_loss = {'seed': 19}
+    other = get_criterion(conf, 'VGG19', '0', target_key='target')
+    other.criterion.vgg.cuda()
+  with torch.no_grad():
+    lo = float(other({'pred': pred.detach()}, {'target': batch['target'].cuda()}))
+  assert abs(lo - float(lw)) > 1e-2 * abs(float(lw))
+  # (c) this module's own key space, wrapped in {'state_dict': ...}
+  own = str(tmp_path / 'vgg19_own.pth')
+  torch.save({'state_dict': dict(PV)}, own)
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    other.criterion.vgg.load_pretrained(own)
+  with torch.no_grad():
+    l2 = float(other({'pred': pred.detach()}, {'target': batch['target'].cuda()}))
+  assert abs(l2 - float(lw)) < 1e-4 * abs(float(lw))
+  # refusals
+  bad = dict(tv)
+  del bad['features.34.bias']
+  torch.save(bad, str(tmp_path / 'missing.pth'))
+  with pytest.raises(KeyError):
+    vgg.load_pretrained(str(tmp_path / 'missing.pth'))
+  bad = dict(tv)
+  bad['features.0.weight'] = torch.zeros(64, 1, 3, 3)
+  torch.save(bad, str(tmp_path / 'shape.pth'))
+  with pytest.raises(ValueError):
+    vgg.load_pretrained(str(tmp_path / 'shape.pth'))
+  conf.vgg_loss = {'allow_random': False}
+  with pytest.raises(RuntimeError):
+    get_criterion(conf, 'VGG19', '0', target_key='target')
+
+
 def test_f4_refinement_wrapper_fwd_bwd_fp32_vs_reference_golden(env):
   """F4 (the reference's RefinementWrapper, models/refinement_wrapper.py:169-220, reduced-width U-Net,
   128^2, scale = 0.37): the four outputs (2e-5), the BatchNorm running statistics after the forward,
