@@ -206,6 +206,7 @@ _SIGS = {
     'csmri_ssim': (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     'csmri_adam': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
     'csmri_adam_dev': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp]),
+    'csmri_adam_dev_lr': (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, vp, f32, vp]),
     'csmri_image_pool_exchange': (i32, [vp, vp, vp, vp, i32, i64, vp]),
     'csmri_weighted_sum': (i32, [C.POINTER(ScalarList), vp, vp]),
     'csmri_weighted_sum_bwd': (i32, [C.POINTER(ScalarList), vp, vp, vp]),
@@ -262,6 +263,7 @@ HBM_BYTES = {
     'csmri_bn_bwd_apply': ('bn_bwd_apply_kernel', lambda a: 3 * a[9] * a[10] * a[11] * _es(a[0])),
     # (p, g, m, v, n, ...): read p, g, m, v; write p, m, v
     'csmri_adam_dev': ('adam_dev_kernel', lambda a: 7 * a[4] * 4),
+    'csmri_adam_dev_lr': ('adam_dev_kernel', lambda a: 7 * a[4] * 4),
     'csmri_adam': ('adam_kernel', lambda a: 7 * a[4] * 4),
 }
 

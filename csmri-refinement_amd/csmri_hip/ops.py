@@ -398,6 +398,7 @@ def quantize_fp8(x, amax=None):
 
 
 SPLITK_OVERRIDE = None   # tools/sk_sweep.py only: force the split-K factor of csmri_gconv launches
+GCONV_FLAGS = 0          # tools only: or-ed into csmri_gconv_desc.flags (2 = CSMRI_GCONV_TAP_MAJOR)
 
 
 def _gconv_run(d, want_stats, flops=0.0):
@@ -423,13 +424,14 @@ def _gconv_run(d, want_stats, flops=0.0):
     nm = C.create_string_buffer(96)
     lib.call('csmri_gconv_kernel_name', C.byref(d), nm, 96)
     LAUNCH_LOG.append(('gconv', nm.value.decode(), splitk))
+  d.flags = GCONV_FLAGS
   if PROFILE is None:
     lib.call('csmri_gconv', C.byref(d), stream())
     return stats
   # profiling: bracket the main kernel alone, keyed by the instance name rocprofv3 reports
   name = C.create_string_buffer(96)
   lib.call('csmri_gconv_kernel_name', C.byref(d), name, 96)
-  d.flags = 1                                 # CSMRI_GCONV_DEFER_REDUCE
+  d.flags = 1 | GCONV_FLAGS                   # CSMRI_GCONV_DEFER_REDUCE
   label = name.value.decode()
   if PROFILE_SHAPES:
     label += ' B%d %dx%d Cin%d Cout%d t%dx%d s%d ncls%d sk%d' % (
@@ -2129,6 +2131,12 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
 
 def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0):
   """Adam with the step counter (int32 device tensor, steps already taken) on the device --
-  the form that can be captured into a hipGraph and replayed."""
+  the form that can be captured into a hipGraph and replayed.  ``lr``: a float, or a 1-element fp32 DEVICE tensor
+  (csmri_adam_dev_lr: a captured graph then follows a learning-rate schedule without being captured again)."""
+  if torch.is_tensor(lr):
+    assert lr.is_cuda and lr.dtype == torch.float32 and lr.numel() == 1
+    lib.call('csmri_adam_dev_lr', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr.data_ptr(),
+             float(beta1), float(beta2), float(eps), step_dev.data_ptr(), float(grad_scale), stream())
+    return
   lib.call('csmri_adam_dev', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
            float(beta1), float(beta2), float(eps), step_dev.data_ptr(), float(grad_scale), stream())

@@ -270,6 +270,7 @@ extern "C" int csmri_gconv_stats_rows(const csmri_gconv_desc* d0) {
   const csmri_gconv_desc* d = &t;
   if (uconv_eligible(d)) return uconv_stats_rows(d);
   if (tconv_eligible(d)) return tconv_stats_rows(d);
+  if (gpipe_eligible(d)) return gpipe_stats_rows(d);
   GConfig c = pick_config(d);
   return cdiv(desc_M(d), c.BM) * c.WM;
 }
@@ -291,7 +292,8 @@ extern "C" size_t csmri_gconv_slab_bytes(const csmri_gconv_desc* d) {
 #endif
 extern "C" int csmri_gconv_suggest_splitk(const csmri_gconv_desc* d) {
   { csmri_gconv_desc t = *d; t.splitk = 1;
-    if (thin_out1_eligible(&t) || tconv_eligible(&t) || pconv2_eligible(&t) || uconv_eligible(&t)) return 1; }
+    if (thin_out1_eligible(&t) || tconv_eligible(&t) || pconv2_eligible(&t) || uconv_eligible(&t)) return 1;
+    if (gpipe_eligible(&t)) return gpipe_splitk(&t); }
   GConfig c = pick_config(d);
   if (gconv_glds_eligible(d)) { c.BM = 128; c.BN = gconv_glds_bn(d); }
   if (d->dtype == CSMRI_FP8) { c.BM = 128; c.BN = gconv_fp8_bn(d); c.KC = 1; }
@@ -405,6 +407,7 @@ extern "C" int csmri_gconv_kernel_name(const csmri_gconv_desc* d, char* buf, int
   if (pconv2_eligible(d)) { snprintf(buf, n, "pconv2_kernel<3, 3, %d, false>", pconv2_bn(d)); return CSMRI_OK; }
   if (uconv_eligible(d)) { uconv_kernel_name(d, buf, n); return CSMRI_OK; }
   if (tconv_eligible(d)) { tconv_kernel_name(d, buf, n); return CSMRI_OK; }
+  if (gpipe_eligible(d)) { gpipe_kernel_name(d, buf, n); return CSMRI_OK; }
   if (gconv_glds_eligible(d)) { gconv_glds_kernel_name(d, buf, n); return CSMRI_OK; }
   GConfig c = pick_config(d);
   const int wn = c.BN >= 64 ? 2 : 1;
@@ -440,6 +443,12 @@ extern "C" int csmri_gconv(const csmri_gconv_desc* d, void* stream) {
   if (pconv2_eligible(d)) return pconv2_launch(p, d, st);
   if (uconv_eligible(d)) return uconv_launch(p, d, st);
   if (tconv_eligible(d)) return tconv_launch(p, d, st);
+  if (gpipe_eligible(d)) {
+    rc = gpipe_launch(p, d, st);
+    if (rc != CSMRI_OK) return rc;
+    if (p.splitk > 1 && !(d->flags & CSMRI_GCONV_DEFER_REDUCE)) return launch_reduce(p, st);
+    return CSMRI_OK;
+  }
   if (gconv_glds_eligible(d)) {
     rc = gconv_glds_launch(p, d, st);
     if (rc != CSMRI_OK) return rc;

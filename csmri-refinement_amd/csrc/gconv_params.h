@@ -20,6 +20,7 @@ struct GParams {
   int off32;                  // every input / output byte offset fits 32 bits
   const float* dq0; const float* dq1;   // fp8 operands: device scalars whose product dequantises the accumulators
   int us_n, us_x, us_y;                 // uconv: strips in all, strips per row of strips, rows of strips per image
+  int kord;                             // gpipe: K order of the steps (0 tap-major, 1 tap-inner)
   char* outq; int oqps; const float* oqs; unsigned* oamax;   // pconv2: fp8 copy of the output, its scale, |out| maximum (bits)
 };
 
@@ -64,6 +65,13 @@ void uconv_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
 int pconv2_eligible(const csmri_gconv_desc* d);
 int pconv2_bn(const csmri_gconv_desc* d);
 int pconv2_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
+
+// gpipe.hip
+int gpipe_eligible(const csmri_gconv_desc* d);
+int gpipe_splitk(const csmri_gconv_desc* d);
+int gpipe_stats_rows(const csmri_gconv_desc* d);
+int gpipe_launch(const GParams& p, const csmri_gconv_desc* d, hipStream_t st);
+void gpipe_kernel_name(const csmri_gconv_desc* d, char* buf, int n);
 
 // gconv_glds.hip
 int gconv_glds_eligible(const csmri_gconv_desc* d);

@@ -675,9 +675,10 @@ extern "C" int csmri_adam(float* p, const float* g, float* m, float* v, long lon
 // taken; this launch performs step *step_dev + 1 and a trailing 1-thread kernel increments the
 // counter) -- nothing step-dependent is baked into the launch, so the optimizer can live inside
 // a captured hipGraph and be replayed.
-__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n, float lr,
-                                float b1, float b2, float eps, const int* step_dev, float gscale) {
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n, float lr_arg,
+                                float b1, float b2, float eps, const int* step_dev, float gscale, const float* lr_dev) {
   const int step = *step_dev + 1;
+  const float lr = lr_dev ? *lr_dev : lr_arg;         // (csmri_adam_dev_lr: the rate lives in device memory)
   const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
   const float step_size = lr / bc1;
@@ -710,7 +711,22 @@ extern "C" int csmri_adam_dev(float* p, const float* g, float* m, float* v, long
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return CSMRI_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, lr, beta1,
-                     beta2, eps, (const int*)step_dev, grad_scale);
+                     beta2, eps, (const int*)step_dev, grad_scale, (const float*)nullptr);
+  CSMRI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(64), 0, st, step_dev);
+  CSMRI_LAUNCH_CHECK();
+  return CSMRI_OK;
+}
+// The same update with the learning rate read from device memory: NOTHING a scheduler changes is baked into the launch,
+// so a captured hipGraph follows an LR schedule without being captured again (the host writes *lr_dev before a replay).
+extern "C" int csmri_adam_dev_lr(float* p, const float* g, float* m, float* v, long long n, const float* lr_dev,
+                                 float beta1, float beta2, float eps, int* step_dev, float grad_scale,
+                                 void* stream) {
+  CSMRI_CHECK_ARG(p && g && m && v && n > 0 && step_dev && lr_dev);
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return CSMRI_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, 0.f, beta1,
+                     beta2, eps, (const int*)step_dev, grad_scale, lr_dev);
   CSMRI_LAUNCH_CHECK();
   hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(64), 0, st, step_dev);
   CSMRI_LAUNCH_CHECK();

@@ -114,6 +114,22 @@ def _split_disc_output(out, b):
   return first, second
 
 
+# hipGraph executables this process no longer replays are PARKED here, not destroyed.  Destroying a captured graph and
+# then instantiating and launching a new one whose buffers have the same addresses (the caching allocator hands a second
+# runner of the same shapes the blocks the first one freed) crashes inside hipGraphLaunch of this runtime -- a stale
+# entry of the executable's stream list, libamdhip64 +0xaee41, fault address 0x1d8; reproduced 28 times in 45 runs with
+# runners c3 -> c5 -> c5 in one process, 0 in 45 with the first c5 graphs kept alive (tools/segv_hunt.sh, DESIGN.md
+# section 4).  A training process captures once (the learning rate is a device scalar); only benchmarks and tests build
+# several runners, and they are short-lived.  CSMRI_DESTROY_GRAPHS=1 restores the destruction (the reproduction).
+GRAPH_GRAVEYARD = []
+
+
+def retire_graphs(g):
+  import os
+  if os.environ.get('CSMRI_DESTROY_GRAPHS') != '1':
+    GRAPH_GRAVEYARD.append([g.get('graphs'), g.get('pf_graph'), g.get('graph'), g.get('graph_adam')])
+
+
 def _epoch_window(spec):
   """Half-open epoch window [first, end) of a pretraining phase from its config value: a count n means the first n
   epochs (1-based), a pair is a window as given, None an empty window (semantics pinned by fixture F11 /
@@ -599,6 +615,8 @@ class AdversarialRunner(BaseRunner):
     else:
       segments = (self._seg1, self._seg2, self._seg3, self._seg4)
     cap_stream = ops.named_stream('capture')
+    self.disc_optimizer.sync_lr()
+    self.gen_optimizer.sync_lr()
     ops.GRAD_READY_HOOK = self._grad_hook        # same launch plan as the eager steps (the hook itself is a no-op while capturing)
     try:
       for seg in segments:
@@ -644,7 +662,14 @@ class AdversarialRunner(BaseRunner):
     g = getattr(self, '_graph', None)
     if g is not None and g['pool'] is not None:
       g['pool'].external_plan = False
+    if g is not None:
+      retire_graphs(g)
     self._graph = None
+
+  def __del__(self):
+    g = getattr(self, '_graph', None)
+    if g is not None:
+      retire_graphs(g)
 
   def _run_segments_graphed(self, batch, batch_next=None, pre_cur=None):
     from csmri_hip import ops
@@ -684,6 +709,8 @@ class AdversarialRunner(BaseRunner):
       G['pf_done'] = done
     if self.lookahead_first:
       launch_lookahead()
+    self.disc_optimizer.sync_lr()                  # (a scheduler may have moved the rates: device scalars, not graph nodes)
+    self.gen_optimizer.sync_lr()
     if len(G['graphs']) == 1:
       G['graphs'][0].replay()
       if not self.lookahead_first:
@@ -788,16 +815,11 @@ class AdversarialRunner(BaseRunner):
     self._after_lr_change(lrs)
 
   def _after_lr_change(self, old_lrs):
-    """The learning rate is a launch argument of the fused Adam kernel, i.e. baked into a captured
-    hipGraph: capture again (same static buffers' shapes) when a scheduler moved it."""
-    if self._learning_rates() != old_lrs and getattr(self, '_graph', None) is not None:
-      example = {k: v.clone() for k, v in self._graph['static'].items()}
-      # drop the old graphs (incl. the look-ahead graph) and their pool BEFORE the new capture
-      self.disable_graphs()
-      import gc
-      gc.collect()
-      torch.cuda.empty_cache()
-      self.enable_graphs(example, warmup=0)
+    """Nothing to re-capture: the fused Adam kernel reads its learning rate from device memory (csmri_adam_dev_lr,
+    FlatAdam.lr_dev), which FlatAdam.sync_lr() refreshes in front of the next eager step or graph replay.  (Until round 5
+    the rate was a launch argument and a scheduler step forced a new capture -- and dropping a captured graph to capture
+    its successor is what the HIP runtime does not survive reliably)"""
+    return None
 
   # -- steps outside the fused one-update-each case: a network disabled by a pretraining window, or several updates
   #    per step.  Semantics pinned by fixture F11 against oracle.gan_train_step / oracle.gan_train_multi_step

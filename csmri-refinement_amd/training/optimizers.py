@@ -36,6 +36,10 @@ class FlatAdam(object):
       p.grad = self.flat_g[off:off + n].view_as(p)
     self.step_count = 0                       # host mirror of step_dev
     self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    # the learning rate as the kernel reads it (csmri_adam_dev_lr): param_groups[0]['lr'] is what schedulers move;
+    # sync_lr() copies it here whenever it has changed -- before an eager step and before a graph replay
+    self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+    self._lr_mirror = float(lr)
     self._scale = 1.0
     # sub-buckets for the gradient exchange, cut at conv weights from the END of the buffer (the backward
     # finishes the last layers first) whenever a tail of >= 4 M elements has accumulated: the
@@ -107,15 +111,25 @@ class FlatAdam(object):
   def wait_allreduce(self):
     self._scale = self.bucket.wait()
 
+  def sync_lr(self):
+    """Bring the device-side learning rate up to date with param_groups[0]['lr'] (a fill on the current stream; nothing
+    when the rate has not moved).  Not callable while the stream is capturing: the rate must not become a graph node."""
+    lr = float(self.param_groups[0]['lr'])
+    if lr != self._lr_mirror:
+      assert not torch.cuda.is_current_stream_capturing(), 'learning rate changed inside a stream capture'
+      self.lr_dev.fill_(lr)
+      self._lr_mirror = lr
+
   def apply(self):
-    """The Adam kernel itself (step counter on the device: hipGraph-capturable)."""
+    """The Adam kernel itself (step counter and learning rate on the device: hipGraph-capturable)."""
+    self.sync_lr()
     if self.lazy_zero:
       for p in self.params:                         # parameters no kernel wrote since zero_grad(): zero gradient
         if getattr(p, '_grad_fresh', False):
           p.grad.zero_()
           p._grad_fresh = False
     ops.adam_step_dev(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq,
-                      self.param_groups[0]['lr'], self.betas[0], self.betas[1], self.eps,
+                      self.lr_dev, self.betas[0], self.betas[1], self.eps,
                       self.step_dev, self._scale)
     self.step_count += 1
     groups = self.pack_groups() if self.pack_groups is not None else None

@@ -104,19 +104,9 @@ class Runner(BaseRunner):
     return self.optimizer.param_groups[0]['lr'] if self.optimizer is not None else None
 
   def _after_lr_change(self, old_lr):
-    """The learning rate is a launch argument of the fused Adam kernel, i.e. baked into the captured hipGraph:
-    capture again when a scheduler moved it (as AdversarialRunner._after_lr_change does).  No warm-up steps: the
-    re-capture must not train."""
-    G = getattr(self, '_graph', None)
-    if G is not None and self._lr() != old_lr:
-      example = {k: v.clone() for k, v in G['static'].items()}
-      # drop the old graph and its private pool BEFORE the new capture (otherwise peak memory doubles at batch 64)
-      self.disable_graphs()
-      del G
-      import gc
-      gc.collect()
-      torch.cuda.empty_cache()
-      self.enable_graphs(example, warmup=0)
+    """Nothing to re-capture: the captured Adam kernel reads the learning rate from device memory
+    (FlatAdam.lr_dev / sync_lr, csmri_adam_dev_lr); see AdversarialRunner._after_lr_change."""
+    return None
 
   def predict(self, batch):
     return self.model(*self.train_model_input_fn(batch, use_batch_transform=False))
@@ -172,6 +162,7 @@ class Runner(BaseRunner):
     import gc
     gc.collect()
     cap = _ops.named_stream('capture')
+    self.optimizer.sync_lr()                         # (the rate is a device scalar the captured kernel reads: never a node)
     split = dist_utils.exchange_active()
     g = torch.cuda.CUDAGraph()
     g2 = None
@@ -190,7 +181,15 @@ class Runner(BaseRunner):
     return self
 
   def disable_graphs(self):
+    if getattr(self, '_graph', None) is not None:
+      from training.adversarial_runner import retire_graphs
+      retire_graphs(self._graph)
     self._graph = None
+
+  def __del__(self):
+    if getattr(self, '_graph', None) is not None:
+      from training.adversarial_runner import retire_graphs
+      retire_graphs(self._graph)
 
   def _train_step(self, loader):
     batch = self._request_data(loader)
@@ -199,6 +198,7 @@ class Runner(BaseRunner):
     G = getattr(self, '_graph', None)
     if G is not None:
       torch._foreach_copy_(list(G['static'].values()), [batch[k] for k in G['static']])
+      self.optimizer.sync_lr()
       G['graph'].replay()
       if G['graph_adam'] is not None:
         self.optimizer.start_allreduce()

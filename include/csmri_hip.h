@@ -105,7 +105,7 @@ typedef struct csmri_gconv_desc {
   /* split-K */
   int splitk;                /* >=1; >1 needs slab */
   float* slab;               /* [splitk][M][Cout] fp32 workspace */
-  int flags;                 /* CSMRI_GCONV_DEFER_REDUCE: caller runs csmri_gconv_reduce itself */
+  int flags;                 /* CSMRI_GCONV_DEFER_REDUCE: caller runs csmri_gconv_reduce itself; CSMRI_GCONV_TAP_MAJOR */
   /* optional output window (reflection-padded dgrad without a full fold pass): positions whose
    * tensor coordinate (ty, tx) lies inside [win_y0, win_y0+win_h) x [win_x0, win_x0+win_w) are
    * written to `out`, now a dense [B, win_h, win_w] tensor indexed by (ty-win_y0, tx-win_x0)
@@ -129,6 +129,7 @@ typedef struct csmri_gconv_desc {
   void* out_q; int out_q_pix_stride; const float* out_q_scale; float* out_amax;
 } csmri_gconv_desc;
 #define CSMRI_GCONV_DEFER_REDUCE 1
+#define CSMRI_GCONV_TAP_MAJOR 2     /* diagnostic: the persistent gather kernel walks K tap-major (the pack's order) instead of tap-inner */
 
 int csmri_gconv(const csmri_gconv_desc* d, void* stream);
 /* second stage of a split-K launch (slab sum + epilogue); no-op when splitk <= 1 */
@@ -567,6 +568,14 @@ int csmri_adam(float* p, const float* g, float* m, float* v, long long n, float 
 int csmri_adam_dev(float* p, const float* g, float* m, float* v, long long n, float lr,
                    float beta1, float beta2, float eps, int* step_dev, float grad_scale,
                    void* stream);
+
+/* csmri_adam_dev with the learning rate in device memory as well (*lr_dev, fp32): nothing a learning-rate scheduler
+ * (reference training/lr_schedulers.py, stepped by the runners' epoch hooks, training/adversarial_runner.py:267-305)
+ * changes is a launch argument, so a captured hipGraph follows the schedule without being captured again -- the host
+ * writes *lr_dev on the stream ahead of the replay. */
+int csmri_adam_dev_lr(float* p, const float* g, float* m, float* v, long long n, const float* lr_dev,
+                      float beta1, float beta2, float eps, int* step_dev, float grad_scale,
+                      void* stream);
 
 /* One query of the discriminator's history pool of generated images (reference utils/image_pool.py:8-60,
  * called from the discriminator input function, training/adversarial_training.py) as ONE launch:

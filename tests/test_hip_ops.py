@@ -73,6 +73,11 @@ CONV_CASES = [
     ('p2_c192', 192, 256, 3, 1, 'zero', False, 64, 60, 8),             # pconv2: three chunks per tile, two channel blocks, partial tiles
     ('vgg4_patch2', 512, 512, 3, 1, 'zero', False, 40, 36, 12),       # 108 tiles x 4 channel blocks: pconv2 (loader waves), fwd and dgrad; partial edge tiles
     ('unet_patch_k4', 128, 128, 4, 1, 'reflection', False, 96, 96, 16),  # a 4x4 reflection-padded 128-channel layer at 1152 row tiles (gconv_glds, one-buffer variant)
+    # the discriminator's layer forms on the persistent pipelined gather kernel (gpipe.hip), reduced batches:
+    ('gp_l2', 64, 128, 4, 2, 'reflection', False, 128, 128, 4),    # forward 64 tiles; data gradient 4 classes x 67 ragged tiles of 64 channels (two rounds of work items)
+    ('gp_l3', 128, 256, 4, 2, 'reflection', False, 32, 32, 6),     # 192-row tiles
+    ('gp_l5', 512, 1024, 4, 2, 'reflection', False, 16, 16, 3),    # small M: split-K slabs, forward and per-class data gradient
+    ('gp_l6', 1024, 1024, 4, 1, 'reflection', False, 8, 8, 3),     # stride 1 on an 8 x 8 map: 16 taps of 1024 channels, padded data gradient with halo window
 ]
 
 
@@ -106,7 +111,7 @@ def ref_conv(x, wt, bias, stride, pads, mode, up, slope):
 def test_conv_fwd_bwd(hip, case, dtype):
   ops = hip.ops
   name, cin, cout, k, stride, border, up, h, w, b = case
-  if name in ('vgg3_tile256', 'vgg2_patch', 'vgg2_1_patch2', 'p2_c192', 'vgg4_patch2', 'unet_patch_k4') and dtype == torch.float32:
+  if (name in ('vgg3_tile256', 'vgg2_patch', 'vgg2_1_patch2', 'p2_c192', 'vgg4_patch2', 'unet_patch_k4') or name.startswith('gp_')) and dtype == torch.float32:
     pytest.skip('the 256-row / patch kernels are bf16-only; at 16M outputs the fp32 comparison trips on '
                 'LeakyReLU-derivative sign flips of pre-activations at the rounding floor')
   layer, wt, bias, x, pads, mode = make_layer(hip, case, dtype)
@@ -172,6 +177,63 @@ def test_reflection_dgrad_gated_window_vs_oracle(hip, case, g_slope):
   for sl in ((slice(None), slice(None), slice(0, 2)), (slice(None), slice(None), slice(h - 3, h)),
              (slice(None), slice(None), slice(None), slice(0, 2)), (slice(None), slice(None), slice(None), slice(w - 3, w))):
     assert rel_l2(gb[sl], rb[sl]) < 1e-2, (name, sl)
+
+
+GPIPE_CASES = [
+    # name, cin, cout, stride, H, W, B
+    ('l2', 64, 128, 2, 128, 128, 4), ('l3', 128, 256, 2, 64, 64, 3), ('l4', 256, 512, 2, 32, 32, 5),
+    ('l5', 512, 1024, 2, 16, 16, 5), ('l6', 1024, 1024, 1, 8, 8, 5), ('l4_ragged', 256, 256, 2, 22, 26, 3),
+]
+
+
+@pytest.mark.parametrize('case', GPIPE_CASES, ids=[c[0] for c in GPIPE_CASES])
+def test_gpipe_discriminator_layer_forms(hip, case):
+  """The persistent pipelined gather kernel (gpipe.hip) on every form the discriminator's layers 2-6 launch it in
+  (reference models/discriminators.py:137-172: [ReflectionPad -> Conv4x4 stride 2] x 5, [ReflectionPad(1,2,1,2) -> Conv4x4
+  stride 1]), against CPU autograd on the same bf16-rounded operands:
+    forward with the BatchNorm partial sums from the epilogue (the sums against the CPU output's, 1e-3 relative),
+    forward without (split-K slabs where the plan splits), the data gradient of a stride-2 layer as four output-parity
+    classes, of the stride-1 layer on its padded extent, both through the halo window + fold, ungated and gated by the
+    producer's LeakyReLU(0.2) (the gradient that reaches layer 1 is gated: discriminators.py:144).
+  The launch log must name gpipe_kernel for every one of them.  Tolerance: relative L2 <= 1e-2 (bf16 output rounding is
+  ~2e-3; the reductions are fp32)."""
+  ops = hip.ops
+  name, cin, cout, stride, h, w, b = case
+  dtype = torch.bfloat16
+  layer, wt, bias, x, pads, mode = make_layer(hip, (name, cin, cout, 4, stride, 'reflection', False, h, w, b), dtype)
+  xd = to_dev_nhwc(x, dtype)
+  log = ops.LAUNCH_LOG = []
+  try:
+    ref = F.conv2d(O.pad2d(x, pads, mode), wt, None, stride=stride)
+    m = ref.shape[0] * ref.shape[2] * ref.shape[3]
+    y, _ = ops.conv_forward(layer, xd, None, False)
+    check(name + ' fwd', from_dev_nhwc(y, cout), ref, dtype)
+    if m % 64 == 0:
+      ys, stats = ops.conv_forward(layer, xd, None, False, 1.0, True)
+      torch.cuda.synchronize()
+      check(name + ' fwd (stats form)', from_dev_nhwc(ys, cout), ref, dtype)
+      st = stats.cpu().reshape(-1)
+      rows = st.numel() // (2 * y.shape[3])
+      st = st.view(2, y.shape[3], rows).double().sum(2)           # [2][Cout][rows]
+      s1, s2 = ref.double().sum((0, 2, 3)), (ref.double() ** 2).sum((0, 2, 3))
+      assert float((st[0, :cout] - s1).abs().max()) < 1e-3 * float(s1.abs().max() + 1.0), name
+      assert float((st[1, :cout] - s2).abs().max()) < 1e-3 * float(s2.abs().max()), name
+    gen = torch.Generator().manual_seed(3)
+    gy = torch.randn(ref.shape, generator=gen).bfloat16().float()
+    gs = torch.randn(x.shape, generator=gen).bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(O.pad2d(xr, pads, mode), wt, None, stride=stride).backward(gy)
+    gyd, gsd = to_dev_nhwc(gy, dtype), to_dev_nhwc(gs, dtype)
+    dx = ops.conv_dgrad(layer, gyd, (h, w))
+    check(name + ' dgrad', from_dev_nhwc(dx, cin), xr.grad, dtype)
+    dxg = ops.conv_dgrad(layer, gyd, (h, w), g_src=gsd, g_slope=0.2)
+    gated = xr.grad * torch.where(gs > 0, torch.ones_like(gs), torch.full_like(gs, 0.2))
+    check(name + ' dgrad gated', from_dev_nhwc(dxg, cin), gated, dtype)
+  finally:
+    ops.LAUNCH_LOG = None
+  names = [e[1] for e in log if e[0] == 'gconv']
+  print(name, sorted(set((e[1], e[2]) for e in log if e[0] == 'gconv')))
+  assert names and all(n.startswith('gpipe_kernel') for n in names), names
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])

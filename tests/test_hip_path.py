@@ -1603,8 +1603,9 @@ def test_recnet_runner_graph_replay_equals_eager(env):
 
 
 def test_recnet_runner_graph_mode_follows_the_lr_scheduler(env):
-  """the learning rate is a launch argument of the captured Adam kernel, so the standard Runner
-  re-captures its hipGraph when a scheduler moves it (Runner._after_lr_change).  Graph mode + a multistep schedule
+  """The learning rate is a DEVICE scalar of the captured Adam kernel (csmri_adam_dev_lr; until round 5 a launch argument
+  that forced a new capture whenever a scheduler moved it): the graph captured once follows the schedule -- the very
+  same graph object replays in all three epochs.  Graph mode + a multistep schedule
   (decay at epochs 1 and 2, factor 0.1 -- large enough that a stale rate cannot hide) equals the eager run over
   3 epochs bit for bit: losses, learning rates, parameters."""
   Configuration, set_dtype = env
@@ -1627,8 +1628,10 @@ def test_recnet_runner_graph_mode_follows_the_lr_scheduler(env):
     if graphs:
       r.enable_graphs(batches[0], warmup=0)
     out, lrs = [], []
+    g0 = r._graph['graph'] if graphs else None
     for epoch in (1, 2, 3):
       r.epoch_beginning(epoch)
+      assert not graphs or r._graph['graph'] is g0, 'the graph must not be captured again when the rate moves'
       lrs.append(r.optimizer.param_groups[0]['lr'])
       losses, _ = r.train_epoch(Loader(batches), epoch)
       r.epoch_finished(epoch)

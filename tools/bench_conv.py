@@ -104,6 +104,7 @@ def run(name, mode='fwd', iters=20):
 
 
 if __name__ == '__main__':
+  ops.GCONV_FLAGS = int(os.environ.get('GCONV_FLAGS', '0'))
   names = [a for a in sys.argv[1:] if a in CASES] or list(CASES)
   modes = [a for a in sys.argv[1:] if a in ('fwd', 'fwdb', 'fwdb8', 'fwdbq', 'fwds', 'dgrad', 'dgradg', 'wgrad')] or ['fwd']
   for n in names:

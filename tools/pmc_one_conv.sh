@@ -13,7 +13,7 @@ R = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for fn in glob.glob(R + '/gpurun_out/pmc1/**/*counter_collection.csv', recursive=True):
   for r in csv.DictReader(open(fn)):
-    if ('conv' in r['Kernel_Name'] or 'wgrad' in r['Kernel_Name'] or 'wpatch' in r['Kernel_Name']) and 'reduce' not in r['Kernel_Name'] and 'scatter' not in r['Kernel_Name']:
+    if ('conv' in r['Kernel_Name'] or 'gpipe' in r['Kernel_Name'] or 'wgrad' in r['Kernel_Name'] or 'wpatch' in r['Kernel_Name']) and 'reduce' not in r['Kernel_Name'] and 'scatter' not in r['Kernel_Name']:
       agg[r['Kernel_Name'][:48]][r['Counter_Name']] += float(r['Counter_Value']); n[(r['Kernel_Name'][:48], r['Counter_Name'])] += 1
 for k, d in agg.items():
   for c, v in sorted(d.items()):
