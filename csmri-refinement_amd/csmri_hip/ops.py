@@ -398,10 +398,11 @@ def quantize_fp8(x, amax=None):
 
 
 SPLITK_OVERRIDE = None   # tools/sk_sweep.py only: force the split-K factor of csmri_gconv launches
-GCONV_FLAGS = 0          # tools only: or-ed into csmri_gconv_desc.flags (2 = CSMRI_GCONV_TAP_MAJOR)
+GCONV_FLAGS = 0          # or-ed into csmri_gconv_desc.flags (2 = CSMRI_GCONV_USE_GPIPE: the persistent gather kernel, opt-in)
 
 
 def _gconv_run(d, want_stats, flops=0.0):
+  d.flags = GCONV_FLAGS
   splitk = lib.raw('csmri_gconv_suggest_splitk')(C.byref(d))
   if SPLITK_OVERRIDE is not None and splitk >= 1 and not want_stats:
     splitk = SPLITK_OVERRIDE

@@ -20,7 +20,7 @@ struct GParams {
   int off32;                  // every input / output byte offset fits 32 bits
   const float* dq0; const float* dq1;   // fp8 operands: device scalars whose product dequantises the accumulators
   int us_n, us_x, us_y;                 // uconv: strips in all, strips per row of strips, rows of strips per image
-  int kord;                             // gpipe: K order of the steps (0 tap-major, 1 tap-inner)
+  unsigned dv_howo_m, dv_howo_s, dv_wo_m, dv_wo_s;   // gpipe: magic numbers of the divisions by Ho*Wo and Wo (non powers of two)
   char* outq; int oqps; const float* oqs; unsigned* oamax;   // pconv2: fp8 copy of the output, its scale, |out| maximum (bits)
 };
 

@@ -57,6 +57,9 @@ template <int N> __device__ __forceinline__ void gp_vmwait() { asm volatile("s_w
 #define GP_TIE_B2 "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1])
 #define GP_TIE_B4 "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3])
 
+// n / d for a divisor fixed on the host (round-up magic number, branch-free form): q = (t + ((n - t) >> 1)) >> s, t = mulhi(m, n)
+__device__ __forceinline__ unsigned gp_div(unsigned n, unsigned m, unsigned sh) { const unsigned t = __umulhi(m, n); return (t + ((n - t) >> 1)) >> sh; }
+
 struct GpItem { int m0, n0, cls, ks, mt, s_begin, nst; };
 
 template <int FM, int BN>
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(768, 1) void gpipe_kernel(const GParams p) {
   constexpr int BM = 64 * FM, ABYTES = BM * 128, BBYTES = BN * 128, STG = ABYTES + BBYTES, NS = 3;
   constexpr int KA = BM / 32, KB = BN / 32, NP = KA + KB;          // LDS-DMA pieces (1 KiB) per loader wave and stage
   constexpr int FN = BN / 32;                                       // 16-channel fragments per compute wave
-  static_assert((FM == 4 || FM == 3) && (BN == 128 || BN == 64) && NS * STG <= 160 * 1024, "tile");
+  static_assert((FM == 4 || FM == 3) && (BN == 128 || BN == 64) && NS * STG + 16 * BM * 4 <= 160 * 1024, "tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,35 +92,41 @@ __global__ __launch_bounds__(768, 1) void gpipe_kernel(const GParams p) {
   };
   int S = 0;
   for (int j = 0; j < n_my; ++j) S += item(j).nst;
+  // m -> (image, row, column) of the output class: shifts when Ho * Wo and Wo are powers of two, else host-made magic numbers
+  auto decode = [&](int m, int& b, int& oy, int& ox) __attribute__((always_inline)) {
+    if (p.howo_shift >= 0) { b = m >> p.howo_shift; const int r = m & (HoWo - 1); oy = r >> p.wo_shift; ox = r & (p.Wo - 1); }
+    else { b = (int)gp_div((unsigned)m, p.dv_howo_m, p.dv_howo_s); const int r = m - b * HoWo; oy = (int)gp_div((unsigned)r, p.dv_wo_m, p.dv_wo_s); ox = r - oy * p.Wo; }
+  };
 
   if (wv >= 8) {
     // =================================================== loader waves ===================================================
     const int L = wv - 8, lrow = lane >> 3;
     // piece k of a stage = rows 8 (L + 4 k) .. + 7 of the image; this lane's 16-byte slot holds K chunk `chunk` of its row
     const int chunk = (lane & 7) ^ ((4 * (L & 1) + (lane >> 4)) & 7);
-    int by[KA], bx[KA], ibase[KA];
-    const char* aptr[KA];
-    const char* wrow[KB];
+    const char* aptr[KA]; unsigned ainc[KA];
+    const char* wptr[KB];
     int ci = 0, tap = 0, left = 0, jn = 0;
-    const int ntaps = p.TH * p.TW;
+    const int ntaps = p.TH * p.TW, sub = lane & 7;
     const char* in0 = p.in0 + chunk * 16;
     const char* zero_page = gp_zero_page;
     const unsigned ps2 = (unsigned)p.ps0 * 2u;
-    // K order (p.kord): 0 = tap-major (all channel chunks of a tap, then the next tap: the weight pack's order),
-    // 1 = TAP-INNER (all taps of a 64-channel chunk, then the next chunk).  Neighbouring taps read the same input
-    // pixels for shifted output positions: tap-inner puts those re-reads one step apart, where they still hit L2 --
-    // tap-major puts Cin / 64 steps (x 32 CUs x 40-48 KiB per step through a 4 MiB L2) between them.
-    auto compute_ptrs = [&]() __attribute__((always_inline)) {
-      const int ty = tap / p.TW, tx = tap - ty * p.TW;
+    // Source pixel of every (tap, tile row) of the current item: a table in LDS behind the ring, [16 taps][BM rows] ints,
+    // -1 = outside the image (zero page).  The eight lanes that share a row build it together at the item's start (two
+    // taps each) and read it back at every tap change -- one ds_read per row instead of the border arithmetic (the
+    // arithmetic at every tap change cost the loaders ~1700 cycles per change, profiles/r06_gpipe_stamps2.log).  Only this
+    // wave touches its rows' entries: no barrier, LDS operations of one wave stay in order.
+    int* const tab = (int*)(smem + NS * STG) + 8 * L + lrow;          // + 32 k for piece k, + BM per tap
+    const int tinv = (256 + p.TW - 1) / p.TW;                          // tap / TW for tap < 16, TW <= 4
+    auto load_tap = [&]() __attribute__((always_inline)) {
+      int pix[KA];
+#pragma unroll
+      for (int k = 0; k < KA; ++k) pix[k] = tab[tap * BM + 32 * k];
 #pragma unroll
       for (int k = 0; k < KA; ++k) {
-        int u = by[k] + ty * p.dys, v = bx[k] + tx * p.dxs;
-        bool ok = ibase[k] >= 0;
-        if (p.border == CSMRI_BORDER_REFLECT) { u = reflect_idx(u, p.Hin); v = reflect_idx(v, p.Win); }
-        else ok = ok && (unsigned)u < (unsigned)p.Hin && (unsigned)v < (unsigned)p.Win;
-        const int pix = ibase[k] + u * p.Win + v;
-        const char* g = p.off32 ? in0 + ((unsigned)pix * ps2 + (unsigned)ci * 2u) : in0 + ((size_t)pix * ps2 + (size_t)ci * 2);
+        const bool ok = pix[k] >= 0;
+        const char* g = in0 + ((unsigned)pix[k] * ps2 + (unsigned)ci * 2u);         // 32-bit offsets (gpipe_eligible)
         aptr[k] = ok ? g : zero_page;
+        ainc[k] = ok ? 128u : 0u;
       }
     };
     auto begin_item = [&]() __attribute__((always_inline)) {
@@ -128,57 +137,80 @@ __global__ __launch_bounds__(768, 1) void gpipe_kernel(const GParams p) {
         const int m = it.m0 + 8 * (L + 4 * k) + lrow;
         int b = 0, oy = 0, ox = 0;
         const bool mv = m < p.M;
-        if (mv) {
-          if (p.howo_shift >= 0) { b = m >> p.howo_shift; const int r = m & (HoWo - 1); oy = r >> p.wo_shift; ox = r & (p.Wo - 1); }
-          else { b = m / HoWo; const int r = m - b * HoWo; oy = r / p.Wo; ox = r - oy * p.Wo; }
+        if (mv) decode(m, b, oy, ox);
+        const int by = oy * p.S + p.dy0, bx = ox * p.S + p.dx0, ibase = b * p.Hin * p.Win;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = sub + 8 * tt;
+          if (t < ntaps) {
+            const int ty = (t * tinv) >> 8, tx = t - ty * p.TW;
+            int u = by + ty * p.dys, v = bx + tx * p.dxs;
+            bool ok = mv;
+            if (p.border == CSMRI_BORDER_REFLECT) { u = reflect_idx(u, p.Hin); v = reflect_idx(v, p.Win); }
+            else ok = ok && (unsigned)u < (unsigned)p.Hin && (unsigned)v < (unsigned)p.Win;
+            tab[t * BM + 32 * k] = ok ? ibase + u * p.Win + v : -1;
+          }
         }
-        by[k] = oy * p.S + p.dy0; bx[k] = ox * p.S + p.dx0;
-        ibase[k] = mv ? b * p.Hin * p.Win : -1;
       }
-      if (p.kord) { const int ch = it.s_begin / ntaps; tap = it.s_begin - ch * ntaps; ci = ch * 64; }
-      else { const int k0 = it.s_begin * 64; tap = k0 / p.Cin; ci = k0 - tap * p.Cin; }
-      compute_ptrs();
+      const int k0 = it.s_begin * 64;
+      tap = k0 / p.Cin; ci = k0 - tap * p.Cin;
+      load_tap();
 #pragma unroll
       for (int k = 0; k < KB; ++k)
-        wrow[k] = p.w + ((size_t)it.cls * (size_t)p.wcs + (size_t)(it.n0 + 8 * (L + 4 * k) + lrow) * p.Kp + chunk * 8) * 2;
+        wptr[k] = p.w + ((size_t)it.cls * (size_t)p.wcs + (size_t)(it.n0 + 8 * (L + 4 * k) + lrow) * p.Kp + chunk * 8) * 2 +
+                  (size_t)it.s_begin * 128;
     };
+    // A stage is issued in TWO parts, one per half step (an LDS-DMA instruction costs its wave ~100-160 cycles: the
+    // whole stage in the first half made that half 1600 cycles long with the compute waves waiting at its barrier,
+    // profiles/r06_gpipe_stamps1.log): pieces [0, N1) = the first N1 of {A pieces, then B pieces}, pieces [N1, NP) the rest.
+#ifndef GPIPE_N1_NUM
+#define GPIPE_N1_NUM 6
+#endif
+    constexpr int N1 = (NP * GPIPE_N1_NUM + 9) / 10;                  // first part: 60 % of the pieces (the second half also holds the wait)
     unsigned ring = 0;
-    auto issue_stage = [&]() __attribute__((always_inline)) {
+    auto issue_part = [&](auto part_c) __attribute__((always_inline)) {
+      constexpr int part = decltype(part_c)::value;
       char* dst = smem + ring + L * 1024;
 #pragma unroll
       for (int k = 0; k < KA; ++k)
-        __builtin_amdgcn_global_load_lds((gpg_t)aptr[k], (gpl_t)(dst + k * 4096), 16, 0, 0);
-      const size_t koff = ((size_t)tap * p.Cin + ci) * 2;            // this step's 64 K elements in the [N][Kp] pack
+        if ((part == 0) == (k < N1)) {
+          __builtin_amdgcn_global_load_lds((gpg_t)aptr[k], (gpl_t)(dst + k * 4096), 16, 0, 0);
+          aptr[k] += ainc[k];
+        }
 #pragma unroll
       for (int k = 0; k < KB; ++k)
-        __builtin_amdgcn_global_load_lds((gpg_t)(wrow[k] + koff), (gpl_t)(dst + ABYTES + k * 4096), 16, 0, 0);
-      ring += STG; if (ring == NS * STG) ring = 0;
-      if (--left == 0) { if (jn < n_my) begin_item(); }
-      else if (p.kord) {
-        if (++tap == ntaps) { tap = 0; ci += 64; }
-        compute_ptrs();
-      } else {
-        ci += 64;
-        if (ci == p.Cin) { ci = 0; ++tap; }
-        compute_ptrs();
+        if ((part == 0) == (KA + k < N1)) {
+          __builtin_amdgcn_global_load_lds((gpg_t)wptr[k], (gpl_t)(dst + ABYTES + k * 4096), 16, 0, 0);
+          wptr[k] += 128;
+        }
+      if constexpr (part == 1) {
+        ring += STG; if (ring == NS * STG) ring = 0;
+        if (--left == 0) { if (jn < n_my) begin_item(); }
+        else {
+          ci += 64;
+          if (ci == p.Cin) { ci = 0; ++tap; load_tap(); }
+        }
       }
     };
     begin_item();
-    issue_stage();
-    if (S > 1) { issue_stage(); gp_vmwait<NP>(); } else gp_vmwait<0>();
+    issue_part(std::integral_constant<int, 0>{}); issue_part(std::integral_constant<int, 1>{});
+    if (S > 1) { issue_part(std::integral_constant<int, 0>{}); issue_part(std::integral_constant<int, 1>{}); gp_vmwait<NP>(); }
+    else gp_vmwait<0>();
     __builtin_amdgcn_s_barrier();                      // stage 0 has landed
     GP_STAMP_DECL;
     for (int s = 0; s < S; ++s) {
-      // ---- first half of step s: stage s+2 into the slot stage s-1 left
-      if (s + 2 < S) issue_stage();
+      // ---- first half of step s: the first part of stage s+2 into the slot stage s-1 left
+      if (s + 2 < S) issue_part(std::integral_constant<int, 0>{});
       GP_STAMP(0);
       __builtin_amdgcn_s_barrier();
       GP_STAMP(1);
-      // ---- second half: retire stage s+1 (read from the next first half on); only stage s+2's pieces are younger
-      if (s + 2 < S) gp_vmwait<NP>(); else gp_vmwait<0>();
-      GP_STAMP(2);
-      __builtin_amdgcn_s_barrier();
+      // ---- second half: retire stage s+1 (read from the next first half on) -- only the N1 pieces just issued are
+      // younger --, then the second part of stage s+2
+      if (s + 2 < S) { gp_vmwait<N1>(); GP_STAMP(2); issue_part(std::integral_constant<int, 1>{}); }
+      else { gp_vmwait<0>(); GP_STAMP(2); }
       GP_STAMP(3);
+      __builtin_amdgcn_s_barrier();
+      GP_STAMP(4);
     }
     __builtin_amdgcn_s_barrier();
     GP_STAMP_DUMP;
@@ -251,8 +283,7 @@ __global__ __launch_bounds__(768, 1) void gpipe_kernel(const GParams p) {
         bool inside = true;
         if (!p.dense_out) {
           int b, oy, ox;
-          if (p.howo_shift >= 0) { b = m >> p.howo_shift; const int r = m & (HoWo - 1); oy = r >> p.wo_shift; ox = r & (p.Wo - 1); }
-          else { b = m / HoWo; const int r = m - b * HoWo; oy = r / p.Wo; ox = r - oy * p.Wo; }
+          decode(mv ? m : 0, b, oy, ox);
           const int ty_ = oy * p.osy + ooy, tx_ = ox * p.osx + oox;
           fpix = (unsigned)((b * p.Hout_t + ty_) * p.Wout_t + tx_); opix = fpix;
           if (p.out2) {
@@ -393,10 +424,13 @@ __global__ __launch_bounds__(768, 1) void gpipe_kernel(const GParams p) {
 
 // ---------------------------------------------------------------------------------------------
 #ifndef GPIPE
-#define GPIPE 1
+#define GPIPE 1        // 1: eligible launches with at least GPIPE_MIN_STEPS K steps; 0: only where csmri_gconv_desc.flags carries CSMRI_GCONV_USE_GPIPE
 #endif
-#ifndef GPIPE_KORD
-#define GPIPE_KORD 1
+// Measured against gconv_glds on the discriminator's fifteen launches (profiles/r06_gpipe_vs_glds.log): gpipe wins where an
+// item's K loop is long enough to amortise its epilogue (the persistent workgroup cannot hide it behind another
+// workgroup's K loop as three resident gconv_glds workgroups do): from 32 steps on (layers 3-6 forward, 4-6 data gradient).
+#ifndef GPIPE_MIN_STEPS
+#define GPIPE_MIN_STEPS 32
 #endif
 #ifndef GPIPE_CUS
 #define GPIPE_CUS 256
@@ -433,11 +467,16 @@ static GpPlan gp_plan(const csmri_gconv_desc* d, int forced_sk = 0) {
 }
 
 int gpipe_eligible(const csmri_gconv_desc* d) {
-  if (!GPIPE) return 0;
+  if (!(d->flags & CSMRI_GCONV_USE_GPIPE) && (!GPIPE || d->TH * d->TW * d->Cin / 64 < GPIPE_MIN_STEPS || d->stats_partial)) return 0;
   if (d->dtype != CSMRI_BF16) return 0;
   if (d->Cin % 64 || d->Cout % 64) return 0;
   if (d->in1 || d->upsample) return 0;
   if (d->in0_pix_stride % 8) return 0;
+  if (d->TH * d->TW > 16 || d->TW > 4) return 0;        // rows of the source-pixel table; tap / TW by multiplication
+  { const long long howo = (long long)d->Ho * d->Wo;     // m -> (b, oy, ox): both divisors powers of two, or neither (magic numbers)
+    auto p2 = [](long long v) { return (v & (v - 1)) == 0; };
+    if (!(p2(howo) && p2(d->Wo)) && (p2(howo) || p2(d->Wo) || d->Wo < 3)) return 0; }
+  if ((long long)d->B * d->Hin * d->Win * d->in0_pix_stride * 2 >= (1ll << 31)) return 0;   // 32-bit input byte offsets
   if (d->stats_partial && d->g_src) return 0;           // the BatchNorm-sums instance of the epilogue carries no gate
   if (d->stats_partial && ((long long)d->B * d->Ho * d->Wo) % 64) return 0;
   if (!(d->act_slope >= 0.f && d->act_slope <= 1.f)) return 0;
@@ -455,7 +494,7 @@ int gpipe_stats_rows(const csmri_gconv_desc* d) { return gp_plan(d, 1).mtiles * 
 
 template <int FM, int BN>
 static int launch_gpipe(const GParams& p, int grid, hipStream_t st) {
-  constexpr int lds = 3 * (64 * FM + BN) * 128;
+  constexpr int lds = 3 * (64 * FM + BN) * 128 + 16 * 64 * FM * 4;     // ring of three stages + the (tap, row) source-pixel table
   auto kern = gpipe_kernel<FM, BN>;
   CSMRI_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, st, p);
@@ -478,7 +517,18 @@ int gpipe_launch(const GParams& p0, const csmri_gconv_desc* d, hipStream_t st) {
   const long long w_elems = (long long)d->Cout * d->TH * d->TW * d->Cin * p.nclass;
   const long long x_elems = (long long)d->B * d->Hin * d->Win * d->Cin;
   p.nt_major = w_elems > x_elems;
-  p.kord = (d->flags & CSMRI_GCONV_TAP_MAJOR) ? 0 : GPIPE_KORD;
+  auto magic = [](unsigned dd, unsigned* m, unsigned* sh) {            // round-up magic number of n / dd, dd >= 2 and not a power of two
+    unsigned l = 0; while ((1ull << l) < dd) ++l;
+    *m = (unsigned)((((1ull << l) - dd) << 32) / dd + 1); *sh = l - 1;
+  };
+  p.dv_howo_m = p.dv_howo_s = p.dv_wo_m = p.dv_wo_s = 0;
+  if (p.howo_shift < 0) {
+    auto pow2 = [](unsigned v) { return (v & (v - 1)) == 0; };
+    // (a power-of-two divisor beside a non-power-of-two one: the magic form needs l >= 1; handle through shift-only magic)
+    const unsigned howo = (unsigned)d->Ho * d->Wo, wo = (unsigned)d->Wo;
+    if (pow2(howo) || pow2(wo) || howo < 2 || wo < 2) return CSMRI_E_UNSUPPORTED;
+    magic(howo, &p.dv_howo_m, &p.dv_howo_s); magic(wo, &p.dv_wo_m, &p.dv_wo_s);
+  }
   if (pl.fm == 4) return pl.bn == 128 ? launch_gpipe<4, 128>(p, grid, st) : launch_gpipe<4, 64>(p, grid, st);
   return pl.bn == 128 ? launch_gpipe<3, 128>(p, grid, st) : launch_gpipe<3, 64>(p, grid, st);
 }

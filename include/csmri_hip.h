@@ -105,7 +105,7 @@ typedef struct csmri_gconv_desc {
   /* split-K */
   int splitk;                /* >=1; >1 needs slab */
   float* slab;               /* [splitk][M][Cout] fp32 workspace */
-  int flags;                 /* CSMRI_GCONV_DEFER_REDUCE: caller runs csmri_gconv_reduce itself; CSMRI_GCONV_TAP_MAJOR */
+  int flags;                 /* CSMRI_GCONV_DEFER_REDUCE: caller runs csmri_gconv_reduce itself; CSMRI_GCONV_USE_GPIPE */
   /* optional output window (reflection-padded dgrad without a full fold pass): positions whose
    * tensor coordinate (ty, tx) lies inside [win_y0, win_y0+win_h) x [win_x0, win_x0+win_w) are
    * written to `out`, now a dense [B, win_h, win_w] tensor indexed by (ty-win_y0, tx-win_x0)
@@ -129,7 +129,7 @@ typedef struct csmri_gconv_desc {
   void* out_q; int out_q_pix_stride; const float* out_q_scale; float* out_amax;
 } csmri_gconv_desc;
 #define CSMRI_GCONV_DEFER_REDUCE 1
-#define CSMRI_GCONV_TAP_MAJOR 2     /* diagnostic: the persistent gather kernel walks K tap-major (the pack's order) instead of tap-inner */
+#define CSMRI_GCONV_USE_GPIPE 2     /* take the persistent pipelined gather kernel (gpipe.hip) where it is eligible (opt-in: DESIGN.md 3.10) */
 
 int csmri_gconv(const csmri_gconv_desc* d, void* stream);
 /* second stage of a split-K launch (slab sum + epilogue); no-op when splitk <= 1 */

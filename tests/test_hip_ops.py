@@ -203,6 +203,7 @@ def test_gpipe_discriminator_layer_forms(hip, case):
   layer, wt, bias, x, pads, mode = make_layer(hip, (name, cin, cout, 4, stride, 'reflection', False, h, w, b), dtype)
   xd = to_dev_nhwc(x, dtype)
   log = ops.LAUNCH_LOG = []
+  old_flags, ops.GCONV_FLAGS = ops.GCONV_FLAGS, 2          # CSMRI_GCONV_USE_GPIPE (the kernel is opt-in)
   try:
     ref = F.conv2d(O.pad2d(x, pads, mode), wt, None, stride=stride)
     m = ref.shape[0] * ref.shape[2] * ref.shape[3]
@@ -231,6 +232,7 @@ def test_gpipe_discriminator_layer_forms(hip, case):
     check(name + ' dgrad gated', from_dev_nhwc(dxg, cin), gated, dtype)
   finally:
     ops.LAUNCH_LOG = None
+    ops.GCONV_FLAGS = old_flags
   names = [e[1] for e in log if e[0] == 'gconv']
   print(name, sorted(set((e[1], e[2]) for e in log if e[0] == 'gconv')))
   assert names and all(n.startswith('gpipe_kernel') for n in names), names

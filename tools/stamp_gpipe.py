@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, 'csmri-refinement_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import torch
 from csmri_hip import ops, lib
+ops.GCONV_FLAGS = 2
 import ctypes as C
 import bench_conv
 
@@ -16,6 +17,7 @@ cin, cout, k, s, border, up, h, w, b = bench_conv.CASES[name]
 dbg = torch.zeros(1 << 20, dtype=torch.int64, device='cuda')
 info = {}
 def patched(d, want_stats, flops=0.0):
+  d.flags = 2
   d.splitk = 1                                  # (stamps are dumped by unsplit launches: the slab pointer carries the buffer)
   d.slab = dbg.data_ptr()
   nm = C.create_string_buffer(96)
@@ -43,11 +45,11 @@ busy = t[:, 0, :].sum(1) > 0
 nb = int(busy.sum())
 t = t[busy]
 print(info['name'], name, mode, 'workgroups with work', nb, 'K steps per item', info['steps'], 'launch %.1f us' % (e0.elapsed_time(e1) * 1e3))
-ld = t[:, 8:12, :4]
+ld = t[:, 8:12, :5]
 cp = t[:, 0:8, :5]
 tot_l, tot_c = ld.sum(2).mean(), cp.sum(2).mean()
 print(' loader waves: %.0f cycles in the step loop per wave' % tot_l)
-for i, n in enumerate(['issue stage s+2 (+ address rebuilds)', 'barrier A', 'vmcnt wait for stage s+1', 'barrier B']):
+for i, n in enumerate(['issue part 1 of stage s+2', 'barrier A', 'vmcnt wait for stage s+1', 'issue part 2 (+ address rebuilds)', 'barrier B']):
   print('   %-40s %9.0f  %5.1f %%' % (n, ld[:, :, i].mean(), 100 * ld[:, :, i].mean() / tot_l))
 print(' compute waves: %.0f cycles in the step loop per wave' % tot_c)
 for i, n in enumerate(['fragment reads + wait', 'barrier A', 'MFMA block', 'epilogue (item ends)', 'barrier B']):
