@@ -447,7 +447,8 @@ static GpPlan gp_plan(const csmri_gconv_desc* d, int forced_sk = 0) {
   const long long M = (long long)d->B * d->Ho * d->Wo;
   const int nsteps = d->TH * d->TW * d->Cin / 64, ntiles = d->Cout / bn;
   const bool stats = d->stats_partial != nullptr;
-  for (int fm = 4; fm >= (stats ? 4 : 3); --fm) {
+  const int fm_hi = (d->flags & 8) ? 3 : 4, fm_lo = (d->flags & 4) ? 4 : (stats ? 4 : 3);      // (tools: flags 4 / 8 force the tile height)
+  for (int fm = fm_hi; fm >= fm_lo; --fm) {
     const int bm = 64 * fm, mtiles = cdiv(M, bm);
     const long long base = (long long)mtiles * ntiles * nclass;
     const double t_intake = (bm + bn) * 128.0 / 70e3, t_mfma = 2.0 * fm * (bn / 32) * 2 * 16 / 2.2e3;   // us per step

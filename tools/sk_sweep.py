@@ -6,6 +6,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'csmri-refinement_amd'))
 from csmri_hip import ops
+ops.GCONV_FLAGS = int(os.environ.get('GCONV_FLAGS', '0'))      # 2 = gpipe where eligible, +4 / +8 = 256- / 192-row tiles
+ONLY = [a for a in sys.argv[1:]]
 
 S = 256
 CASES = [   # name, cin, cout, k, stride, border, H, B, mode
@@ -47,6 +49,8 @@ def timeit(fn, iters=30):
 
 
 for name, cin, cout, k, s, border, h, b, mode in CASES:
+  if ONLY and not any(o in name for o in ONLY):
+    continue
   wt = torch.nn.Parameter((torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)).cuda())
   layer = ops.ConvLayer(wt, None, s, pads_for(k, s), border, torch.bfloat16)
   x = torch.randn(b, h, h, ops.pad8(cin), device='cuda').bfloat16()
@@ -67,7 +71,7 @@ for name, cin, cout, k, s, border, h, b, mode in CASES:
       fn()
       kern = log[0][1]
       ops.LAUNCH_LOG = None
-      res.append((sk, timeit(fn), kern.replace('gconv_glds_kernel', 'glds')))
+      res.append((sk, timeit(fn), kern.replace('gconv_glds_kernel', 'glds').replace('gpipe_kernel', 'gp')))
     except Exception as e:
       ops.LAUNCH_LOG = None
       res.append((sk, float('nan'), repr(e)[:30]))
