@@ -398,7 +398,7 @@ def quantize_fp8(x, amax=None):
 
 
 SPLITK_OVERRIDE = None   # tools/sk_sweep.py only: force the split-K factor of csmri_gconv launches
-GCONV_FLAGS = 0          # or-ed into csmri_gconv_desc.flags (2 = CSMRI_GCONV_USE_GPIPE: the persistent gather kernel, opt-in)
+GCONV_FLAGS = int(os.environ.get('CSMRI_GCONV_FLAGS', '0'))   # or-ed into csmri_gconv_desc.flags (A/B switches of the conv dispatch: 2 / 16 = gpipe everywhere / nowhere)
 
 
 def _gconv_run(d, want_stats, flops=0.0):

@@ -468,6 +468,7 @@ static GpPlan gp_plan(const csmri_gconv_desc* d, int forced_sk = 0) {
 }
 
 int gpipe_eligible(const csmri_gconv_desc* d) {
+  if (d->flags & CSMRI_GCONV_NO_GPIPE) return 0;
   if (!(d->flags & CSMRI_GCONV_USE_GPIPE) && (!GPIPE || d->TH * d->TW * d->Cin / 64 < GPIPE_MIN_STEPS || d->stats_partial)) return 0;
   if (d->dtype != CSMRI_BF16) return 0;
   if (d->Cin % 64 || d->Cout % 64) return 0;

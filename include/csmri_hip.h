@@ -129,7 +129,8 @@ typedef struct csmri_gconv_desc {
   void* out_q; int out_q_pix_stride; const float* out_q_scale; float* out_amax;
 } csmri_gconv_desc;
 #define CSMRI_GCONV_DEFER_REDUCE 1
-#define CSMRI_GCONV_USE_GPIPE 2     /* take the persistent pipelined gather kernel (gpipe.hip) where it is eligible (opt-in: DESIGN.md 3.10) */
+#define CSMRI_GCONV_USE_GPIPE 2     /* take the persistent pipelined gather kernel (gpipe.hip) wherever it is eligible, not only where it measured faster */
+#define CSMRI_GCONV_NO_GPIPE 16     /* never take it (A/B against gconv_glds); 4 / 8: force its 256- / 192-row tile (tools/sk_sweep.py) */
 
 int csmri_gconv(const csmri_gconv_desc* d, void* stream);
 /* second stage of a split-K launch (slab sum + epilogue); no-op when splitk <= 1 */

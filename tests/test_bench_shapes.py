@@ -211,7 +211,7 @@ def test_bench_layer_vs_oracle_bf16(hip, case):
 
 def test_dispatch_variants_are_all_exercised():
   """Every kernel instance the BENCHMARKED step launches (the `conv_kernels` table of the committed bench line,
-  profiles/r04_bench_n1.json: keys are the instance names rocprofv3 prints) has been reached by a bench shape above,
+  profiles/r06_bench_n1.json: keys are the instance names rocprofv3 prints) has been reached by a bench shape above,
   i.e. has been compared with the oracle; a dispatch change that strands an instance, or a bench line taken with a
   build whose instances these shapes no longer reach, fails here."""
   import json
@@ -224,11 +224,11 @@ def test_dispatch_variants_are_all_exercised():
   fam = set(n.split('<')[0].replace('void ', '') for n in names)
   splitk = any(e[2] > 1 and e[0] == 'gconv' for v in SEEN.values() for e in v)
   assert splitk, 'no split-K convolution among the bench shapes'
-  need = {'tconv_kernel', 'uconv_kernel', 'gconv_kernel', 'gconv_glds_kernel', 'pconv2_kernel',
+  need = {'tconv_kernel', 'uconv_kernel', 'gconv_kernel', 'gconv_glds_kernel', 'gpipe_kernel', 'pconv2_kernel',
           'thin_out1_tile_kernel', 'wpatch_kernel', 'wrow_kernel', 'wgrad_glds_row_kernel', 'wthin_out_kernel'}
   assert need <= fam, (need - fam, fam)
-  path = os.path.join(ROOT, 'profiles', 'r05_bench_n1.json')
-  assert os.path.exists(path), 'commit the bench line of this build as profiles/r05_bench_n1.json'
+  path = os.path.join(ROOT, 'profiles', 'r06_bench_n1.json')
+  assert os.path.exists(path), 'commit the bench line of this build as profiles/r06_bench_n1.json'
   table = json.load(open(path))['conv_kernels']
   # second stages / fused blocks that are not csmri_gconv / csmri_wgrad main kernels (covered by tests/test_hip_ops.py)
   other = {'gconv_reduce_kernel', 'convblock_fwd_kernel'}
