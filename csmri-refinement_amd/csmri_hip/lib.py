@@ -27,7 +27,7 @@ _lib = C.CDLL(LIB_PATH)
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
-ABI = 102           # csmri_version() of the library these structures mirror (102: csmri_gconv_desc.out_q .. out_amax)
+ABI = 103           # csmri_version() of the library these structures mirror (103: csmri_adam_dev_lr; 102: csmri_gconv_desc.out_q .. out_amax)
 _lib.csmri_version.restype = C.c_int
 if _lib.csmri_version() != ABI:
   raise RuntimeError('%s reports ABI %d, this binding is for %d: rebuild the library (python __graft_entry__.py)'

@@ -630,7 +630,7 @@ extern "C" int csmri_copy_channels(const void* src, int src_dtype, int src_pix_s
   return CSMRI_OK;
 }
 
-extern "C" int csmri_version(void) { return 102; }   // 101: csmri_dc_in_bf16 takes x_dtype; csmri_dropout2d_mask state is uint64[3]
+extern "C" int csmri_version(void) { return 103; }   // 103: csmri_adam_dev_lr, csmri_gconv_desc.flags dispatch switches; 101: csmri_dc_in_bf16 takes x_dtype; csmri_dropout2d_mask state is uint64[3]
 extern "C" const char* csmri_error_string(int code) {
   switch (code) {
     case CSMRI_OK: return "ok";
