@@ -164,9 +164,9 @@ __global__ __launch_bounds__(768, 1) void gpipe_kernel(const GParams p) {
     // whole stage in the first half made that half 1600 cycles long with the compute waves waiting at its barrier,
     // profiles/r06_gpipe_stamps1.log): pieces [0, N1) = the first N1 of {A pieces, then B pieces}, pieces [N1, NP) the rest.
 #ifndef GPIPE_N1_NUM
-#define GPIPE_N1_NUM 6
+#define GPIPE_N1_NUM 8        // swept 5 / 6 / 7 / 8 tenths on ten launches: 448 / 441 / 441 / 437 us in all (profiles/r06_gpipe_n1.log)
 #endif
-    constexpr int N1 = (NP * GPIPE_N1_NUM + 9) / 10;                  // first part: 60 % of the pieces (the second half also holds the wait)
+    constexpr int N1 = (NP * GPIPE_N1_NUM + 9) / 10;                  // first part: 80 % of the pieces (the second half also holds the wait and the tap / item bookkeeping)
     unsigned ring = 0;
     auto issue_part = [&](auto part_c) __attribute__((always_inline)) {
       constexpr int part = decltype(part_c)::value;
