@@ -667,9 +667,12 @@ class AdversarialRunner(BaseRunner):
     self._graph = None
 
   def __del__(self):
-    g = getattr(self, '_graph', None)
-    if g is not None:
-      retire_graphs(g)
+    try:
+      g = getattr(self, '_graph', None)
+      if g is not None:
+        retire_graphs(g)
+    except Exception:       # interpreter shutdown: module globals are already gone, and so is the need
+      pass
 
   def _run_segments_graphed(self, batch, batch_next=None, pre_cur=None):
     from csmri_hip import ops

@@ -187,9 +187,12 @@ class Runner(BaseRunner):
     self._graph = None
 
   def __del__(self):
-    if getattr(self, '_graph', None) is not None:
-      from training.adversarial_runner import retire_graphs
-      retire_graphs(self._graph)
+    try:
+      if getattr(self, '_graph', None) is not None:
+        from training.adversarial_runner import retire_graphs
+        retire_graphs(self._graph)
+    except Exception:       # interpreter shutdown
+      pass
 
   def _train_step(self, loader):
     batch = self._request_data(loader)
